@@ -1,0 +1,344 @@
+#!/usr/bin/env python3
+"""Capture golden input/output vectors from the reference itself (runs in the BUILD container only).
+
+Imports ``mpd.models`` from /root/reference (read-only mount, never present on the GPU box),
+loads the repo's own seeded synthetic weights (ramp_amd/synth.py) into it, injects noise by
+patching ``torch.randn`` / ``torch.randn_like`` and writes small ``.npz`` fixtures to
+tests/golden/.  The fixtures hold DATA only (inputs, expected outputs, a few intermediate
+activations / gradients), never reference source text.
+
+    python oracle/make_goldens.py            # regenerates every fixture (≈2-4 min on 8 cores)
+
+What is captured:
+  schedule_T{25,50,100}.npz   the 12 schedule buffers
+  unet2d_h48.npz              forward_no_energy, eps, per-module outputs + output-grads (N=4 rows)
+  unet3d_h48.npz / h64        same for the 3-D net (N=2 rows: cond, uncond)
+  scene_latents.npz           2-D 6x64 / 16x64 clouds, 3-D 5x50 / 20x200 clouds
+  chain_ddpm_*.npz            full T=25 DDPM chains, B=4, with / without APF, with extra no-noise steps
+  chain_ddim_*.npz            DDIM-5 of T=100 chains, with / without APF
+  chain3d_ddpm.npz            3-D DDPM T=25: B independent n_samples=1 runs stacked
+  apf_cases.npz               avoidance() in/out pairs (hits, no-hit early-out, window clipped at ends)
+  cost_cases.npz              compute_collision_with_pointcloud / compute_trajectory_costs
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("RAMP_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from ramp_amd import synth  # noqa: E402
+from ramp_amd.spec import make_unet_spec, unet_param_shapes, SCHEDULE_BUFFERS  # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from mpd.models import (TemporalUnetInference, UNET_DIM_MULTS, StaticGaussianDiffusionModel,  # noqa: E402
+                            GaussianDiffusionModel3d)
+    from mpd.models.diffusion_models.sample_functions import ddpm_sample_fn  # noqa: E402
+    from mpd.models.diffusion_models.APFhelper import ObstacleField, avoidance  # noqa: E402
+    from mpd.models.diffusion_models import cost as ref_cost  # noqa: E402
+    from mpd.models.diffusion_models.obstacle_encoder import ObstacleEncoderSet  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def build_unet(state_dim, horizon, obstacle_3d, seed=0):
+    sp = make_unet_spec(state_dim, horizon, obstacle_3d=obstacle_3d)
+    sd = synth.make_unet_state_dict(sp, seed=seed)
+    m = quiet(TemporalUnetInference, n_support_points=horizon, state_dim=state_dim, unet_input_dim=32,
+              dim_mults=UNET_DIM_MULTS[1], obstacle_3d=obstacle_3d)
+    ref_sd = m.state_dict()
+    assert set(ref_sd.keys()) == set(sd.keys()), "spec.py key name mismatch with reference"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(sd[k].shape), (k, v.shape, sd[k].shape)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m.eval()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m, sp, sd
+
+
+class NoiseInjector:
+    """Replace torch.randn / randn_like by a pre-generated list (consumed in call order)."""
+
+    def __init__(self, tensors):
+        self.q = list(tensors)
+        self.used = 0
+
+    def __enter__(self):
+        self._randn, self._randn_like = torch.randn, torch.randn_like
+
+        def randn(*shape, **kw):
+            if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+                shape = tuple(shape[0])
+            t = self.q[self.used]
+            self.used += 1
+            assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+            return t.clone()
+
+        def randn_like(x, **kw):
+            t = self.q[self.used]
+            self.used += 1
+            assert t.shape == x.shape
+            return t.clone()
+
+        torch.randn, torch.randn_like = randn, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._randn, self._randn_like
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_schedules(unet2d):
+    for T in (25, 50, 100):
+        dm = quiet(StaticGaussianDiffusionModel, model=unet2d, variance_schedule="exponential",
+                   n_diffusion_steps=T, predict_epsilon=True)
+        save(f"schedule_T{T}.npz", **{k: getattr(dm, k).numpy() for k in SCHEDULE_BUFFERS})
+
+
+def hook_modules(m, names):
+    """forward hooks capturing module outputs and (through tensor hooks) grads w.r.t. those outputs."""
+    outs, grads, handles = OrderedDict(), OrderedDict(), []
+    mods = dict(m.named_modules())
+    for n in names:
+        def fh(mod, inp, out, n=n):
+            outs[n] = out.detach().clone()
+            if out.requires_grad:
+                out.register_hook(lambda g, n=n: grads.__setitem__(n, g.detach().clone()))
+        handles.append(mods[n].register_forward_hook(fh))
+    return outs, grads, handles
+
+
+def module_names(sp):
+    names = []
+    for k, lv in enumerate(sp.downs):
+        names += [f"downs.{k}.0", f"downs.{k}.1", f"downs.{k}.3"]
+        if lv.resample:
+            names.append(f"downs.{k}.4")
+    names += ["mid_block1", "mid_attention", "mid_block2"]
+    for k, lv in enumerate(sp.ups):
+        names += [f"ups.{k}.0", f"ups.{k}.1", f"ups.{k}.3", f"ups.{k}.4"]
+    return names
+
+
+def cl(t):  # (N,C,L) -> channels-last (N,L,C)
+    return t.permute(0, 2, 1).contiguous().numpy()
+
+
+def gen_unet(tag, m, sp, cloud, n_rows, t_val, seed):
+    """One score-net evaluation with per-module taps. cloud (No,Np,D)."""
+    H, S = sp.horizon, sp.state_dim
+    x = torch.from_numpy(synth.make_noise((n_rows, H, S), seed=seed))
+    t = torch.full((n_rows,), t_val, dtype=torch.long)
+    pts = torch.from_numpy(cloud)[None].repeat(n_rows, 1, 1, 1)
+    m.reset_cache()
+    lat_full = m.scene_encoder(pts[:1])[0].detach().numpy()
+    names = module_names(sp)
+    outs, grads, handles = hook_modules(m, names)
+    m.reset_cache()
+    eps = m(x, t, None, obstacle_pts=pts).detach()
+    for h in handles:
+        h.remove()
+    m.reset_cache()
+    with torch.no_grad():
+        f = m.forward_no_energy(x, t, obstacle_pts=pts)
+    # time embedding
+    temb = m.time_mlp(t).detach().numpy()
+    arrs = dict(x=x.numpy(), t=t.numpy(), cloud=cloud, latent=lat_full, f=f.numpy(), eps=eps.numpy(), temb=temb)
+    for n in names:
+        arrs["out/" + n] = cl(outs[n])
+        if n in grads:
+            arrs["gout/" + n] = cl(grads[n])
+    save(f"unet{tag}.npz", **arrs)
+
+
+def gen_scene_latents(m2, m3):
+    arrs = {}
+    c = synth.make_cloud(6, 64, 2, seed=42)
+    arrs["cloud2d_6x64"] = c
+    arrs["lat2d_6x64"] = m2.scene_encoder(torch.from_numpy(c)[None])[0].detach().numpy()
+    enc16 = ObstacleEncoderSet(num_obstacles=16)
+    enc16.load_state_dict(m2.scene_encoder.state_dict())
+    enc16.eval()
+    c = synth.make_cloud(16, 64, 2, seed=43)
+    arrs["cloud2d_16x64"] = c
+    arrs["lat2d_16x64"] = enc16(torch.from_numpy(c)[None])[0].detach().numpy()
+    for (no, npnt, sd) in ((5, 50, 44), (20, 200, 45)):
+        c = synth.make_cloud(no, npnt, 3, seed=sd)
+        arrs[f"cloud3d_{no}x{npnt}"] = c
+        arrs[f"lat3d_{no}x{npnt}"] = m3.scene_encoder(torch.from_numpy(c)[None])[0].detach().numpy()
+    save("scene_latents.npz", **arrs)
+
+
+def run_static(unet, sp, T, B, cloud, noise, ddim, use_apf, n_without_noise=0):
+    dm = quiet(StaticGaussianDiffusionModel, model=unet, variance_schedule="exponential", n_diffusion_steps=T,
+               predict_epsilon=True, compose=False, use_apf=use_apf)
+    dm.eval()
+    dm.ddim = ddim
+    unet.reset_cache()
+    hc = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(sp.state_dim, sp.horizon).items()}
+    pts = torch.from_numpy(cloud)
+    with NoiseInjector([torch.from_numpy(n) for n in noise]) as inj:
+        chain = dm.run_inference(None, hc, n_samples=B, horizon=sp.horizon, return_chain=True,
+                                 traj_normalized=torch.zeros(sp.horizon, sp.state_dim), obstacle_pts=pts,
+                                 sample_fn=ddpm_sample_fn, guide=None, n_guide_steps=1, t_start_guide=7,
+                                 noise_std_extra_schedule_fn=lambda x: 0.5,
+                                 n_diffusion_steps_without_noise=n_without_noise)
+        used = inj.used
+    return chain.detach().numpy(), used
+
+
+def gen_chains(m2, sp2):
+    B, H, S = 4, sp2.horizon, sp2.state_dim
+    cloud = synth.make_cloud(6, 64, 2, seed=42)
+    m2.reset_cache()
+    latent = m2.scene_encoder(torch.from_numpy(cloud)[None])[0].detach().numpy()
+    # DDPM T=25
+    for tag, apf, nwn in (("plain", False, 0), ("apf", True, 0), ("extra2", False, 2)):
+        n_steps = 25 + nwn
+        noise = synth.make_noise((n_steps + 1, B, H, S), seed=1234)
+        chain, used = run_static(m2, sp2, 25, B, cloud, noise, ddim=False, use_apf=apf, n_without_noise=nwn)
+        assert used == n_steps + 1 and chain.shape == (n_steps + 1, B, H, S), (used, chain.shape)
+        save(f"chain_ddpm_{tag}.npz", chain=chain, noise=noise, cloud=cloud, latent=latent, T=25,
+             n_without_noise=nwn, use_apf=apf)
+    # DDIM-5 of T=100 (script default mode)
+    for tag, apf in (("plain", False), ("apf", True)):
+        noise = synth.make_noise((1, B, H, S), seed=4321)
+        chain, used = run_static(m2, sp2, 100, B, cloud, noise, ddim=True, use_apf=apf, n_without_noise=5)
+        assert used == 1 and chain.shape == (6, B, H, S)
+        save(f"chain_ddim_{tag}.npz", chain=chain, noise=noise, cloud=cloud, latent=latent, T=100, K=5, use_apf=apf)
+
+
+def gen_chain3d(m3, sp3):
+    H, S, T, B = sp3.horizon, sp3.state_dim, 25, 2
+    cloud = synth.make_cloud(5, 50, 3, seed=44)
+    m3.reset_cache()
+    latent = m3.scene_encoder(torch.from_numpy(cloud)[None])[0].detach().numpy()
+    noise = synth.make_noise((T + 1, B, H, S), seed=777)
+    chains = []
+    for b in range(B):
+        dm = quiet(GaussianDiffusionModel3d, model=m3, variance_schedule="exponential", n_diffusion_steps=T,
+                   predict_epsilon=True, compose=False, use_apf=False)
+        dm.eval()
+        m3.reset_cache()
+        hc = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(S, H).items()}
+        with NoiseInjector([torch.from_numpy(noise[j, b:b + 1]) for j in range(T + 1)]) as inj:
+            chain = dm.run_inference(None, hc, n_samples=1, horizon=H, return_chain=True,
+                                     traj_normalized=torch.zeros(H, S), obstacle_pts=torch.from_numpy(cloud),
+                                     sample_fn=ddpm_sample_fn, guide=None, n_guide_steps=1, t_start_guide=7,
+                                     noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=0)
+            assert inj.used == T + 1
+        chains.append(chain.detach().numpy())
+    chain = np.concatenate(chains, axis=1)
+    save("chain3d_ddpm.npz", chain=chain, noise=noise, cloud=cloud, latent=latent, T=T, w=5.75)
+
+
+def gen_apf():
+    arrs = {}
+    cloud = synth.make_cloud(6, 64, 2, seed=42).reshape(-1, 2)
+    g = np.random.Generator(np.random.PCG64(99))
+    cases = {}
+    # (a) random trajectories over the workspace: many hits
+    cases["rand"] = (g.uniform(-1, 1, size=(3, 48, 4)).astype(np.float32), cloud, 0.07, 0.1, 5)
+    # (b) straight line start->goal, window 7
+    lin = np.linspace(-0.8, 0.8, 48, dtype=np.float32)
+    tr = np.zeros((2, 48, 4), np.float32)
+    tr[0, :, 0] = lin; tr[0, :, 1] = lin
+    tr[1, :, 0] = lin; tr[1, :, 1] = -lin
+    cases["line"] = (tr, cloud, 0.07, 0.1, 7)
+    # (c) no hit: cloud far away -> early-out returns the input unchanged
+    cases["nohit"] = (g.uniform(-0.2, 0.2, size=(2, 48, 4)).astype(np.float32), cloud + 5.0, 0.07, 0.1, 5)
+    # (d) hits only at the first / last waypoints: window clipped at both ends
+    tr = np.full((2, 48, 4), 3.0, np.float32)
+    tr[0, 0, :2] = cloud[10] + np.float32(0.01)
+    tr[0, 1, :2] = cloud[11] - np.float32(0.02)
+    tr[1, 47, :2] = cloud[200] + np.float32(0.03)
+    cases["ends"] = (tr, cloud, 0.07, 0.1, 7)
+    # (e) larger cloud / threshold
+    cloud16 = synth.make_cloud(16, 64, 2, seed=43).reshape(-1, 2)
+    cases["big"] = (g.uniform(-1, 1, size=(4, 48, 4)).astype(np.float32), cloud16, 0.1, 0.2, 7)
+    for name, (traj, cl_, thr, strength, win) in cases.items():
+        field = ObstacleField(cl_, distance_threshold=thr)
+        out = avoidance(torch.from_numpy(traj.copy()), field, avoidance_window=win, avoidance_strength=strength)
+        arrs[f"{name}/traj"] = traj
+        arrs[f"{name}/cloud"] = cl_
+        arrs[f"{name}/params"] = np.array([thr, strength, win], np.float64)
+        arrs[f"{name}/out"] = out.numpy()
+        print(f"    apf case {name}: changed elements = {(out.numpy() != traj).sum()}")
+    save("apf_cases.npz", **arrs)
+
+
+def gen_cost():
+    cloud = synth.make_cloud(6, 64, 2, seed=42)
+    g = np.random.Generator(np.random.PCG64(5))
+    base = np.linspace(-0.8, 0.8, 48, dtype=np.float32)
+    trajs = np.zeros((10, 48, 4), np.float32)
+    for b in range(10):
+        if b % 2 == 0:   # diagonal-ish paths through the obstacle field (mostly colliding)
+            trajs[b, :, 0] = base + 0.05 * g.standard_normal(48).astype(np.float32)
+            trajs[b, :, 1] = base * (1 if b % 4 == 0 else -1) + 0.3 * np.sin(np.linspace(0, 3, 48)).astype(np.float32) * b / 8
+        else:            # paths hugging the workspace border (x = -0.97), free of every box
+            trajs[b, :, 0] = -0.97 + 0.005 * g.standard_normal(48).astype(np.float32) * b
+            trajs[b, :, 1] = base * (0.5 + 0.05 * b)
+        trajs[b, 1:, 2:] = np.diff(trajs[b, :, :2], axis=0)
+    arrs = dict(trajs=trajs, cloud=cloud)
+    for thr in (0.02, 0.05, 0.1):
+        mask = ref_cost.compute_collision_with_pointcloud(torch.from_numpy(trajs), torch.from_numpy(cloud), thr)
+        arrs[f"mask_{thr}"] = mask.numpy()
+        print(f"    collision mask thr={thr}: {mask.numpy().astype(int)}")
+    best, best_cost, total, free, idx = quiet(ref_cost.compute_trajectory_costs, torch.from_numpy(trajs),
+                                              torch.from_numpy(cloud), collision_threshold=0.05)
+    assert best is not None
+    arrs["best"] = best.numpy(); arrs["total_costs"] = total.numpy(); arrs["best_index"] = int(idx)
+    arrs["free_mask"] = free.numpy()
+    arrs["path_length"] = ref_cost.compute_path_length(torch.from_numpy(trajs)).numpy()
+    arrs["smoothness"] = ref_cost.compute_smoothness(torch.from_numpy(trajs)).numpy()
+    save("cost_cases.npz", **arrs)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cost":
+        gen_cost(); return
+    if len(sys.argv) > 1 and sys.argv[1] == "apf":
+        gen_apf(); return
+    print("building reference models with synthetic weights ...")
+    m2, sp2, _ = build_unet(4, 48, False)
+    m3, sp3, _ = build_unet(6, 48, True)
+    m3b, sp3b, _ = build_unet(6, 64, True)
+    print("schedules"); gen_schedules(m2)
+    print("unet taps")
+    gen_unet("2d_h48", m2, sp2, synth.make_cloud(6, 64, 2, seed=42), 4, 7, seed=10)
+    gen_unet("3d_h48", m3, sp3, synth.make_cloud(5, 50, 3, seed=44), 2, 3, seed=11)
+    gen_unet("3d_h64", m3b, sp3b, synth.make_cloud(5, 50, 3, seed=44), 2, 20, seed=12)
+    print("scene latents"); gen_scene_latents(m2, m3)
+    print("apf"); gen_apf()
+    print("cost"); gen_cost()
+    print("chains 2-D"); gen_chains(m2, sp2)
+    print("chain 3-D"); gen_chain3d(m3, sp3)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
