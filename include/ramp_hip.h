@@ -1,0 +1,171 @@
+/* ramp_hip.h — C ABI of the MI355X-native RAMP trajectory sampler (libramp_hip.so, gfx950).
+ *
+ * The reference (wondmgezahu/RAMP) has no FFI: its boundary for this path is two Python
+ * nn.Module surfaces.  Each entry point below names the reference call it
+ * replaces; the Python shim in ramp_amd/ binds them with ctypes and re-creates the reference's
+ * own signatures on top (INTEGRATION.md shows the stub a RAMP maintainer would add).
+ *
+ * Conventions: every function returns 0 on success, a negative code on failure with a message
+ * available from ramp_last_error().  All tensor pointers are DEVICE pointers to contiguous fp32
+ * (or int32 where noted) owned by the caller (e.g. torch tensors' data_ptr()) unless a parameter
+ * is documented as host memory.  `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  A context is bound to the HIP device current at creation; it is thread-compatible,
+ * not thread-safe.  Layouts: trajectories (B, H, S) row-major exactly as the reference's
+ * `x : [batch x horizon x state_dim]` (UnetInference.py:177-181); network rows are interleaved
+ * per trajectory [variant 0, variant 1, (variant 2)] like `repeat_interleave`
+ * (diffusion_model_static.py:131-147).
+ */
+#ifndef RAMP_HIP_H
+#define RAMP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ramp_ctx ramp_ctx;
+
+/* Architecture of TemporalUnetInference.__init__ (UnetInference.py:42-56, 93-145). */
+typedef struct ramp_config {
+  int32_t state_dim;       /* S: 4 (Maze2D) or 6 (Maze3D)                              */
+  int32_t horizon;         /* H = n_support_points, multiple of 8, <= 128              */
+  int32_t unet_input_dim;  /* 32                                                       */
+  int32_t n_levels;        /* len(dim_mults) = 4 for UNET_DIM_MULTS[1] = (1,2,4,8)      */
+  int32_t context_dim;     /* 320 (2-D scene encoder) or 256 (3-D)                     */
+  int32_t max_rows;        /* capacity in network rows per chunk (rows = B * n_rp)     */
+  int32_t debug_taps;      /* 1: keep per-module outputs / output-grads for ramp_debug_read */
+  int32_t reserved;
+} ramp_config;
+
+const char* ramp_last_error(void);
+int ramp_version(void);
+
+/* nn.Module construction / .to(device)  (inference_static.py:99-105). */
+int ramp_create(const ramp_config* cfg, ramp_ctx** out);
+int ramp_destroy(ramp_ctx* ctx);
+
+/* load_state_dict (inference_static.py:107-111): one call per U-Net tensor, `name` is the
+ * reference key without the leading "model." (e.g. "downs.0.0.blocks.0.block.0.weight").
+ * `data` is HOST memory, fp32, `shape[ndim]` as in the checkpoint.  scene_encoder.* keys are
+ * accepted and ignored here (the scene encoder runs once per scene above this ABI). */
+int ramp_load_weight(ramp_ctx* ctx, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* after the last ramp_load_weight: verifies every required tensor arrived, packs GEMM layouts. */
+int ramp_finalize_weights(ramp_ctx* ctx);
+
+/* time_mlp + every cond_mlp for t = 0..T-1 (layers.py:233-259, 340-344): the reference evaluates
+ * these inside each forward; t is identical across the batch (make_timesteps,
+ * diffusion_model_static.py:16-18) so they are tabulated once. */
+int ramp_prepare_time_table(ramp_ctx* ctx, int32_t T, void* stream);
+
+/* cache_scene_encoding + latent masking + attn2 (UnetInference.py:146-156,190-197;
+ * layers_attention_mini.py:101-127): `latents` (n_variants, context_dim); an unconditional
+ * variant is an all-zero row.  Row r of the network uses variant row_variant[r] (int32, HOST
+ * array of length n_rows_pattern, applied cyclically: [0,1] = CFG, [0,1,2] = compose). */
+int ramp_set_scene(ramp_ctx* ctx, const float* latents, int32_t n_variants,
+                   const int32_t* row_variant_host, int32_t n_rows_pattern, void* stream);
+
+/* TemporalUnetInference.forward / forward_no_energy (UnetInference.py:157-224).
+ * x (B,H,S); each trajectory is evaluated n_rp times (rows b*n_rp + v).  f_out (B*n_rp,H,S)
+ * receives forward_no_energy's output, eps_out (B*n_rp,H,S) the energy gradient; either may be
+ * NULL.  t is the (batch-uniform) diffusion timestep, 0 <= t < T of the prepared table. */
+int ramp_score(ramp_ctx* ctx, const float* x, int32_t B, int32_t n_rp, int32_t t,
+               float* f_out, float* eps_out, void* stream);
+
+/* ---- sampler loops: run_inference -> conditional_sample -> p_sample_loop / ddim_p_sample_loop
+ *      (diffusion_model_static.py:232-256, 347-384, 438-463; diffusion_model_3d.py:185-218) ---- */
+typedef struct ramp_apf_params {
+  const float* cloud;      /* device (P,2) obstacle points, or NULL = APF off             */
+  int32_t n_points;
+  int32_t window;          /* avoidance_window                                            */
+  const float* window_weights_host; /* host (2*window+1) Gaussian weights (APFhelper.py:42-44) */
+  double threshold;        /* distance_threshold                                          */
+  double strength;         /* avoidance_strength                                          */
+  int32_t passes;          /* DDIM: 3 sequential passes with hard-conditioning; DDPM: 1   */
+  int32_t reserved;
+} ramp_apf_params;
+
+typedef struct ramp_sample_params {
+  int32_t B;               /* trajectories                                                */
+  int32_t n_rp;            /* 2 = CFG, 3 = compose                                        */
+  int32_t n_steps;         /* loop iterations                                             */
+  int32_t ddim;            /* 0 = DDPM (ddpm_sample_fn), 1 = DDIM eta=0                   */
+  double w0, w1;           /* guidance weights (w for CFG; w1,w2 for compose)             */
+  /* per-iteration HOST arrays of length n_steps (computed by the caller exactly like the
+   * reference's registered buffers / extract(): see ramp_amd/diffusion.py) */
+  const int32_t* t;              /* timestep fed to the network                          */
+  const float* sqrt_recip;       /* sqrt_recip_alphas_cumprod[t]                          */
+  const float* sqrt_recipm1;     /* sqrt_recipm1_alphas_cumprod[t]                        */
+  const float* coef1;            /* posterior_mean_coef1[t]         (DDPM)                */
+  const float* coef2;            /* posterior_mean_coef2[t]         (DDPM)                */
+  const float* stdv;             /* exp(0.5*posterior_log_variance_clipped[t]) (DDPM)     */
+  const int32_t* use_noise;      /* 0 where t == 0                  (DDPM)                */
+  const float* sqrt_a_t;         /* alphas_cumprod[t]**0.5          (DDIM)                */
+  const float* sqrt_1m_a_t;      /* (1-alphas_cumprod[t])**0.5      (DDIM)                */
+  const float* sqrt_a_prev;      /* alpha_prod_t_prev**0.5          (DDIM)                */
+  const float* dir_coef;         /* (1-alpha_prod_t_prev)**0.5      (DDIM)                */
+  const int32_t* apply_apf;      /* 1 on iterations where the APF hook fires              */
+  const float* noise_scale;      /* noise_std_extra_schedule_fn(t) per iteration (scripts: 0.5); NULL = 1.0 */
+  int32_t clip_denoised;
+  int32_t reserved0;
+  /* hard conditioning (sample_functions.py:5-10) */
+  int32_t n_hard;                /* number of conditioned waypoints                       */
+  const int32_t* hard_idx_host;  /* host (n_hard) waypoint indices                        */
+  const float* hard_val;         /* device (n_hard, B, S)                                 */
+  ramp_apf_params apf;
+  int32_t use_graph;             /* 1: capture the whole loop in a hipGraph and replay it */
+  int32_t reserved;
+} ramp_sample_params;
+
+/* noise: device (n_steps+1, B, H, S) for DDPM — noise[0] = x_T, noise[1+j] the randn_like of
+ * iteration j; for DDIM only noise[0] is read.  chain_out: device (n_steps+1, B, H, S) or NULL.
+ * x_out: device (B,H,S) final trajectories or NULL. */
+int ramp_sample(ramp_ctx* ctx, const ramp_sample_params* p, const float* noise, float* chain_out,
+                float* x_out, void* stream);
+
+/* ---- kernel-level entry points (same kernels the loops use; exported for parity tests) ---- */
+/* avoidance(trajectories, ObstacleField(cloud, thr), window, strength) in place (APFhelper.py:37-104) */
+int ramp_apf(float* traj, int32_t B, int32_t H, int32_t S, const ramp_apf_params* p, void* stream);
+/* apply_hard_conditioning (sample_functions.py:5-10); idx host, val device (n,B,S) */
+int ramp_hard_cond(float* x, int32_t B, int32_t H, int32_t S, int32_t n, const int32_t* idx_host,
+                   const float* val, void* stream);
+/* compute_collision_with_pointcloud + compute_path_length + compute_smoothness (cost.py:3-54):
+ * mask (B) int32, path_len (B), smooth (B) */
+int ramp_traj_costs(const float* traj, int32_t B, int32_t H, int32_t S, const float* cloud, int32_t n_points,
+                    float threshold, int32_t* mask, float* path_len, float* smooth, void* stream);
+/* one p_mean_variance evaluation given eps (diffusion_model_static.py:161-172) */
+int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32_t n_rp, double w0, double w1,
+                  float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip,
+                  float* x0_out, float* mean_out, float* ecomb_out, void* stream);
+/* generic fp32 MFMA GEMM with taps: C[M,N] = sum_tap shift(A)[M,K] W[tap][N][K]^T + bias + resid */
+int ramp_op_gemm(const float* A, const float* W, const float* bias, const float* resid, float* C,
+                 int32_t M, int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step,
+                 int32_t L, void* stream);
+int ramp_op_groupnorm(const float* x, const float* gamma, const float* beta, const float* tbias,
+                      const float* resid, float* y, float* stats, int32_t R, int32_t L, int32_t C,
+                      float eps, int32_t mish, void* stream);
+int ramp_op_groupnorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
+                          const float* beta, const float* add, float* dx, int32_t R, int32_t L, int32_t C,
+                          int32_t mish, void* stream);
+int ramp_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t n_tok, void* stream);
+int ramp_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
+                          int32_t n_tok, void* stream);
+int ramp_op_geglu(const float* ag, float* hg, int32_t n_tok, int32_t F, void* stream);
+int ramp_op_geglu_bwd(const float* dhg, const float* ag, float* dag, int32_t n_tok, int32_t F, void* stream);
+int ramp_op_attention(const float* qkv, float* o, int32_t R, int32_t L, void* stream);
+int ramp_op_attention_bwd(const float* qkv, const float* dout, float* dqkv, int32_t R, int32_t L, void* stream);
+
+/* debug taps (cfg.debug_taps = 1): kind "out" = module output, "gout" = dE/d(module output) of
+ * the last ramp_score call; module names as in the reference ("downs.0.3", "mid_block1", ...).
+ * Copies min(n_floats, available) floats, channels-last (rows, L, C); returns count via *n_copied. */
+int ramp_debug_read(ramp_ctx* ctx, const char* kind, const char* module, float* out, int64_t n_floats,
+                    int64_t* n_copied, void* stream);
+
+/* bookkeeping for bench / profiling */
+int ramp_workspace_bytes(ramp_ctx* ctx, int64_t* bytes);
+int ramp_launch_count(ramp_ctx* ctx, int64_t* kernels_last_score);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAMP_HIP_H */

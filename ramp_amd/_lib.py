@@ -1,0 +1,119 @@
+"""ctypes binding of libramp_hip.so (the C ABI declared in include/ramp_hip.h).
+
+There is no CPU fallback: if the library is missing, or fails to load, every use raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libramp_hip.so")
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+
+
+class RampConfig(C.Structure):
+    _fields_ = [("state_dim", C.c_int32), ("horizon", C.c_int32), ("unet_input_dim", C.c_int32),
+                ("n_levels", C.c_int32), ("context_dim", C.c_int32), ("max_rows", C.c_int32),
+                ("debug_taps", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RampApfParams(C.Structure):
+    _fields_ = [("cloud", C.c_void_p), ("n_points", C.c_int32), ("window", C.c_int32),
+                ("window_weights_host", c_f32p), ("threshold", C.c_double), ("strength", C.c_double),
+                ("passes", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RampSampleParams(C.Structure):
+    _fields_ = [("B", C.c_int32), ("n_rp", C.c_int32), ("n_steps", C.c_int32), ("ddim", C.c_int32),
+                ("w0", C.c_double), ("w1", C.c_double),
+                ("t", c_i32p), ("sqrt_recip", c_f32p), ("sqrt_recipm1", c_f32p), ("coef1", c_f32p),
+                ("coef2", c_f32p), ("stdv", c_f32p), ("use_noise", c_i32p), ("sqrt_a_t", c_f32p),
+                ("sqrt_1m_a_t", c_f32p), ("sqrt_a_prev", c_f32p), ("dir_coef", c_f32p), ("apply_apf", c_i32p),
+                ("noise_scale", c_f32p), ("clip_denoised", C.c_int32), ("reserved0", C.c_int32),
+                ("n_hard", C.c_int32), ("hard_idx_host", c_i32p), ("hard_val", C.c_void_p),
+                ("apf", RampApfParams), ("use_graph", C.c_int32), ("reserved", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/ramp_hip.h
+PROTOTYPES = {
+    "ramp_last_error": (C.c_char_p, []),
+    "ramp_version": (C.c_int, []),
+    "ramp_create": (C.c_int, [C.POINTER(RampConfig), C.POINTER(C.c_void_p)]),
+    "ramp_destroy": (C.c_int, [C.c_void_p]),
+    "ramp_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, c_f32p, c_i64p, C.c_int32]),
+    "ramp_finalize_weights": (C.c_int, [C.c_void_p]),
+    "ramp_prepare_time_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ramp_set_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_i32p, C.c_int32, C.c_void_p]),
+    "ramp_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                             C.c_void_p]),
+    "ramp_sample": (C.c_int, [C.c_void_p, C.POINTER(RampSampleParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p]),
+    "ramp_apf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RampApfParams), C.c_void_p]),
+    "ramp_hard_cond": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p,
+                                 C.c_void_p]),
+    "ramp_traj_costs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ramp_cfg_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
+    "ramp_op_gemm": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]),
+    "ramp_op_groupnorm": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p]),
+    "ramp_op_groupnorm_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p]),
+    "ramp_op_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]),
+    "ramp_op_layernorm_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_void_p]),
+    "ramp_op_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "ramp_op_geglu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "ramp_op_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "ramp_op_attention_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "ramp_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64, c_i64p, C.c_void_p]),
+    "ramp_workspace_bytes": (C.c_int, [C.c_void_p, c_i64p]),
+    "ramp_launch_count": (C.c_int, [C.c_void_p, c_i64p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class RampHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libramp_hip.so and bind every prototype.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RampHipError(f"{LIB_PATH} not found: build it with `python -m ramp_amd.build` "
+                           "(hipcc --offload-arch=gfx950). The RAMP sampler has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ramp_last_error()
+        raise RampHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device (or host) address of a contiguous torch tensor, None for None."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream() -> Optional[int]:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,65 @@
+"""Build libramp_hip.so (gfx950) in-tree with hipcc.  `python -m ramp_amd.build` or build()."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libramp_hip.so")
+SOURCES = ["gemm.hip", "rowops.hip", "sampler.hip", "engine.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# sampler.hip mirrors the reference's elementwise fp32 expressions rounding for rounding: hipcc's default
+# -ffp-contract=fast would fuse a*b - c*d into an FMA (HIP's __fmul_rn is a plain multiply), so it is off there.
+EXTRA_FLAGS = {"sampler.hip": ["-ffp-contract=off"]}
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ramp_hip.h")]
+    jobs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _stale(op, [sp] + headers):
+            jobs.append((sp, op))
+
+    def compile_one(job):
+        sp, op = job
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(sp), []) + ["-c", sp, "-o", op]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {sp}:\n{r.stderr[-4000:]}")
+        return sp
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            for sp in ex.map(compile_one, jobs):
+                if verbose:
+                    print(f"[ramp_amd.build] compiled {os.path.basename(sp)}", file=sys.stderr)
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[ramp_amd.build] linked {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,157 @@
+// Shared declarations for the RAMP sampler HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace ramp {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_last_error(const std::string& msg);
+const char* last_error_cstr();
+
+#define RAMP_HIP_CHECK(expr)                                                                   \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      ::ramp::set_last_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " \
+                             + __FILE__ + ":" + std::to_string(__LINE__));                     \
+      return -1;                                                                               \
+    }                                                                                          \
+  } while (0)
+
+#define RAMP_REQUIRE(cond, msg)                                                       \
+  do {                                                                                \
+    if (!(cond)) {                                                                    \
+      ::ramp::set_last_error(std::string("requirement failed: ") + #cond + " — " + (msg) + \
+                             " at " + __FILE__ + ":" + std::to_string(__LINE__));     \
+      return -2;                                                                      \
+    }                                                                                 \
+  } while (0)
+
+// ---- GEMM -----------------------------------------------------------------------------------
+// C[m, n] = sum_{tap<taps} sum_{k<K} Asrc(m + shift0 + tap*shift_step)[k] * W[tap][n][k]
+//           (+ bias[n]) (+ rowbias[rowvar[row0 + m / L]][n]) (+ resid[m, n]) (+ resid2[m, n])
+// A rows are tokens of segments ("trajectory rows") of length L; a shifted source row that
+// leaves its segment reads as zero (Conv1d zero padding).  The reduction dimension may be
+// split over two sources: k < K1 from A, k >= K1 from A2 (channel concat without a copy).
+// The output may be split over two destinations: n < N1 to C, n >= N1 to C2.
+struct GemmArgs {
+  const float* A = nullptr;  int lda = 0;
+  const float* A2 = nullptr; int lda2 = 0; int K1 = 0;    // K1 == K when A2 unused
+  const float* W = nullptr;                                 // [taps][N][K], K contiguous
+  const float* bias = nullptr;                              // [N]
+  const float* rowbias = nullptr; const int* rowvar = nullptr; int row0 = 0; int rb_stride = 0;  // [n_var][rb_stride]
+  const float* resid = nullptr;  int ldr = 0;
+  const float* resid2 = nullptr; int ldr2 = 0;
+  float* C = nullptr;  int ldc = 0;
+  float* C2 = nullptr; int ldc2 = 0; int N1 = 0;            // N1 == N when C2 unused
+  int M = 0, N = 0, K = 0;
+  int taps = 1, shift0 = 0, shift_step = 0, L = 1;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+int init_gemm_attributes();        // raise the dynamic-LDS limit of every GEMM instantiation (once)
+int init_attention_attributes();   // same for the attention kernels
+
+// ---- row-wise ops (rowops.hip) --------------------------------------------------------------
+// GroupNorm over (L, C/8) per (row, group) [+ Mish] [+ per-channel time bias] [+ residual]
+struct GnArgs {
+  const float* x = nullptr;       // (R, L, C) conv output
+  const float* gamma = nullptr; const float* beta = nullptr;
+  const float* tbias = nullptr;   // (C) added after the activation, or null
+  const float* resid = nullptr;   // (R, L, C) added after the activation, or null
+  float* y = nullptr;             // (R, L, C)
+  float* stats = nullptr;         // (R, 8, 2) mean, rstd (written)
+  int R = 0, L = 0, C = 0; float eps = 1e-5f; int mish = 1;
+};
+int launch_gn_fwd(const GnArgs& a, hipStream_t s);
+// dX of the above: dx = GNbwd( dy * mish'(n) ) (+ add)
+struct GnBwdArgs {
+  const float* dy = nullptr; const float* x = nullptr; const float* stats = nullptr;
+  const float* gamma = nullptr; const float* beta = nullptr;
+  const float* add = nullptr;     // (R, L, C) added to the result, or null
+  float* dx = nullptr;
+  int R = 0, L = 0, C = 0; int mish = 1;
+};
+int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s);
+
+int launch_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int n_tok, hipStream_t s);
+// dx = add + LNbwd(dy; x, gamma)
+int launch_ln_bwd(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
+                  int n_tok, hipStream_t s);
+
+// GEGLU on ag (n_tok, 2*F): hg = a * gelu(g); backward writes dag (n_tok, 2*F)
+int launch_geglu_fwd(const float* ag, float* hg, int n_tok, int F, hipStream_t s);
+int launch_geglu_bwd(const float* dhg, const float* ag, float* dag, int n_tok, int F, hipStream_t s);
+
+// 4-head x 64 softmax self-attention inside each row of L tokens. qkv (R*L, 768) -> o (R*L, 256)
+int launch_attn_fwd(const float* qkv, float* o, int R, int L, hipStream_t s);
+int launch_attn_bwd(const float* qkv, const float* dout, float* dqkv, int R, int L, hipStream_t s);
+
+// stride-2 resampling convolutions and their dX, one generic gather kernel.
+//   mode 0: src = 2*o + j - 1          (Downsample1d fwd, Upsample1d dX)      Lout = Lin/2
+//   mode 1: t = o + 1 - j, src = t/2 if t even   (Downsample1d dX, Upsample1d fwd)   Lout = 2*Lin
+// W packed as [taps][Cin][Cout] (Cout contiguous). y = bias + sum + add.
+struct ResampleArgs {
+  const float* x = nullptr; const float* W = nullptr; const float* bias = nullptr; const float* add = nullptr;
+  float* y = nullptr; int R = 0, Lin = 0, Lout = 0, Cin = 0, Cout = 0, taps = 3, mode = 0;
+};
+int launch_resample(const ResampleArgs& a, hipStream_t s);
+
+// first layer: x (B,H,S) -> c1 (R,H,32) [conv k5] and res (R,H,32) [1x1], row r reads x[r / n_rp]
+int launch_conv_in_fwd(const float* x, const float* W5 /*[5][S][32]*/, const float* b5, const float* W1 /*[S][32]*/,
+                       const float* b1, float* c1, float* res, int R, int n_rp, int H, int S, hipStream_t s);
+// eps[r,l,s] = sum_j sum_c dc1[r,l-j+2,c] W5[j][s][c] + sum_c dy[r,l,c] W1[s][c]
+int launch_conv_in_bwd(const float* dc1, const float* dy, const float* W5, const float* W1, float* eps,
+                       int R, int H, int S, hipStream_t s);
+// last layer: f = a Wf^T + bf (R*H, S); da = f Wf  (the seed of the energy gradient: dE/df = f)
+int launch_conv_out(const float* a, const float* Wf /*[S][32]*/, const float* bf, float* f, float* da,
+                    int n_tok, int S, hipStream_t s);
+
+// ---- sampler (sampler.hip) ------------------------------------------------------------------
+struct CfgMeanArgs {
+  const float* x = nullptr;     // (B,H,S)
+  const float* eps = nullptr;   // (B*n_rp,H,S) interleaved [v0,v1,(v2)] per trajectory
+  float* x0 = nullptr; float* mean = nullptr;   // either may be null
+  float* ecomb = nullptr;       // optional
+  int B = 0, HS = 0, n_rp = 2;
+  float w0 = 0, w1 = 0, w0p1 = 1; // n_rp=2: e=w0p1*v0 - w0*v1 (w0p1 = float(1+w)) ; n_rp=3: e=v2+w0*(v0-v2)+w1*(v1-v2)
+  float sqrt_recip = 0, sqrt_recipm1 = 0, coef1 = 0, coef2 = 0; int clip = 1;
+};
+int launch_cfg_mean(const CfgMeanArgs& a, hipStream_t s);
+
+struct HardConds { const int* idx = nullptr; const float* val = nullptr; int n = 0; };  // val (n,B,S)
+
+// x = mean + (std * z) * noise_scale ; z = 0 when !use_noise (t == 0) ; then hard conditioning
+int launch_ddpm_finish(const float* mean, const float* noise, float stdv, float noise_scale, int use_noise,
+                       HardConds hc, float* x, float* chain_out, int B, int H, int S, hipStream_t s);
+int launch_ddim_finish(const float* x_in, const float* x0, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
+                       float dir_coef, HardConds hc, float* x, float* chain_out, int B, int H, int S, hipStream_t s);
+int launch_hard_cond(float* x, HardConds hc, int B, int H, int S, hipStream_t s);
+
+struct ApfArgs {
+  float* traj = nullptr;        // (B,H,S) modified in place (xy channels only)
+  const float* cloud = nullptr; // (P,2)
+  const float* window = nullptr;// (2*win+1) Gaussian weights
+  int B = 0, H = 0, S = 0, P = 0, win = 0;
+  double thr = 0, strength = 0;
+};
+int launch_apf(const ApfArgs& a, hipStream_t s);
+// mask[b] = any_{h,p} ||xy - p|| < thr ; plen[b], smooth[b]
+int launch_traj_costs(const float* traj, const float* cloud, int B, int H, int S, int P, float thr,
+                      int* mask, float* plen, float* smooth, hipStream_t s);
+
+// ---- setup kernels --------------------------------------------------------------------------
+// time-bias table: tb[t][off_i + c] = Wc_i silu(temb(t)) + bc_i for every RTB i, t in [0,T)
+struct TimeTableArgs {
+  const float* w1; const float* b1; const float* w2; const float* b2;   // time_mlp
+  const float* const* cond_w; const float* const* cond_b; const int* couts; const int* offs; int n_rtb;
+  float* table; int stride; int T;
+};
+int launch_time_table(const TimeTableArgs& a, hipStream_t s);
+// cross-attention bias: out[v][blk][256] = Wo_blk (Wv_blk lat[v]) + bo_blk
+int launch_cross_bias(const float* lat, int n_var, int ctx_dim, const float* const* wv, const float* const* wo,
+                      const float* const* bo, int n_blk, float* out, hipStream_t s);
+
+}  // namespace ramp

@@ -1,0 +1,992 @@
+// Context, weight packing and the forward / input-VJP schedule of the RAMP score network,
+// plus the sampler loops and their hipGraph capture.  Host-side C++ over the kernels in
+// gemm.hip / rowops.hip / sampler.hip; exported through the C ABI in include/ramp_hip.h.
+//
+// Reference structure being scheduled: TemporalUnetInference.forward_no_energy
+// (UnetInference.py:176-224) and EnergyGradFunction (UnetInference.py:19-37) whose
+// autograd.grad is replaced by the explicit dX chain below (all parameters are frozen, so no
+// dW / db products exist anywhere).
+#include "common.h"
+#include "../../include/ramp_hip.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace ramp {
+
+static thread_local std::string g_err;
+void set_last_error(const std::string& msg) { g_err = msg; }
+const char* last_error_cstr() { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void permute3_kernel(const float* __restrict__ in, float* __restrict__ out, int D0, int D1, int D2,
+                                int p0, int p1, int p2) {
+  // out[i_p0][i_p1][i_p2] = in[i0][i1][i2]
+  const long n = (long)D0 * D1 * D2;
+  const int dims[3] = {D0, D1, D2};
+  const int O1 = dims[p1], O2 = dims[p2];
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    int i[3];
+    i[2] = (int)(idx % D2); i[1] = (int)((idx / D2) % D1); i[0] = (int)(idx / ((long)D1 * D2));
+    out[((long)i[p0] * O1 + i[p1]) * O2 + i[p2]] = in[idx];
+  }
+}
+__global__ void fill_pattern_kernel(int* out, const int* pat, int n_pat, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = pat[i % n_pat];
+}
+
+struct DevArena {
+  std::vector<void*> blocks;
+  size_t total = 0;
+  ~DevArena() { for (void* p : blocks) (void)hipFree(p); }
+  float* alloc(size_t n_floats) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(n_floats, 4) * sizeof(float);
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    blocks.push_back(p);
+    total += bytes;
+    return static_cast<float*>(p);
+  }
+};
+
+struct ConvW {       // k=5 conv as 5-tap GEMM
+  float* fwd = nullptr;   // [5][Cout][Cin]
+  float* bwd = nullptr;   // [5][Cin][Cout]
+  float* bias = nullptr;
+  int cin = 0, cout = 0;
+};
+struct RTB {
+  std::string name;
+  int cin = 0, cout = 0, L = 0, tb_off = 0;
+  bool has_res = false, first = false;
+  ConvW c1, c2;
+  float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+  float *res_f = nullptr, *res_b = nullptr, *res_bias = nullptr;   // [Cout][Cin], [Cin][Cout]
+  float *w5in = nullptr, *w1in = nullptr;                           // first layer packed [5][S][32], [S][32]
+  // activations (capacity rows)
+  float *a_c1 = nullptr, *a_st1 = nullptr, *a_h = nullptr, *a_c2 = nullptr, *a_st2 = nullptr, *a_out = nullptr;
+};
+struct STBlock {
+  float *wqkv_f = nullptr, *wqkv_b = nullptr, *wo_f = nullptr, *wo_b = nullptr, *bo = nullptr;
+  float *w1_f = nullptr, *w1_b = nullptr, *b1 = nullptr, *w2_f = nullptr, *w2_b = nullptr, *b2 = nullptr;
+  float *ln1_g = nullptr, *ln1_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
+  const float *wv2 = nullptr, *wo2 = nullptr, *bo2 = nullptr;    // attn2 (cross) raw
+  float *a_qkv = nullptr, *a_z1 = nullptr, *a_ag = nullptr, *a_z2 = nullptr;
+};
+struct ST {
+  std::string name;
+  int C = 0, L = 0, blk0 = 0;
+  float *gn_g = nullptr, *gn_b = nullptr, *wpi_f = nullptr, *wpi_b = nullptr, *bpi = nullptr;
+  float *wpo_f = nullptr, *wpo_b = nullptr, *bpo = nullptr;
+  STBlock blk[2];
+  float *a_gst = nullptr, *a_z0 = nullptr, *a_y = nullptr;
+};
+struct Resample {
+  std::string name;
+  float *w_f = nullptr, *w_b = nullptr, *bias = nullptr;
+  int C = 0, Lin = 0, Lout = 0, taps = 0;
+  float* a_y = nullptr;
+};
+
+}  // namespace ramp
+
+using namespace ramp;
+
+struct ramp_ctx {
+  ramp_config cfg{};
+  int device = 0;
+  DevArena arena;
+  std::unordered_map<std::string, std::pair<float*, std::vector<int64_t>>> raw;   // device copies
+  bool finalized = false;
+  std::vector<int> chan;       // channels per level
+  std::vector<RTB> rtbs;       // order: downs (2/level), mid1, mid2, ups (2/level)
+  std::vector<ST> sts;         // order: downs, mid, ups
+  std::vector<Resample> downs, ups;
+  ConvW final_conv; float *fin_g = nullptr, *fin_b = nullptr, *fin_w = nullptr, *fin_bias = nullptr;
+  float *a_fin_c = nullptr, *a_fin_st = nullptr, *a_fin_a = nullptr, *a_fin_da = nullptr;
+  // shared temporaries
+  float *t_res = nullptr, *t_xn = nullptr, *t_ln = nullptr, *t_o = nullptr, *t_hg = nullptr;
+  float *t_dag = nullptr, *t_dqkv = nullptr, *t_dln = nullptr, *t_dz = nullptr, *t_dz1 = nullptr;
+  float *g_a = nullptr, *g_b = nullptr, *g_t1 = nullptr, *g_t2 = nullptr, *g_tr = nullptr;
+  std::vector<float*> skip_grad;   // per level
+  // time table / scene
+  float* time_table = nullptr; int tt_stride = 0, tt_T = 0;
+  float* cross_bias = nullptr; int n_variants = 0; int* row_variant = nullptr; int row_variant_cap = 0;
+  int n_blocks_total = 0;
+  // device pointer tables for setup kernels
+  void* d_ptr_tables = nullptr;
+  // sampler state
+  float *s_x = nullptr, *s_eps = nullptr, *s_mean = nullptr, *s_x0 = nullptr, *s_noise = nullptr, *s_chain = nullptr;
+  size_t s_cap_B = 0, s_cap_rows = 0, s_noise_cap = 0, s_chain_cap = 0;
+  int* s_hard_idx = nullptr; float* s_hard_val = nullptr; size_t s_hard_val_cap = 0; float* s_window = nullptr;
+  float* s_cloud = nullptr; size_t s_cloud_cap = 0;
+  // graph cache
+  hipGraphExec_t graph_exec = nullptr; std::string graph_key;
+  // debug
+  std::map<std::string, std::pair<float*, size_t>> dbg;
+  int64_t launches = 0;
+};
+
+namespace {
+
+#define CK(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
+
+int dev_alloc(ramp_ctx* c, float** out, size_t n) {
+  *out = c->arena.alloc(n);
+  RAMP_REQUIRE(*out != nullptr, "hipMalloc failed for " + std::to_string(n * 4) + " bytes");
+  return 0;
+}
+
+int get_raw(ramp_ctx* c, const std::string& key, std::initializer_list<int64_t> shape, float** out) {
+  auto it = c->raw.find(key);
+  RAMP_REQUIRE(it != c->raw.end(), "missing weight '" + key + "'");
+  std::vector<int64_t> want(shape);
+  RAMP_REQUIRE(it->second.second == want, "weight '" + key + "' has the wrong shape");
+  *out = it->second.first;
+  return 0;
+}
+
+int permute3(ramp_ctx* c, const float* in, int D0, int D1, int D2, int p0, int p1, int p2, float** out) {
+  CK(dev_alloc(c, out, (size_t)D0 * D1 * D2));
+  hipLaunchKernelGGL(permute3_kernel, dim3(std::min<long>(((long)D0 * D1 * D2 + 255) / 256, 4096)), dim3(256), 0, 0,
+                     in, *out, D0, D1, D2, p0, p1, p2);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int pack_conv5(ramp_ctx* c, const std::string& prefix, int cin, int cout, ConvW* w) {
+  float* raw; float* b;
+  CK(get_raw(c, prefix + ".weight", {cout, cin, 5}, &raw));
+  CK(get_raw(c, prefix + ".bias", {cout}, &b));
+  w->cin = cin; w->cout = cout; w->bias = b;
+  CK(permute3(c, raw, cout, cin, 5, 2, 0, 1, &w->fwd));   // [5][Cout][Cin]
+  CK(permute3(c, raw, cout, cin, 5, 2, 1, 0, &w->bwd));   // [5][Cin][Cout]
+  return 0;
+}
+
+int pack_linear(ramp_ctx* c, const std::string& key, int n, int k, bool conv1, float** fwd, float** bwd) {
+  float* raw;
+  if (conv1) CK(get_raw(c, key, {n, k, 1}, &raw)); else CK(get_raw(c, key, {n, k}, &raw));
+  *fwd = raw;
+  CK(permute3(c, raw, n, k, 1, 1, 0, 2, bwd));            // [K][N]
+  return 0;
+}
+
+int build_rtb(ramp_ctx* c, RTB& r) {
+  const std::string& n = r.name;
+  if (r.first) {
+    float* raw;
+    CK(get_raw(c, n + ".blocks.0.block.0.weight", {r.cout, r.cin, 5}, &raw));
+    CK(get_raw(c, n + ".blocks.0.block.0.bias", {r.cout}, &r.c1.bias));
+    CK(permute3(c, raw, r.cout, r.cin, 5, 2, 1, 0, &r.w5in));            // [5][S][32]
+    CK(get_raw(c, n + ".residual_conv.weight", {r.cout, r.cin, 1}, &raw));
+    CK(permute3(c, raw, r.cout, r.cin, 1, 2, 1, 0, &r.w1in));            // [1][S][32]
+    CK(get_raw(c, n + ".residual_conv.bias", {r.cout}, &r.res_bias));
+    r.c1.cin = r.cin; r.c1.cout = r.cout;
+  } else {
+    CK(pack_conv5(c, n + ".blocks.0.block.0", r.cin, r.cout, &r.c1));
+    if (r.has_res) {
+      CK(pack_linear(c, n + ".residual_conv.weight", r.cout, r.cin, true, &r.res_f, &r.res_b));
+      CK(get_raw(c, n + ".residual_conv.bias", {r.cout}, &r.res_bias));
+    }
+  }
+  CK(pack_conv5(c, n + ".blocks.1.block.0", r.cout, r.cout, &r.c2));
+  CK(get_raw(c, n + ".blocks.0.block.2.weight", {r.cout}, &r.g1));
+  CK(get_raw(c, n + ".blocks.0.block.2.bias", {r.cout}, &r.b1));
+  CK(get_raw(c, n + ".blocks.1.block.2.weight", {r.cout}, &r.g2));
+  CK(get_raw(c, n + ".blocks.1.block.2.bias", {r.cout}, &r.b2));
+  const size_t cap = (size_t)c->cfg.max_rows, lc = (size_t)r.L * r.cout;
+  CK(dev_alloc(c, &r.a_c1, cap * lc)); CK(dev_alloc(c, &r.a_st1, cap * 16));
+  CK(dev_alloc(c, &r.a_h, cap * lc));  CK(dev_alloc(c, &r.a_c2, cap * lc));
+  CK(dev_alloc(c, &r.a_st2, cap * 16)); CK(dev_alloc(c, &r.a_out, cap * lc));
+  return 0;
+}
+
+int build_st(ramp_ctx* c, ST& s) {
+  const std::string& n = s.name;
+  const int D = 256, ctx = c->cfg.context_dim;
+  CK(get_raw(c, n + ".norm.weight", {s.C}, &s.gn_g));
+  CK(get_raw(c, n + ".norm.bias", {s.C}, &s.gn_b));
+  CK(pack_linear(c, n + ".proj_in.weight", D, s.C, true, &s.wpi_f, &s.wpi_b));
+  CK(get_raw(c, n + ".proj_in.bias", {D}, &s.bpi));
+  CK(pack_linear(c, n + ".proj_out.weight", s.C, D, true, &s.wpo_f, &s.wpo_b));
+  CK(get_raw(c, n + ".proj_out.bias", {s.C}, &s.bpo));
+  const size_t cap = (size_t)c->cfg.max_rows, tok = cap * s.L;
+  CK(dev_alloc(c, &s.a_gst, cap * 16)); CK(dev_alloc(c, &s.a_z0, tok * D)); CK(dev_alloc(c, &s.a_y, cap * s.L * s.C));
+  for (int b = 0; b < 2; ++b) {
+    STBlock& k = s.blk[b];
+    const std::string t = n + ".transformer_blocks." + std::to_string(b);
+    float *q, *kk, *v;
+    CK(get_raw(c, t + ".attn1.to_q.weight", {D, D}, &q));
+    CK(get_raw(c, t + ".attn1.to_k.weight", {D, D}, &kk));
+    CK(get_raw(c, t + ".attn1.to_v.weight", {D, D}, &v));
+    CK(dev_alloc(c, &k.wqkv_f, 3 * D * D));
+    RAMP_HIP_CHECK(hipMemcpy(k.wqkv_f, q, D * D * 4, hipMemcpyDeviceToDevice));
+    RAMP_HIP_CHECK(hipMemcpy(k.wqkv_f + D * D, kk, D * D * 4, hipMemcpyDeviceToDevice));
+    RAMP_HIP_CHECK(hipMemcpy(k.wqkv_f + 2 * D * D, v, D * D * 4, hipMemcpyDeviceToDevice));
+    CK(permute3(c, k.wqkv_f, 3 * D, D, 1, 1, 0, 2, &k.wqkv_b));      // [256][768]
+    CK(pack_linear(c, t + ".attn1.to_out.0.weight", D, D, false, &k.wo_f, &k.wo_b));
+    CK(get_raw(c, t + ".attn1.to_out.0.bias", {D}, &k.bo));
+    CK(pack_linear(c, t + ".ff.net.0.proj.weight", 2048, D, false, &k.w1_f, &k.w1_b));
+    CK(get_raw(c, t + ".ff.net.0.proj.bias", {2048}, &k.b1));
+    CK(pack_linear(c, t + ".ff.net.2.weight", D, 1024, false, &k.w2_f, &k.w2_b));
+    CK(get_raw(c, t + ".ff.net.2.bias", {D}, &k.b2));
+    CK(get_raw(c, t + ".norm1.weight", {D}, &k.ln1_g)); CK(get_raw(c, t + ".norm1.bias", {D}, &k.ln1_b));
+    CK(get_raw(c, t + ".norm3.weight", {D}, &k.ln3_g)); CK(get_raw(c, t + ".norm3.bias", {D}, &k.ln3_b));
+    float* tmp;
+    CK(get_raw(c, t + ".attn2.to_v.weight", {D, ctx}, &tmp)); k.wv2 = tmp;
+    CK(get_raw(c, t + ".attn2.to_out.0.weight", {D, D}, &tmp)); k.wo2 = tmp;
+    CK(get_raw(c, t + ".attn2.to_out.0.bias", {D}, &tmp)); k.bo2 = tmp;
+    // attn2.to_q / to_k / norm2 only feed a softmax over a single key (== 1): checked present, unused
+    CK(get_raw(c, t + ".attn2.to_q.weight", {D, D}, &tmp));
+    CK(get_raw(c, t + ".attn2.to_k.weight", {D, ctx}, &tmp));
+    CK(get_raw(c, t + ".norm2.weight", {D}, &tmp)); CK(get_raw(c, t + ".norm2.bias", {D}, &tmp));
+    CK(dev_alloc(c, &k.a_qkv, tok * 768)); CK(dev_alloc(c, &k.a_z1, tok * D));
+    CK(dev_alloc(c, &k.a_ag, tok * 2048)); CK(dev_alloc(c, &k.a_z2, tok * D));
+  }
+  return 0;
+}
+
+// ---- op wrappers that count launches -----------------------------------------------------------
+struct Run {
+  ramp_ctx* c; hipStream_t s; int R; int row0;
+  int gemm(const GemmArgs& a) { c->launches++; return launch_gemm(a, s); }
+};
+
+GemmArgs lin(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K) {
+  GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.taps = 1; a.shift0 = 0; a.shift_step = 0; a.L = 1;
+  return a;
+}
+GemmArgs conv5(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K,
+               int L, bool backward) {
+  GemmArgs a = lin(A, lda, W, bias, C, ldc, M, N, K);
+  a.taps = 5; a.L = L;
+  if (backward) { a.shift0 = 2; a.shift_step = -1; } else { a.shift0 = -2; a.shift_step = 1; }
+  return a;
+}
+
+int dbg_store(ramp_ctx* c, const std::string& key, const float* src, size_t n, hipStream_t s) {
+  if (!c->cfg.debug_taps) return 0;
+  auto it = c->dbg.find(key);
+  if (it == c->dbg.end() || it->second.second < n) {
+    float* p; CK(dev_alloc(c, &p, n));
+    c->dbg[key] = {p, n};
+    it = c->dbg.find(key);
+  }
+  RAMP_HIP_CHECK(hipMemcpyAsync(it->second.first, src, n * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// ---- ResidualTemporalBlock ---------------------------------------------------------------------
+// xa (R,L,Ca) [, xb (R,L,Cb) concatenated along channels]; x_first: (B,H,S) for the first layer
+int rtb_forward(Run& r, RTB& m, const float* xa, int ca, const float* xb, int cb, const float* x_first, int n_rp,
+                int t) {
+  ramp_ctx* c = r.c; const int R = r.R, M = R * m.L;
+  const float* tbias = c->time_table + (size_t)t * c->tt_stride + m.tb_off;
+  const float* resid;
+  if (m.first) {
+    c->launches++;
+    CK(launch_conv_in_fwd(x_first, m.w5in, m.c1.bias, m.w1in, m.res_bias, m.a_c1, c->t_res, R, n_rp, m.L, m.cin, r.s));
+    resid = c->t_res;
+  } else {
+    GemmArgs a = conv5(xa, ca, m.c1.fwd, m.c1.bias, m.a_c1, m.cout, M, m.cout, m.cin, m.L, false);
+    if (xb) { a.A2 = xb; a.lda2 = cb; a.K1 = ca; }
+    CK(r.gemm(a));
+    if (m.has_res) {
+      GemmArgs b = lin(xa, ca, m.res_f, m.res_bias, c->t_res, m.cout, M, m.cout, m.cin);
+      if (xb) { b.A2 = xb; b.lda2 = cb; b.K1 = ca; }
+      CK(r.gemm(b));
+      resid = c->t_res;
+    } else {
+      resid = xa;
+    }
+  }
+  GnArgs g; g.x = m.a_c1; g.gamma = m.g1; g.beta = m.b1; g.tbias = tbias; g.resid = nullptr; g.y = m.a_h;
+  g.stats = m.a_st1; g.R = R; g.L = m.L; g.C = m.cout; g.eps = 1e-5f; g.mish = 1;
+  c->launches++; CK(launch_gn_fwd(g, r.s));
+  CK(r.gemm(conv5(m.a_h, m.cout, m.c2.fwd, m.c2.bias, m.a_c2, m.cout, M, m.cout, m.cout, m.L, false)));
+  g.x = m.a_c2; g.gamma = m.g2; g.beta = m.b2; g.tbias = nullptr; g.resid = resid; g.y = m.a_out; g.stats = m.a_st2;
+  c->launches++; CK(launch_gn_fwd(g, r.s));
+  CK(dbg_store(c, "out/" + m.name, m.a_out, (size_t)M * m.cout, r.s));
+  return 0;
+}
+
+// dy (R,L,Cout) -> dxa (R,L,Ca) [, dxb (R,L,Cb)] ; add2: optional extra addend on dxa (same shape)
+int rtb_backward(Run& r, RTB& m, const float* dy, float* dxa, int ca, float* dxb, int cb, const float* add2,
+                 float* eps_out) {
+  ramp_ctx* c = r.c; const int R = r.R, M = R * m.L;
+  CK(dbg_store(c, "gout/" + m.name, dy, (size_t)M * m.cout, r.s));
+  GnBwdArgs g; g.dy = dy; g.x = m.a_c2; g.stats = m.a_st2; g.gamma = m.g2; g.beta = m.b2; g.add = nullptr;
+  g.dx = c->g_t1; g.R = R; g.L = m.L; g.C = m.cout; g.mish = 1;
+  c->launches++; CK(launch_gn_bwd(g, r.s));                                                     // dc2
+  CK(r.gemm(conv5(c->g_t1, m.cout, m.c2.bwd, nullptr, c->g_t2, m.cout, M, m.cout, m.cout, m.L, true)));   // dh
+  g.dy = c->g_t2; g.x = m.a_c1; g.stats = m.a_st1; g.gamma = m.g1; g.beta = m.b1; g.dx = c->g_t1;
+  c->launches++; CK(launch_gn_bwd(g, r.s));                                                     // dc1
+  if (m.first) {
+    c->launches++;
+    CK(launch_conv_in_bwd(c->g_t1, dy, m.w5in, m.w1in, eps_out, R, m.L, m.cin, r.s));
+    return 0;
+  }
+  const float* resid; int ldr;
+  if (m.has_res) {
+    CK(r.gemm(lin(dy, m.cout, m.res_b, nullptr, c->g_tr, m.cin, M, m.cin, m.cout)));
+    resid = c->g_tr; ldr = m.cin;
+  } else {
+    resid = dy; ldr = m.cout;
+  }
+  GemmArgs a = conv5(c->g_t1, m.cout, m.c1.bwd, nullptr, dxa, ca, M, m.cin, m.cout, m.L, true);
+  a.resid = resid; a.ldr = ldr;
+  if (dxb) { a.C2 = dxb; a.ldc2 = cb; a.N1 = ca; }
+  if (add2) { RAMP_REQUIRE(dxb == nullptr, "add2 with split output"); a.resid2 = add2; a.ldr2 = ca; }
+  CK(r.gemm(a));
+  return 0;
+}
+
+// ---- SpatialTransformer ------------------------------------------------------------------------
+int st_forward(Run& r, ST& m, const float* x) {
+  ramp_ctx* c = r.c; const int R = r.R, M = R * m.L, D = 256;
+  GnArgs g; g.x = x; g.gamma = m.gn_g; g.beta = m.gn_b; g.y = c->t_xn; g.stats = m.a_gst; g.R = R; g.L = m.L;
+  g.C = m.C; g.eps = 1e-6f; g.mish = 0;
+  c->launches++; CK(launch_gn_fwd(g, r.s));
+  CK(r.gemm(lin(c->t_xn, m.C, m.wpi_f, m.bpi, m.a_z0, D, M, D, m.C)));
+  const float* zin = m.a_z0;
+  for (int b = 0; b < 2; ++b) {
+    STBlock& k = m.blk[b];
+    c->launches++; CK(launch_ln_fwd(zin, k.ln1_g, k.ln1_b, c->t_ln, M, r.s));
+    CK(r.gemm(lin(c->t_ln, D, k.wqkv_f, nullptr, k.a_qkv, 768, M, 768, D)));
+    c->launches++; CK(launch_attn_fwd(k.a_qkv, c->t_o, R, m.L, r.s));
+    GemmArgs a = lin(c->t_o, D, k.wo_f, k.bo, k.a_z1, D, M, D, D);
+    a.resid = zin; a.ldr = D; a.L = m.L;
+    a.rowbias = c->cross_bias + (size_t)(m.blk0 + b) * D; a.rb_stride = c->n_blocks_total * D;
+    a.rowvar = c->row_variant; a.row0 = r.row0;
+    CK(r.gemm(a));
+    c->launches++; CK(launch_ln_fwd(k.a_z1, k.ln3_g, k.ln3_b, c->t_ln, M, r.s));
+    CK(r.gemm(lin(c->t_ln, D, k.w1_f, k.b1, k.a_ag, 2048, M, 2048, D)));
+    c->launches++; CK(launch_geglu_fwd(k.a_ag, c->t_hg, M, 1024, r.s));
+    GemmArgs f = lin(c->t_hg, 1024, k.w2_f, k.b2, k.a_z2, D, M, D, 1024);
+    f.resid = k.a_z1; f.ldr = D;
+    CK(r.gemm(f));
+    zin = k.a_z2;
+  }
+  GemmArgs o = lin(zin, D, m.wpo_f, m.bpo, m.a_y, m.C, M, m.C, D);
+  o.resid = x; o.ldr = m.C;
+  CK(r.gemm(o));
+  CK(dbg_store(c, "out/" + m.name, m.a_y, (size_t)M * m.C, r.s));
+  return 0;
+}
+
+int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx) {
+  ramp_ctx* c = r.c; const int R = r.R, M = R * m.L, D = 256;
+  CK(dbg_store(c, "gout/" + m.name, dy, (size_t)M * m.C, r.s));
+  float* dz = c->t_dz; float* dz1 = c->t_dz1;
+  CK(r.gemm(lin(dy, m.C, m.wpo_b, nullptr, dz, D, M, D, m.C)));
+  for (int b = 1; b >= 0; --b) {
+    STBlock& k = m.blk[b];
+    const float* zin = (b == 0) ? m.a_z0 : m.blk[0].a_z2;
+    CK(r.gemm(lin(dz, D, k.w2_b, nullptr, c->t_hg, 1024, M, 1024, D)));                 // d(hg)
+    c->launches++; CK(launch_geglu_bwd(c->t_hg, k.a_ag, c->t_dag, M, 1024, r.s));        // d(ag)
+    CK(r.gemm(lin(c->t_dag, 2048, k.w1_b, nullptr, c->t_dln, D, M, D, 2048)));          // d(ln3)
+    c->launches++; CK(launch_ln_bwd(c->t_dln, k.a_z1, k.ln3_g, dz, dz1, M, r.s));         // dz1
+    CK(r.gemm(lin(dz1, D, k.wo_b, nullptr, c->t_o, D, M, D, D)));                       // d(o)
+    c->launches++; CK(launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, R, m.L, r.s));
+    CK(r.gemm(lin(c->t_dqkv, 768, k.wqkv_b, nullptr, c->t_dln, D, M, D, 768)));         // d(ln1)
+    c->launches++; CK(launch_ln_bwd(c->t_dln, zin, k.ln1_g, dz1, dz, M, r.s));            // dz (block input)
+  }
+  CK(r.gemm(lin(dz, D, m.wpi_b, nullptr, c->t_xn, m.C, M, m.C, D)));                    // d(xn)
+  GnBwdArgs g; g.dy = c->t_xn; g.x = x; g.stats = m.a_gst; g.gamma = m.gn_g; g.beta = m.gn_b; g.add = dy; g.dx = dx;
+  g.R = R; g.L = m.L; g.C = m.C; g.mish = 0;
+  c->launches++; CK(launch_gn_bwd(g, r.s));
+  return 0;
+}
+
+// ---- whole network -----------------------------------------------------------------------------
+// x (B,H,S) device pointer of the FIRST trajectory of this chunk; rows [row0, row0 + R)
+int net_forward(ramp_ctx* c, const float* x_chunk, int row0, int R, int n_rp, int t, float* f_out, bool want_grad,
+                hipStream_t s) {
+  Run r{c, s, R, row0};
+  const int nl = c->cfg.n_levels;
+  const float* cur = nullptr; int cc = 0;
+  for (int k = 0; k < nl; ++k) {
+    RTB& a = c->rtbs[2 * k]; RTB& b = c->rtbs[2 * k + 1]; ST& st = c->sts[k];
+    CK(rtb_forward(r, a, cur, cc, nullptr, 0, x_chunk, n_rp, t));
+    CK(rtb_forward(r, b, a.a_out, a.cout, nullptr, 0, nullptr, n_rp, t));
+    CK(st_forward(r, st, b.a_out));
+    if (k < nl - 1) {
+      Resample& d = c->downs[k];
+      ResampleArgs ra; ra.x = st.a_y; ra.W = d.w_f; ra.bias = d.bias; ra.y = d.a_y; ra.R = R; ra.Lin = d.Lin;
+      ra.Lout = d.Lout; ra.Cin = d.C; ra.Cout = d.C; ra.taps = 3; ra.mode = 0;
+      c->launches++; CK(launch_resample(ra, s));
+      CK(dbg_store(c, "out/" + d.name, d.a_y, (size_t)R * d.Lout * d.C, s));
+      cur = d.a_y; cc = d.C;
+    } else {
+      cur = st.a_y; cc = st.C;
+    }
+  }
+  RTB& m1 = c->rtbs[2 * nl]; RTB& m2 = c->rtbs[2 * nl + 1]; ST& ms = c->sts[nl];
+  CK(rtb_forward(r, m1, cur, cc, nullptr, 0, nullptr, n_rp, t));
+  CK(st_forward(r, ms, m1.a_out));
+  CK(rtb_forward(r, m2, ms.a_y, ms.C, nullptr, 0, nullptr, n_rp, t));
+  cur = m2.a_out; cc = m2.cout;
+  for (int k = 0; k < nl - 1; ++k) {
+    RTB& a = c->rtbs[2 * nl + 2 + 2 * k]; RTB& b = c->rtbs[2 * nl + 3 + 2 * k]; ST& st = c->sts[nl + 1 + k];
+    ST& skip = c->sts[nl - 1 - k];
+    CK(rtb_forward(r, a, cur, cc, skip.a_y, skip.C, nullptr, n_rp, t));
+    CK(rtb_forward(r, b, a.a_out, a.cout, nullptr, 0, nullptr, n_rp, t));
+    CK(st_forward(r, st, b.a_out));
+    Resample& u = c->ups[k];
+    ResampleArgs ra; ra.x = st.a_y; ra.W = u.w_f; ra.bias = u.bias; ra.y = u.a_y; ra.R = R; ra.Lin = u.Lin;
+    ra.Lout = u.Lout; ra.Cin = u.C; ra.Cout = u.C; ra.taps = 4; ra.mode = 1;
+    c->launches++; CK(launch_resample(ra, s));
+    CK(dbg_store(c, "out/" + u.name, u.a_y, (size_t)R * u.Lout * u.C, s));
+    cur = u.a_y; cc = u.C;
+  }
+  const int H = c->cfg.horizon, C0 = c->cfg.unet_input_dim, M = R * H;
+  CK(r.gemm(conv5(cur, cc, c->final_conv.fwd, c->final_conv.bias, c->a_fin_c, C0, M, C0, C0, H, false)));
+  GnArgs g; g.x = c->a_fin_c; g.gamma = c->fin_g; g.beta = c->fin_b; g.y = c->a_fin_a; g.stats = c->a_fin_st;
+  g.R = R; g.L = H; g.C = C0; g.eps = 1e-5f; g.mish = 1;
+  c->launches++; CK(launch_gn_fwd(g, s));
+  c->launches++;
+  CK(launch_conv_out(c->a_fin_a, c->fin_w, c->fin_bias, f_out, want_grad ? c->a_fin_da : nullptr, M, c->cfg.state_dim, s));
+  return 0;
+}
+
+int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s) {
+  Run r{c, s, R, row0};
+  const int nl = c->cfg.n_levels, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim, M = R * H;
+  GnBwdArgs g; g.dy = c->a_fin_da; g.x = c->a_fin_c; g.stats = c->a_fin_st; g.gamma = c->fin_g; g.beta = c->fin_b;
+  g.dx = c->g_t1; g.R = R; g.L = H; g.C = C0; g.mish = 1;
+  c->launches++; CK(launch_gn_bwd(g, s));
+  float* d = c->g_a; float* e = c->g_b;
+  CK(r.gemm(conv5(c->g_t1, C0, c->final_conv.bwd, nullptr, d, C0, M, C0, C0, H, true)));
+  for (int k = nl - 2; k >= 0; --k) {
+    RTB& a = c->rtbs[2 * nl + 2 + 2 * k]; RTB& b = c->rtbs[2 * nl + 3 + 2 * k]; ST& st = c->sts[nl + 1 + k];
+    Resample& u = c->ups[k];
+    CK(dbg_store(c, "gout/" + u.name, d, (size_t)R * u.Lout * u.C, s));
+    ResampleArgs ra; ra.x = d; ra.W = u.w_b; ra.y = e; ra.R = R; ra.Lin = u.Lout; ra.Lout = u.Lin; ra.Cin = u.C;
+    ra.Cout = u.C; ra.taps = 4; ra.mode = 0;
+    c->launches++; CK(launch_resample(ra, s)); std::swap(d, e);
+    CK(st_backward(r, st, b.a_out, d, e)); std::swap(d, e);
+    CK(rtb_backward(r, b, d, e, b.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e);
+    const int lvl = nl - 1 - k;                      // the skip consumed by ups.k
+    const int ca = a.cin - c->sts[lvl].C;
+    CK(rtb_backward(r, a, d, e, ca, c->skip_grad[lvl], c->sts[lvl].C, nullptr, nullptr)); std::swap(d, e);
+  }
+  RTB& m1 = c->rtbs[2 * nl]; RTB& m2 = c->rtbs[2 * nl + 1]; ST& ms = c->sts[nl];
+  CK(rtb_backward(r, m2, d, e, m2.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e);
+  CK(st_backward(r, ms, m1.a_out, d, e)); std::swap(d, e);
+  // the deepest level's transformer output feeds both mid_block1 and (as skip) ups.0
+  CK(rtb_backward(r, m1, d, e, m1.cin, nullptr, 0, c->skip_grad[nl - 1], nullptr)); std::swap(d, e);
+  for (int k = nl - 1; k >= 0; --k) {
+    RTB& a = c->rtbs[2 * k]; RTB& b = c->rtbs[2 * k + 1]; ST& st = c->sts[k];
+    if (k < nl - 1) {
+      Resample& dn = c->downs[k];
+      CK(dbg_store(c, "gout/" + dn.name, d, (size_t)R * dn.Lout * dn.C, s));
+      ResampleArgs ra; ra.x = d; ra.W = dn.w_b; ra.y = e; ra.R = R; ra.Lin = dn.Lout; ra.Lout = dn.Lin; ra.Cin = dn.C;
+      ra.Cout = dn.C; ra.taps = 3; ra.mode = 1; ra.add = (k >= 1) ? c->skip_grad[k] : nullptr;
+      c->launches++; CK(launch_resample(ra, s)); std::swap(d, e);
+    }
+    CK(st_backward(r, st, b.a_out, d, e)); std::swap(d, e);
+    CK(rtb_backward(r, b, d, e, b.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e);
+    if (k > 0) { CK(rtb_backward(r, a, d, e, a.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e); }
+    else CK(rtb_backward(r, a, d, nullptr, 0, nullptr, 0, nullptr, eps_out));
+  }
+  return 0;
+}
+
+hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+int ensure_sampler_buffers(ramp_ctx* c, int B, int n_rp, int n_steps, bool chain) {
+  const size_t HS = (size_t)c->cfg.horizon * c->cfg.state_dim;
+  bool moved = false;
+  if ((size_t)B > c->s_cap_B) {
+    CK(dev_alloc(c, &c->s_x, B * HS)); CK(dev_alloc(c, &c->s_mean, B * HS)); CK(dev_alloc(c, &c->s_x0, B * HS));
+    c->s_cap_B = B; moved = true;
+  }
+  if ((size_t)B * n_rp > c->s_cap_rows) {
+    CK(dev_alloc(c, &c->s_eps, (size_t)B * n_rp * HS)); c->s_cap_rows = (size_t)B * n_rp; moved = true;
+  }
+  const size_t nn = (size_t)(n_steps + 1) * B * HS;
+  if (nn > c->s_noise_cap) { CK(dev_alloc(c, &c->s_noise, nn)); c->s_noise_cap = nn; moved = true; }
+  if (chain && nn > c->s_chain_cap) { CK(dev_alloc(c, &c->s_chain, nn)); c->s_chain_cap = nn; moved = true; }
+  if (moved) c->graph_key.clear();      // captured nodes hold the old pointers
+  return 0;
+}
+
+// one score evaluation over all rows of a batch, chunked to the context capacity
+int score_all(ramp_ctx* c, const float* x, int B, int n_rp, int t, float* f_out, float* eps_out, hipStream_t s) {
+  const int H = c->cfg.horizon, S = c->cfg.state_dim;
+  RAMP_REQUIRE(c->finalized, "weights not finalized");
+  RAMP_REQUIRE(c->time_table != nullptr && t >= 0 && t < c->tt_T, "timestep outside the prepared time table");
+  RAMP_REQUIRE(c->cross_bias != nullptr, "ramp_set_scene has not been called");
+  RAMP_REQUIRE(B > 0 && n_rp >= 1 && n_rp <= 3, "bad batch");
+  RAMP_REQUIRE(c->row_variant_cap >= B * n_rp, "row-variant table shorter than the batch (call ramp_set_scene after sizing)");
+  const int cap_traj = c->cfg.max_rows / n_rp;
+  RAMP_REQUIRE(cap_traj >= 1, "max_rows smaller than n_rp");
+  for (int b0 = 0; b0 < B; b0 += cap_traj) {
+    const int nb = std::min(cap_traj, B - b0), R = nb * n_rp, row0 = b0 * n_rp;
+    float* fo = f_out ? f_out + (size_t)row0 * H * S : nullptr;
+    CK(net_forward(c, x + (size_t)b0 * H * S, row0, R, n_rp, t, fo, eps_out != nullptr, s));
+    if (eps_out) CK(net_backward(c, row0, R, eps_out + (size_t)row0 * H * S, s));
+  }
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* ramp_last_error(void) { return last_error_cstr(); }
+int ramp_version(void) { return 1; }
+
+int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
+  RAMP_REQUIRE(cfg && out, "null argument");
+  RAMP_REQUIRE(cfg->state_dim >= 2 && cfg->state_dim <= 16, "state_dim out of range");
+  RAMP_REQUIRE(cfg->n_levels == 4, "only UNET_DIM_MULTS[1] = (1,2,4,8) is built");
+  RAMP_REQUIRE(cfg->unet_input_dim == 32, "unet_input_dim must be 32");
+  RAMP_REQUIRE(cfg->horizon % 8 == 0 && cfg->horizon >= 48 && cfg->horizon <= 64,
+               "horizon must be 48 or 64 (attention kernel instantiations)");
+  RAMP_REQUIRE(cfg->context_dim > 0 && cfg->context_dim <= 512, "context_dim out of range");
+  RAMP_REQUIRE(cfg->max_rows >= 1, "max_rows must be positive");
+  int ndev = 0;
+  RAMP_HIP_CHECK(hipGetDeviceCount(&ndev));
+  RAMP_REQUIRE(ndev > 0, "no HIP device: the RAMP sampler has no CPU fallback");
+  auto* c = new ramp_ctx();
+  c->cfg = *cfg;
+  RAMP_HIP_CHECK(hipGetDevice(&c->device));
+  *out = c;
+  return 0;
+}
+
+int ramp_destroy(ramp_ctx* c) {
+  if (!c) return 0;
+  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  if (c->d_ptr_tables) (void)hipFree(c->d_ptr_tables);
+  delete c;
+  return 0;
+}
+
+int ramp_load_weight(ramp_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+  RAMP_REQUIRE(c && name && data && (shape || ndim == 0), "null argument");
+  RAMP_REQUIRE(!c->finalized, "weights already finalized");
+  std::string key(name);
+  if (key.rfind("scene_encoder.", 0) == 0) return 0;
+  size_t n = 1; std::vector<int64_t> shp;
+  for (int i = 0; i < ndim; ++i) { RAMP_REQUIRE(shape[i] > 0, "bad shape"); n *= (size_t)shape[i]; shp.push_back(shape[i]); }
+  float* d; CK(dev_alloc(c, &d, n));
+  RAMP_HIP_CHECK(hipMemcpy(d, data, n * sizeof(float), hipMemcpyHostToDevice));
+  c->raw[key] = {d, shp};
+  return 0;
+}
+
+int ramp_finalize_weights(ramp_ctx* c) {
+  RAMP_REQUIRE(c && !c->finalized, "bad context state");
+  const int nl = c->cfg.n_levels, S = c->cfg.state_dim, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim;
+  const size_t cap = (size_t)c->cfg.max_rows;
+  std::vector<int> dims = {S};
+  for (int k = 0; k < nl; ++k) dims.push_back(C0 << k);
+  int L = H, tb = 0;
+  auto add_rtb = [&](const std::string& name, int ci, int co, int len, bool first) {
+    RTB r; r.name = name; r.cin = ci; r.cout = co; r.L = len; r.has_res = ci != co; r.first = first; r.tb_off = tb;
+    tb += co; c->rtbs.push_back(r);
+  };
+  int blk = 0;
+  auto add_st = [&](const std::string& name, int ch, int len) {
+    ST s; s.name = name; s.C = ch; s.L = len; s.blk0 = blk; blk += 2; c->sts.push_back(s);
+  };
+  for (int k = 0; k < nl; ++k) {
+    const std::string p = "downs." + std::to_string(k);
+    add_rtb(p + ".0", dims[k], dims[k + 1], L, k == 0);
+    add_rtb(p + ".1", dims[k + 1], dims[k + 1], L, false);
+    add_st(p + ".3", dims[k + 1], L);
+    if (k < nl - 1) {
+      Resample d; d.name = p + ".4"; d.C = dims[k + 1]; d.Lin = L; d.Lout = L / 2; d.taps = 3;
+      c->downs.push_back(d); L /= 2;
+    }
+  }
+  RAMP_REQUIRE(dims[1] != S, "first block must have a residual conv");
+  const int mid = dims[nl];
+  add_rtb("mid_block1", mid, mid, L, false);
+  add_rtb("mid_block2", mid, mid, L, false);
+  add_st("mid_attention", mid, L);
+  for (int k = 0; k < nl - 1; ++k) {
+    const std::string p = "ups." + std::to_string(k);
+    const int ci = dims[nl - 1 - k], co = dims[nl - k];      // (dim_in, dim_out) of reversed(in_out[1:])
+    add_rtb(p + ".0", co * 2, ci, L, false);
+    add_rtb(p + ".1", ci, ci, L, false);
+    add_st(p + ".3", ci, L);
+    Resample u; u.name = p + ".4"; u.C = ci; u.Lin = L; u.Lout = 2 * L; u.taps = 4;
+    c->ups.push_back(u); L *= 2;
+  }
+  RAMP_REQUIRE(L == H, "level bookkeeping");
+  c->tt_stride = tb; c->n_blocks_total = blk;
+  for (auto& r : c->rtbs) CK(build_rtb(c, r));
+  for (auto& s : c->sts) CK(build_st(c, s));
+  for (auto& d : c->downs) {
+    float* raw;
+    CK(get_raw(c, d.name + ".conv.weight", {d.C, d.C, 3}, &raw));
+    CK(get_raw(c, d.name + ".conv.bias", {d.C}, &d.bias));
+    CK(permute3(c, raw, d.C, d.C, 3, 2, 1, 0, &d.w_f));      // [j][ci][co] = W[co][ci][j]
+    CK(permute3(c, raw, d.C, d.C, 3, 2, 0, 1, &d.w_b));      // [j][co][ci]
+    CK(dev_alloc(c, &d.a_y, cap * d.Lout * d.C));
+  }
+  for (auto& u : c->ups) {
+    float* raw;
+    CK(get_raw(c, u.name + ".conv.weight", {u.C, u.C, 4}, &raw));   // ConvTranspose1d (Cin,Cout,4)
+    CK(get_raw(c, u.name + ".conv.bias", {u.C}, &u.bias));
+    CK(permute3(c, raw, u.C, u.C, 4, 2, 0, 1, &u.w_f));      // [j][ci][co] = W[ci][co][j]
+    CK(permute3(c, raw, u.C, u.C, 4, 2, 1, 0, &u.w_b));      // [j][co][ci]
+    CK(dev_alloc(c, &u.a_y, cap * u.Lout * u.C));
+  }
+  CK(pack_conv5(c, "final_conv.0.block.0", C0, C0, &c->final_conv));
+  CK(get_raw(c, "final_conv.0.block.2.weight", {C0}, &c->fin_g));
+  CK(get_raw(c, "final_conv.0.block.2.bias", {C0}, &c->fin_b));
+  CK(get_raw(c, "final_conv.1.weight", {S, C0, 1}, &c->fin_w));
+  CK(get_raw(c, "final_conv.1.bias", {S}, &c->fin_bias));
+  for (const char* k : {"time_mlp.encoder.1.weight", "time_mlp.encoder.1.bias", "time_mlp.encoder.3.weight",
+                        "time_mlp.encoder.3.bias"})
+    RAMP_REQUIRE(c->raw.count(k), std::string("missing weight '") + k + "'");
+  CK(dev_alloc(c, &c->a_fin_c, cap * H * C0)); CK(dev_alloc(c, &c->a_fin_st, cap * 16));
+  CK(dev_alloc(c, &c->a_fin_a, cap * H * C0)); CK(dev_alloc(c, &c->a_fin_da, cap * H * C0));
+  // shared temporaries
+  size_t max_lc = 0, max_l = 0;
+  for (auto& r : c->rtbs) max_lc = std::max(max_lc, (size_t)r.L * std::max(r.cin, r.cout));
+  for (auto& s : c->sts) max_l = std::max(max_l, (size_t)s.L);
+  max_lc = std::max(max_lc, (size_t)H * C0);
+  CK(dev_alloc(c, &c->t_res, cap * max_lc)); CK(dev_alloc(c, &c->t_xn, cap * max_lc));
+  CK(dev_alloc(c, &c->t_ln, cap * max_l * 256)); CK(dev_alloc(c, &c->t_o, cap * max_l * 256));
+  CK(dev_alloc(c, &c->t_hg, cap * max_l * 1024)); CK(dev_alloc(c, &c->t_dag, cap * max_l * 2048));
+  CK(dev_alloc(c, &c->t_dqkv, cap * max_l * 768)); CK(dev_alloc(c, &c->t_dln, cap * max_l * 256));
+  CK(dev_alloc(c, &c->t_dz, cap * max_l * 256)); CK(dev_alloc(c, &c->t_dz1, cap * max_l * 256));
+  CK(dev_alloc(c, &c->g_a, cap * max_lc)); CK(dev_alloc(c, &c->g_b, cap * max_lc));
+  CK(dev_alloc(c, &c->g_t1, cap * max_lc)); CK(dev_alloc(c, &c->g_t2, cap * max_lc)); CK(dev_alloc(c, &c->g_tr, cap * max_lc));
+  c->skip_grad.assign(nl, nullptr);
+  for (int k = 1; k < nl; ++k) CK(dev_alloc(c, &c->skip_grad[k], cap * c->sts[k].L * c->sts[k].C));
+  RAMP_HIP_CHECK(hipDeviceSynchronize());
+  CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
+  CK(init_attention_attributes());
+  c->finalized = true;
+  return 0;
+}
+
+int ramp_prepare_time_table(ramp_ctx* c, int32_t T, void* stream) {
+  RAMP_REQUIRE(c && c->finalized && T > 0 && T <= 4096, "bad arguments");
+  hipStream_t s = as_stream(stream);
+  const int n = (int)c->rtbs.size();
+  std::vector<const float*> cw(n), cb(n); std::vector<int> couts(n), offs(n);
+  for (int i = 0; i < n; ++i) {
+    float *w, *b;
+    CK(get_raw(c, c->rtbs[i].name + ".cond_mlp.1.weight", {c->rtbs[i].cout, 32}, &w));
+    CK(get_raw(c, c->rtbs[i].name + ".cond_mlp.1.bias", {c->rtbs[i].cout}, &b));
+    cw[i] = w; cb[i] = b; couts[i] = c->rtbs[i].cout; offs[i] = c->rtbs[i].tb_off;
+  }
+  const size_t bytes = n * (2 * sizeof(void*) + 2 * sizeof(int));
+  char* d = nullptr;
+  RAMP_HIP_CHECK(hipMalloc(&d, bytes));
+  std::vector<char> h(bytes);
+  std::memcpy(h.data(), cw.data(), n * sizeof(void*));
+  std::memcpy(h.data() + n * sizeof(void*), cb.data(), n * sizeof(void*));
+  std::memcpy(h.data() + 2 * n * sizeof(void*), couts.data(), n * sizeof(int));
+  std::memcpy(h.data() + 2 * n * sizeof(void*) + n * sizeof(int), offs.data(), n * sizeof(int));
+  RAMP_HIP_CHECK(hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice));
+  if (T > c->tt_T) { CK(dev_alloc(c, &c->time_table, (size_t)T * c->tt_stride)); }
+  TimeTableArgs a;
+  a.w1 = c->raw["time_mlp.encoder.1.weight"].first; a.b1 = c->raw["time_mlp.encoder.1.bias"].first;
+  a.w2 = c->raw["time_mlp.encoder.3.weight"].first; a.b2 = c->raw["time_mlp.encoder.3.bias"].first;
+  a.cond_w = reinterpret_cast<const float* const*>(d);
+  a.cond_b = reinterpret_cast<const float* const*>(d + n * sizeof(void*));
+  a.couts = reinterpret_cast<const int*>(d + 2 * n * sizeof(void*));
+  a.offs = reinterpret_cast<const int*>(d + 2 * n * sizeof(void*) + n * sizeof(int));
+  a.n_rtb = n; a.table = c->time_table; a.stride = c->tt_stride; a.T = T;
+  int rc = launch_time_table(a, s);
+  RAMP_HIP_CHECK(hipStreamSynchronize(s));
+  RAMP_HIP_CHECK(hipFree(d));
+  if (rc) return rc;
+  c->tt_T = T;
+  return 0;
+}
+
+int ramp_set_scene(ramp_ctx* c, const float* latents, int32_t n_variants, const int32_t* row_variant_host,
+                   int32_t n_rows_pattern, void* stream) {
+  RAMP_REQUIRE(c && c->finalized && latents && n_variants >= 1 && n_variants <= 8, "bad arguments");
+  RAMP_REQUIRE(row_variant_host && n_rows_pattern >= 1 && n_rows_pattern <= 64, "bad row-variant pattern");
+  for (int i = 0; i < n_rows_pattern; ++i)
+    RAMP_REQUIRE(row_variant_host[i] >= 0 && row_variant_host[i] < n_variants, "row variant out of range");
+  hipStream_t s = as_stream(stream);
+  const int nb = c->n_blocks_total;
+  if (n_variants > c->n_variants) { CK(dev_alloc(c, &c->cross_bias, (size_t)n_variants * nb * 256)); c->n_variants = n_variants; }
+  std::vector<const float*> wv(nb), wo(nb), bo(nb);
+  for (auto& st : c->sts) for (int b = 0; b < 2; ++b) {
+    wv[st.blk0 + b] = st.blk[b].wv2; wo[st.blk0 + b] = st.blk[b].wo2; bo[st.blk0 + b] = st.blk[b].bo2;
+  }
+  char* d = nullptr;
+  RAMP_HIP_CHECK(hipMalloc(&d, 3 * nb * sizeof(void*) + n_rows_pattern * sizeof(int)));
+  RAMP_HIP_CHECK(hipMemcpy(d, wv.data(), nb * sizeof(void*), hipMemcpyHostToDevice));
+  RAMP_HIP_CHECK(hipMemcpy(d + nb * sizeof(void*), wo.data(), nb * sizeof(void*), hipMemcpyHostToDevice));
+  RAMP_HIP_CHECK(hipMemcpy(d + 2 * nb * sizeof(void*), bo.data(), nb * sizeof(void*), hipMemcpyHostToDevice));
+  RAMP_HIP_CHECK(hipMemcpy(d + 3 * nb * sizeof(void*), row_variant_host, n_rows_pattern * sizeof(int), hipMemcpyHostToDevice));
+  int rc = launch_cross_bias(latents, n_variants, c->cfg.context_dim, reinterpret_cast<const float* const*>(d),
+                             reinterpret_cast<const float* const*>(d + nb * sizeof(void*)),
+                             reinterpret_cast<const float* const*>(d + 2 * nb * sizeof(void*)), nb, c->cross_bias, s);
+  // row -> variant table for the largest batch this context may see in one ramp_sample call
+  const int want = std::max(c->row_variant_cap, 1 << 20);
+  if (rc == 0 && c->row_variant_cap < want) {
+    float* p; rc = dev_alloc(c, &p, want); c->row_variant = reinterpret_cast<int*>(p); c->row_variant_cap = want;
+  }
+  if (rc == 0) {
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, c->row_variant,
+                       reinterpret_cast<const int*>(d + 3 * nb * sizeof(void*)), n_rows_pattern, c->row_variant_cap);
+  }
+  RAMP_HIP_CHECK(hipStreamSynchronize(s));
+  RAMP_HIP_CHECK(hipFree(d));
+  c->graph_key.clear();     // scene changed: cross_bias pointer may have moved
+  return rc;
+}
+
+int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, float* f_out, float* eps_out,
+               void* stream) {
+  RAMP_REQUIRE(c && x, "null argument");
+  c->launches = 0;
+  return score_all(c, x, B, n_rp, t, f_out, eps_out, as_stream(stream));
+}
+
+static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, bool chain) {
+  const int B = p->B, H = c->cfg.horizon, S = c->cfg.state_dim;
+  const size_t HS = (size_t)H * S, n = (size_t)B * HS;
+  HardConds hc; hc.idx = c->s_hard_idx; hc.val = c->s_hard_val; hc.n = p->n_hard;
+  // x_T = noise[0]; apply_hard_conditioning; chain[0]
+  RAMP_HIP_CHECK(hipMemcpyAsync(c->s_x, c->s_noise, n * 4, hipMemcpyDeviceToDevice, s));
+  CK(launch_hard_cond(c->s_x, hc, B, H, S, s));
+  if (chain) RAMP_HIP_CHECK(hipMemcpyAsync(c->s_chain, c->s_x, n * 4, hipMemcpyDeviceToDevice, s));
+  ApfArgs ap; ap.cloud = c->s_cloud; ap.window = c->s_window; ap.B = B; ap.H = H; ap.S = S; ap.P = p->apf.n_points;
+  ap.win = p->apf.window; ap.thr = p->apf.threshold; ap.strength = p->apf.strength;
+  for (int j = 0; j < p->n_steps; ++j) {
+    CK(score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s));
+    CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = p->n_rp;
+    m.w0 = (float)p->w0; m.w1 = (float)p->w1; m.w0p1 = (float)(1.0 + p->w0);
+    m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised;
+    float* chain_j = chain ? c->s_chain + (size_t)(j + 1) * n : nullptr;
+    const bool apf = p->apf.cloud != nullptr && p->apply_apf && p->apply_apf[j];
+    if (!p->ddim) {
+      m.coef1 = p->coef1[j]; m.coef2 = p->coef2[j]; m.mean = c->s_mean; m.x0 = nullptr;
+      CK(launch_cfg_mean(m, s));
+      if (apf) { ap.traj = c->s_mean; for (int q = 0; q < std::max(1, p->apf.passes); ++q) CK(launch_apf(ap, s)); }
+      CK(launch_ddpm_finish(c->s_mean, c->s_noise + (size_t)(j + 1) * n, p->stdv[j], p->noise_scale ? p->noise_scale[j] : 1.f, p->use_noise[j],
+                            hc, c->s_x, chain_j, B, H, S, s));
+    } else {
+      m.mean = nullptr; m.x0 = c->s_x0;
+      CK(launch_cfg_mean(m, s));
+      if (apf) {
+        ap.traj = c->s_x0;
+        for (int q = 0; q < std::max(1, p->apf.passes); ++q) { CK(launch_apf(ap, s)); CK(launch_hard_cond(c->s_x0, hc, B, H, S, s)); }
+      }
+      CK(launch_ddim_finish(c->s_x, c->s_x0, p->sqrt_a_t[j], p->sqrt_1m_a_t[j], p->sqrt_a_prev[j], p->dir_coef[j], hc,
+                            c->s_x, chain_j, B, H, S, s));
+    }
+  }
+  return 0;
+}
+
+int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, float* chain_out, float* x_out,
+                void* stream) {
+  RAMP_REQUIRE(c && p && noise, "null argument");
+  RAMP_REQUIRE(p->B > 0 && p->n_steps > 0 && p->n_rp >= 1 && p->n_rp <= 3, "bad sample dims");
+  RAMP_REQUIRE(p->t && p->sqrt_recip && p->sqrt_recipm1, "missing schedule arrays");
+  if (p->ddim) RAMP_REQUIRE(p->sqrt_a_t && p->sqrt_1m_a_t && p->sqrt_a_prev && p->dir_coef, "missing DDIM arrays");
+  else RAMP_REQUIRE(p->coef1 && p->coef2 && p->stdv && p->use_noise, "missing DDPM arrays");
+  RAMP_REQUIRE(p->n_hard == 0 || (p->hard_idx_host && p->hard_val), "missing hard conditions");
+  hipStream_t s = as_stream(stream);
+  const int B = p->B, H = c->cfg.horizon, S = c->cfg.state_dim;
+  const size_t n = (size_t)B * H * S;
+  const bool chain = chain_out != nullptr;
+  const size_t n_noise = (p->ddim ? 1 : (size_t)p->n_steps + 1) * n;
+  CK(ensure_sampler_buffers(c, B, p->n_rp, p->n_steps, chain));
+  for (int j = 0; j < p->n_hard; ++j) RAMP_REQUIRE(p->hard_idx_host[j] >= 0 && p->hard_idx_host[j] < H, "hard index out of range");
+  if (!c->s_hard_idx) { float* q; CK(dev_alloc(c, &q, 256)); c->s_hard_idx = reinterpret_cast<int*>(q); }
+  RAMP_REQUIRE(p->n_hard <= 256, "too many hard conditions");
+  const size_t hv = (size_t)p->n_hard * B * S;
+  if (hv > c->s_hard_val_cap) { CK(dev_alloc(c, &c->s_hard_val, hv)); c->s_hard_val_cap = hv; c->graph_key.clear(); }
+  if (p->apf.cloud) {
+    RAMP_REQUIRE(p->apf.n_points > 0 && p->apf.window >= 0 && p->apf.window <= 64 && p->apf.window_weights_host, "bad APF params");
+    if (!c->s_window) CK(dev_alloc(c, &c->s_window, 256));
+    if ((size_t)p->apf.n_points * 2 > c->s_cloud_cap) {
+      CK(dev_alloc(c, &c->s_cloud, (size_t)p->apf.n_points * 2)); c->s_cloud_cap = (size_t)p->apf.n_points * 2; c->graph_key.clear();
+    }
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->s_window, p->apf.window_weights_host, (2 * p->apf.window + 1) * 4, hipMemcpyHostToDevice, s));
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->s_cloud, p->apf.cloud, (size_t)p->apf.n_points * 8, hipMemcpyDeviceToDevice, s));
+  }
+  if (p->n_hard) {
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->s_hard_idx, p->hard_idx_host, p->n_hard * 4, hipMemcpyHostToDevice, s));
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->s_hard_val, p->hard_val, hv * 4, hipMemcpyDeviceToDevice, s));
+  }
+  RAMP_HIP_CHECK(hipMemcpyAsync(c->s_noise, noise, n_noise * 4, hipMemcpyDeviceToDevice, s));
+  c->launches = 0;
+  if (!p->use_graph) {
+    CK(sample_body(c, p, s, chain));
+  } else {
+    // key: everything baked into the captured nodes
+    std::string key;
+    auto put = [&](const void* q, size_t b) { key.append(static_cast<const char*>(q), b); };
+    put(&p->B, 4); put(&p->n_rp, 4); put(&p->n_steps, 4); put(&p->ddim, 4); put(&p->w0, 8); put(&p->w1, 8);
+    put(p->t, 4 * p->n_steps); put(p->sqrt_recip, 4 * p->n_steps); put(p->sqrt_recipm1, 4 * p->n_steps);
+    if (p->ddim) { put(p->sqrt_a_t, 4 * p->n_steps); put(p->sqrt_1m_a_t, 4 * p->n_steps); put(p->sqrt_a_prev, 4 * p->n_steps); put(p->dir_coef, 4 * p->n_steps); }
+    else { put(p->coef1, 4 * p->n_steps); put(p->coef2, 4 * p->n_steps); put(p->stdv, 4 * p->n_steps); put(p->use_noise, 4 * p->n_steps); }
+    if (p->apply_apf) put(p->apply_apf, 4 * p->n_steps);
+    if (p->noise_scale) put(p->noise_scale, 4 * p->n_steps);
+    put(&p->clip_denoised, 4); put(&p->n_hard, 4);
+    const int has_apf = p->apf.cloud != nullptr; put(&has_apf, 4);
+    put(&p->apf.n_points, 4); put(&p->apf.window, 4); put(&p->apf.threshold, 8); put(&p->apf.strength, 8); put(&p->apf.passes, 4);
+    const int ch = chain; put(&ch, 4);
+    if (key != c->graph_key || !c->graph_exec) {
+      if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+      hipStream_t cs;
+      RAMP_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      RAMP_HIP_CHECK(hipStreamSynchronize(s));
+      RAMP_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+      int rc = sample_body(c, p, cs, chain);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(cs, &g);
+      if (rc != 0) { if (g) (void)hipGraphDestroy(g); (void)hipStreamDestroy(cs); return rc; }
+      if (e != hipSuccess) { (void)hipStreamDestroy(cs); RAMP_HIP_CHECK(e); }
+      e = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g); (void)hipStreamDestroy(cs);
+      RAMP_HIP_CHECK(e);
+      c->graph_key = key;
+    }
+    RAMP_HIP_CHECK(hipGraphLaunch(c->graph_exec, s));
+  }
+  if (chain_out) RAMP_HIP_CHECK(hipMemcpyAsync(chain_out, c->s_chain, (size_t)(p->n_steps + 1) * n * 4, hipMemcpyDeviceToDevice, s));
+  if (x_out) RAMP_HIP_CHECK(hipMemcpyAsync(x_out, c->s_x, n * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// ---- kernel-level entry points ---------------------------------------------------------------------
+int ramp_apf(float* traj, int32_t B, int32_t H, int32_t S, const ramp_apf_params* p, void* stream) {
+  RAMP_REQUIRE(traj && p && p->cloud && p->window_weights_host, "null argument");
+  RAMP_REQUIRE(p->window >= 0 && p->window <= 64, "bad window");
+  hipStream_t s = as_stream(stream);
+  float* w = nullptr;
+  RAMP_HIP_CHECK(hipMalloc(&w, (2 * p->window + 1) * 4));
+  RAMP_HIP_CHECK(hipMemcpyAsync(w, p->window_weights_host, (2 * p->window + 1) * 4, hipMemcpyHostToDevice, s));
+  ApfArgs a; a.traj = traj; a.cloud = p->cloud; a.window = w; a.B = B; a.H = H; a.S = S; a.P = p->n_points; a.win = p->window;
+  a.thr = p->threshold; a.strength = p->strength;
+  int rc = 0;
+  for (int q = 0; q < std::max(1, p->passes) && rc == 0; ++q) rc = launch_apf(a, s);
+  RAMP_HIP_CHECK(hipStreamSynchronize(s));
+  RAMP_HIP_CHECK(hipFree(w));
+  return rc;
+}
+
+int ramp_hard_cond(float* x, int32_t B, int32_t H, int32_t S, int32_t n, const int32_t* idx_host, const float* val,
+                   void* stream) {
+  RAMP_REQUIRE(x && (n == 0 || (idx_host && val)), "null argument");
+  if (n == 0) return 0;
+  for (int j = 0; j < n; ++j) RAMP_REQUIRE(idx_host[j] >= 0 && idx_host[j] < H, "hard index out of range");
+  hipStream_t s = as_stream(stream);
+  int* d = nullptr;
+  RAMP_HIP_CHECK(hipMalloc(&d, n * 4));
+  RAMP_HIP_CHECK(hipMemcpyAsync(d, idx_host, n * 4, hipMemcpyHostToDevice, s));
+  HardConds hc; hc.idx = d; hc.val = val; hc.n = n;
+  int rc = launch_hard_cond(x, hc, B, H, S, s);
+  RAMP_HIP_CHECK(hipStreamSynchronize(s));
+  RAMP_HIP_CHECK(hipFree(d));
+  return rc;
+}
+
+int ramp_traj_costs(const float* traj, int32_t B, int32_t H, int32_t S, const float* cloud, int32_t n_points,
+                    float threshold, int32_t* mask, float* path_len, float* smooth, void* stream) {
+  RAMP_REQUIRE(traj && cloud && mask && path_len && smooth, "null argument");
+  return launch_traj_costs(traj, cloud, B, H, S, n_points, threshold, mask, path_len, smooth, as_stream(stream));
+}
+
+int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32_t n_rp, double w0, double w1,
+                  float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip, float* x0_out,
+                  float* mean_out, float* ecomb_out, void* stream) {
+  RAMP_REQUIRE(x && eps, "null argument");
+  CfgMeanArgs m; m.x = x; m.eps = eps; m.B = B; m.HS = HS; m.n_rp = n_rp; m.w0 = (float)w0; m.w1 = (float)w1;
+  m.w0p1 = (float)(1.0 + w0); m.sqrt_recip = sqrt_recip; m.sqrt_recipm1 = sqrt_recipm1; m.coef1 = coef1; m.coef2 = coef2;
+  m.clip = clip; m.x0 = x0_out; m.mean = mean_out; m.ecomb = ecomb_out;
+  return launch_cfg_mean(m, as_stream(stream));
+}
+
+int ramp_op_gemm(const float* A, const float* W, const float* bias, const float* resid, float* C, int32_t M, int32_t N,
+                 int32_t K, int32_t taps, int32_t shift0, int32_t shift_step, int32_t L, void* stream) {
+  RAMP_REQUIRE(A && W && C, "null argument");
+  GemmArgs a; a.A = A; a.lda = K; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.C = C; a.ldc = N;
+  a.M = M; a.N = N; a.K = K; a.taps = taps; a.shift0 = shift0; a.shift_step = shift_step; a.L = L;
+  return launch_gemm(a, as_stream(stream));
+}
+int ramp_op_groupnorm(const float* x, const float* gamma, const float* beta, const float* tbias, const float* resid,
+                      float* y, float* stats, int32_t R, int32_t L, int32_t C, float eps, int32_t mish, void* stream) {
+  RAMP_REQUIRE(x && gamma && beta && y, "null argument");
+  GnArgs g; g.x = x; g.gamma = gamma; g.beta = beta; g.tbias = tbias; g.resid = resid; g.y = y; g.stats = stats;
+  g.R = R; g.L = L; g.C = C; g.eps = eps; g.mish = mish;
+  return launch_gn_fwd(g, as_stream(stream));
+}
+int ramp_op_groupnorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta,
+                          const float* add, float* dx, int32_t R, int32_t L, int32_t C, int32_t mish, void* stream) {
+  RAMP_REQUIRE(dy && x && stats && gamma && beta && dx, "null argument");
+  GnBwdArgs g; g.dy = dy; g.x = x; g.stats = stats; g.gamma = gamma; g.beta = beta; g.add = add; g.dx = dx;
+  g.R = R; g.L = L; g.C = C; g.mish = mish;
+  return launch_gn_bwd(g, as_stream(stream));
+}
+int ramp_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t n_tok, void* stream) {
+  RAMP_REQUIRE(x && gamma && beta && y, "null argument");
+  return launch_ln_fwd(x, gamma, beta, y, n_tok, as_stream(stream));
+}
+int ramp_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
+                          int32_t n_tok, void* stream) {
+  RAMP_REQUIRE(dy && x && gamma && dx, "null argument");
+  return launch_ln_bwd(dy, x, gamma, add, dx, n_tok, as_stream(stream));
+}
+int ramp_op_geglu(const float* ag, float* hg, int32_t n_tok, int32_t F, void* stream) {
+  RAMP_REQUIRE(ag && hg, "null argument");
+  return launch_geglu_fwd(ag, hg, n_tok, F, as_stream(stream));
+}
+int ramp_op_geglu_bwd(const float* dhg, const float* ag, float* dag, int32_t n_tok, int32_t F, void* stream) {
+  RAMP_REQUIRE(dhg && ag && dag, "null argument");
+  return launch_geglu_bwd(dhg, ag, dag, n_tok, F, as_stream(stream));
+}
+int ramp_op_attention(const float* qkv, float* o, int32_t R, int32_t L, void* stream) {
+  RAMP_REQUIRE(qkv && o, "null argument");
+  return launch_attn_fwd(qkv, o, R, L, as_stream(stream));
+}
+int ramp_op_attention_bwd(const float* qkv, const float* dout, float* dqkv, int32_t R, int32_t L, void* stream) {
+  RAMP_REQUIRE(qkv && dout && dqkv, "null argument");
+  return launch_attn_bwd(qkv, dout, dqkv, R, L, as_stream(stream));
+}
+
+int ramp_debug_read(ramp_ctx* c, const char* kind, const char* module, float* out, int64_t n_floats,
+                    int64_t* n_copied, void* stream) {
+  RAMP_REQUIRE(c && kind && module && out && n_copied, "null argument");
+  auto it = c->dbg.find(std::string(kind) + "/" + module);
+  RAMP_REQUIRE(it != c->dbg.end(), std::string("no debug tap '") + kind + "/" + module + "' (debug_taps off or module unknown)");
+  const size_t n = std::min<size_t>((size_t)n_floats, it->second.second);
+  RAMP_HIP_CHECK(hipMemcpyAsync(out, it->second.first, n * 4, hipMemcpyDeviceToDevice, as_stream(stream)));
+  *n_copied = (int64_t)n;
+  return 0;
+}
+
+int ramp_workspace_bytes(ramp_ctx* c, int64_t* bytes) {
+  RAMP_REQUIRE(c && bytes, "null argument");
+  *bytes = (int64_t)c->arena.total;
+  return 0;
+}
+int ramp_launch_count(ramp_ctx* c, int64_t* n) {
+  RAMP_REQUIRE(c && n, "null argument");
+  *n = c->launches;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,388 @@
+"""Host-side mirrors of the reference's diffusion wrappers over the HIP C ABI.
+
+  StaticGaussianDiffusionModel   mpd/models/diffusion_models/diffusion_model_static.py:21-463
+  GaussianDiffusionModel3d       mpd/models/diffusion_models/diffusion_model_3d.py:19-344
+
+Same constructor kwargs, schedule buffers (computed with the same torch expressions, so they are
+bitwise the reference's), ``run_inference`` / ``conditional_sample`` / ``warmup`` signatures and
+return shapes.  The reverse-diffusion loop itself — score network, CFG combine, x0 clamp,
+posterior / DDIM update, noise, hard conditioning, APF — runs inside ``ramp_sample`` (one
+hipGraph for the whole loop); noise is drawn here with ``torch.randn`` / ``torch.randn_like``
+in the reference's call order so that seeding / patching those functions behaves identically.
+
+Quirks surfaced as kwargs with the reference's hard-coded values as defaults (SURVEY.md App. C,
+Q5/Q6): ``sampler`` ('ddim' is the reference default, ``self.ddim = True``), ``cfg_weight``,
+``apf_*``.  The 3-D wrapper is batched here: every sample gets its own cond/uncond pair (the
+reference indexes rows 0/1 of the output and is only valid for n_samples == 1, Q2).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from copy import copy
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .sample_functions import apply_hard_conditioning, ddpm_sample_fn, extract  # noqa: F401
+
+
+def exponential_beta_schedule(n_diffusion_steps, beta_start=1e-4, beta_end=1.0):
+    """helpers.py:40-46, same torch expression order."""
+    x = torch.linspace(0, n_diffusion_steps, n_diffusion_steps)
+    beta_start = torch.tensor(beta_start, dtype=torch.float32)
+    beta_end = torch.tensor(beta_end, dtype=torch.float32)
+    a = 1 / n_diffusion_steps * torch.log(beta_end / beta_start)
+    return beta_start * torch.exp(a * x)
+
+
+def cosine_beta_schedule(n_diffusion_steps, s=0.008, a_min=0, a_max=0.999):
+    """helpers.py:26-37."""
+    steps = n_diffusion_steps + 1
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    betas = 1 - (ac[1:] / ac[:-1])
+    return torch.tensor(np.clip(betas, a_min=a_min, a_max=a_max), dtype=torch.float32)
+
+
+def make_timesteps(batch_size, i, device):
+    return torch.full((batch_size,), i, device=device, dtype=torch.long)
+
+
+def _f32(values) -> "C.Array":
+    arr = (C.c_float * len(values))(*[float(v) for v in values])
+    return arr
+
+
+def _i32(values) -> "C.Array":
+    return (C.c_int32 * len(values))(*[int(v) for v in values])
+
+
+class _GaussianDiffusionBase(nn.Module):
+    _default_cfg_weight = 2.0
+
+    def __init__(self, model=None, variance_schedule='exponential', n_diffusion_steps=100, clip_denoised=True,
+                 predict_epsilon=False, loss_type='l2', context_model=None, compose=False, use_apf=False,
+                 training=False, sampler: Optional[str] = None, cfg_weight: Optional[float] = None,
+                 compose_weights=None, use_graph: bool = True, **kwargs):
+        super().__init__()
+        self.model = model
+        self.context_model = context_model
+        self.n_diffusion_steps = n_diffusion_steps
+        self.ddim_num_inference_steps = 8 if (compose and use_apf) else 5      # diffusion_model_static.py:40
+        self.compose = compose
+        self.APF = use_apf
+        self.energy_mode = True
+        self.training = training
+        self.state_dim = self.model.state_dim
+        self.use_graph = use_graph
+        self.cfg_weight = self._default_cfg_weight if cfg_weight is None else float(cfg_weight)
+        self.compose_weights = tuple(compose_weights) if compose_weights is not None else self._default_compose
+        self.ddim = self._default_ddim if sampler is None else (sampler == 'ddim')
+        if not predict_epsilon:
+            raise NotImplementedError("predict_epsilon=False: the reference inference configs all use True "
+                                      "(base_config.py:26) and the energy gradient is an epsilon prediction")
+        if variance_schedule == 'cosine':
+            betas = cosine_beta_schedule(n_diffusion_steps, s=0.008, a_min=0, a_max=0.999)
+        elif variance_schedule == 'exponential':
+            betas = exponential_beta_schedule(n_diffusion_steps, beta_start=1e-4, beta_end=1.0)
+        else:
+            raise NotImplementedError
+        alphas = 1. - betas
+        alphas_cumprod = torch.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = torch.cat([torch.ones(1), alphas_cumprod[:-1]])
+        self.clip_denoised = clip_denoised
+        self.predict_epsilon = predict_epsilon
+        self.register_buffer('betas', betas)
+        self.register_buffer('alphas_cumprod', alphas_cumprod)
+        self.register_buffer('alphas_cumprod_prev', alphas_cumprod_prev)
+        self.register_buffer('sqrt_alphas_cumprod', torch.sqrt(alphas_cumprod))
+        self.register_buffer('sqrt_one_minus_alphas_cumprod', torch.sqrt(1. - alphas_cumprod))
+        self.register_buffer('log_one_minus_alphas_cumprod', torch.log(1. - alphas_cumprod))
+        self.register_buffer('sqrt_recip_alphas_cumprod', torch.sqrt(1. / alphas_cumprod))
+        self.register_buffer('sqrt_recipm1_alphas_cumprod', torch.sqrt(1. / alphas_cumprod - 1))
+        posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
+        self.register_buffer('posterior_variance', posterior_variance)
+        self.register_buffer('posterior_log_variance_clipped', torch.log(torch.clamp(posterior_variance, min=1e-20)))
+        self.register_buffer('posterior_mean_coef1', betas * np.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+        self.register_buffer('posterior_mean_coef2',
+                             (1. - alphas_cumprod_prev) * np.sqrt(alphas) / (1. - alphas_cumprod))
+        self.final_alpha_cumprod = torch.tensor([1.0, ])
+
+    _default_ddim = True
+    _default_compose = (2.0, 2.0)
+    # APF constants hard-coded in the reference method bodies
+    apf_ddpm = dict(threshold=0.07, strength=0.1, window=5, after=20)          # diffusion_model_static.py:176-184
+    apf_ddim = dict(threshold=0.07, strength=0.1, window=7, start=2, passes=3)  # diffusion_model_static.py:298-319
+
+    # ------------------------------------------------------------------ helpers
+    def _device(self):
+        return self.betas.device
+
+    def _n_rp(self) -> int:
+        return 3 if self.compose else 2
+
+    def _prepare_scene(self, obstacle_pts: torch.Tensor):
+        """Encode the distinct scene(s) once and hand the variants to the context."""
+        m = self.model
+        dev = self._device()
+        zero = torch.zeros(1, m.context_dim, device=dev)
+        if self.compose:
+            assert obstacle_pts.dim() == 4 and obstacle_pts.shape[0] == 2, \
+                "compose expects obstacle_pts of shape (2, n_obstacles, n_points, dim)"
+            lat = torch.cat([m.encode_scene(obstacle_pts), zero])
+            pattern = [0, 1, 2]
+        else:
+            lat = torch.cat([m.encode_scene(obstacle_pts), zero])
+            pattern = [0, 1]
+        m.set_scene(lat, pattern)
+        m.cached_batch_size = None          # the compat forward() cache is keyed differently
+
+    @staticmethod
+    def _window_weights(window: int) -> torch.Tensor:
+        # APFhelper.py:42-44, same torch expression
+        return torch.exp(-0.5 * torch.square(torch.arange(-window, window + 1)) / (window / 2) ** 2).float()
+
+    def _hard_arrays(self, hard_conds: Dict[int, torch.Tensor], B: int):
+        keys = list(hard_conds.keys())
+        H = self.model.n_support_points
+        idx = [k if k >= 0 else H + k for k in keys]
+        vals = []
+        for k in keys:
+            v = hard_conds[k].to(self._device(), torch.float32)
+            if v.dim() == 1:
+                v = v.unsqueeze(0).expand(B, -1)
+            vals.append(v)
+        val = torch.stack(vals).contiguous() if vals else torch.zeros(0, B, self.state_dim, device=self._device())
+        return idx, val
+
+    def _launch(self, B, noise, hard_conds, obstacle_pts, ddim: bool, steps, apply_apf, noise_scale, apf_cfg,
+                return_chain: bool):
+        """Fill ramp_sample_params from the schedule buffers exactly as the reference's extract() would."""
+        m = self.model
+        dev = self._device()
+        H, S = m.n_support_points, self.state_dim
+        n_steps = len(steps)
+        m.prepare_time_table(self.n_diffusion_steps)
+        self._prepare_scene(obstacle_pts)
+        buf = {k: getattr(self, k).detach().cpu() for k in
+               ('alphas_cumprod', 'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod',
+                'posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped')}
+        p = _lib.RampSampleParams()
+        keep = []          # keep ctypes arrays alive
+
+        def arr_f(vals):
+            a = _f32(vals); keep.append(a); return C.cast(a, _lib.c_f32p)
+
+        def arr_i(vals):
+            a = _i32(vals); keep.append(a); return C.cast(a, _lib.c_i32p)
+
+        p.B, p.n_rp, p.n_steps, p.ddim = B, self._n_rp(), n_steps, int(ddim)
+        if self.compose:
+            p.w0, p.w1 = float(self.compose_weights[0]), float(self.compose_weights[1])
+        else:
+            p.w0, p.w1 = float(self.cfg_weight), 0.0
+        p.t = arr_i(steps)
+        p.sqrt_recip = arr_f([buf['sqrt_recip_alphas_cumprod'][t] for t in steps])
+        p.sqrt_recipm1 = arr_f([buf['sqrt_recipm1_alphas_cumprod'][t] for t in steps])
+        if not ddim:
+            p.coef1 = arr_f([buf['posterior_mean_coef1'][t] for t in steps])
+            p.coef2 = arr_f([buf['posterior_mean_coef2'][t] for t in steps])
+            # model_std = exp(0.5 * posterior_log_variance_clipped[t])   (sample_functions.py:35-36)
+            p.stdv = arr_f([torch.exp(0.5 * buf['posterior_log_variance_clipped'][t]) for t in steps])
+            p.use_noise = arr_i([0 if t == 0 else 1 for t in steps])
+            p.noise_scale = arr_f(noise_scale)
+        else:
+            ac = buf['alphas_cumprod']
+            K = self.ddim_num_inference_steps
+            sa, s1, sp, dc = [], [], [], []
+            for t in steps:
+                prev = t - self.n_diffusion_steps // K
+                a_t = ac[t]
+                a_prev = ac[prev] if prev >= 0 else self.final_alpha_cumprod[0]
+                variance = (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)
+                std_dev_t = 0.0 * variance ** 0.5                                   # eta = 0
+                sa.append(a_t ** 0.5); s1.append((1 - a_t) ** 0.5); sp.append(a_prev ** 0.5)
+                dc.append((1 - a_prev - std_dev_t ** 2) ** 0.5)
+            p.sqrt_a_t, p.sqrt_1m_a_t, p.sqrt_a_prev, p.dir_coef = arr_f(sa), arr_f(s1), arr_f(sp), arr_f(dc)
+        p.apply_apf = arr_i(apply_apf)
+        p.clip_denoised = int(bool(self.clip_denoised))
+        idx, val = self._hard_arrays(hard_conds, B)
+        p.n_hard = len(idx)
+        p.hard_idx_host = arr_i(idx) if idx else None
+        p.hard_val = _lib.ptr(val) if idx else None
+        cloud = None
+        if apf_cfg is not None and any(apply_apf):
+            if self.compose:      # first six obstacles of scene A + first four of scene B (static.py:306-310)
+                cloud = torch.cat([obstacle_pts[0], obstacle_pts[1][:4]], dim=0).reshape(-1, 2)
+            else:
+                cloud = obstacle_pts.reshape(-1, 2)
+            cloud = cloud.to(dev, torch.float32).contiguous()
+            w = self._window_weights(apf_cfg['window']).contiguous()
+            keep.append(w)
+            p.apf.cloud = _lib.ptr(cloud)
+            p.apf.n_points = cloud.shape[0]
+            p.apf.window = int(apf_cfg['window'])
+            p.apf.window_weights_host = C.cast(w.data_ptr(), _lib.c_f32p)
+            p.apf.threshold = float(apf_cfg['threshold'])
+            p.apf.strength = float(apf_cfg['strength'])
+            p.apf.passes = int(apf_cfg.get('passes', 1))
+        p.use_graph = int(self.use_graph)
+        chain = torch.empty((n_steps + 1, B, H, S), device=dev, dtype=torch.float32) if return_chain else None
+        x_out = torch.empty((B, H, S), device=dev, dtype=torch.float32)
+        noise = noise.contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().ramp_sample(m.ctx(), C.byref(p), _lib.ptr(noise), _lib.ptr(chain), _lib.ptr(x_out),
+                                               _lib.current_stream()), "ramp_sample")
+        return x_out, chain
+
+    # ------------------------------------------------------------------ loops (reference signatures)
+    @torch.no_grad()
+    def p_sample_loop(self, shape, hard_conds, context=None, return_chain=False, traj_normalized=None,
+                      obstacle_pts=None, sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=0,
+                      noise_std_extra_schedule_fn=None, **sample_kwargs):
+        """diffusion_model_static.py:232-256 / diffusion_model_3d.py:185-218 (resample_steps = 1)."""
+        device = self._device()
+        B = shape[0]
+        x = torch.randn(shape, device=device)
+        noises = [x]
+        steps, scales = [], []
+        for i in reversed(range(-n_diffusion_steps_without_noise, self.n_diffusion_steps)):
+            t = max(i, 0)                                           # sample_functions.py:25-27
+            steps.append(t)
+            noises.append(torch.randn_like(x))                      # drawn every step, zeroed at t == 0
+            scales.append(1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(i)))
+        apf = [1 if (self.APF and self._supports_apf and j > self.apf_ddpm['after']) else 0 for j in range(len(steps))]
+        cfg = dict(self.apf_ddpm, passes=1) if any(apf) else None
+        x_out, chain = self._launch(B, torch.stack(noises), hard_conds, obstacle_pts, False, steps, apf, scales, cfg,
+                                    return_chain)
+        if return_chain:
+            return x_out, chain.permute(1, 0, 2, 3)       # reference stacks along dim=1
+        return x_out
+
+    def ddim_set_timesteps(self, num_inference_steps) -> np.ndarray:
+        self.num_inference_steps = num_inference_steps
+        step_ratio = self.n_diffusion_steps // self.num_inference_steps
+        return (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
+
+    @torch.no_grad()
+    def ddim_p_sample_loop(self, shape, hard_conds, context=None, return_chain=False, traj_normalized=None,
+                           obstacle_pts=None, t_start_guide=float('inf'), guide=None, n_guide_steps=1,
+                           **sample_kwargs):
+        """diffusion_model_static.py:347-384 (eta = 0, use_clipped_model_output)."""
+        device = self._device()
+        B = shape[0]
+        x = torch.randn(shape, device=device)
+        steps = [int(i) for i in self.ddim_set_timesteps(self.ddim_num_inference_steps)]
+        apf = [1 if (self.APF and self._supports_apf and j >= self.apf_ddim['start']) else 0 for j in range(len(steps))]
+        cfg = dict(self.apf_ddim) if any(apf) else None
+        x_out, chain = self._launch(B, x.unsqueeze(0), hard_conds, obstacle_pts, True, steps, apf, None, cfg,
+                                    return_chain)
+        if return_chain:
+            return x_out, chain.permute(1, 0, 2, 3)
+        return x_out
+
+    @torch.no_grad()
+    def conditional_sample(self, hard_conds, horizon=None, batch_size=1, ddim=False, traj_normalized=None,
+                           obstacle_pts=None, **sample_kwargs):
+        horizon = horizon or self.model.n_support_points
+        shape = (batch_size, horizon, self.state_dim)
+        if self.ddim:
+            for k in ('sample_fn', 'n_diffusion_steps_without_noise', 'noise_std_extra_schedule_fn'):
+                sample_kwargs.pop(k, None)      # silently ignored by the reference's DDIM loop
+            return self.ddim_p_sample_loop(shape, hard_conds, traj_normalized=traj_normalized,
+                                           obstacle_pts=obstacle_pts, **sample_kwargs)
+        return self.p_sample_loop(shape, hard_conds, traj_normalized=traj_normalized, obstacle_pts=obstacle_pts,
+                                  **sample_kwargs)
+
+    def forward(self, cond, *args, **kwargs):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def warmup(self, horizon=64, traj_normalized=None, obstacle_pts=None, batch_size=None, device='cuda'):
+        """diffusion_model_static.py:405-433: one throw-away score evaluation (consumes one randn)."""
+        shape = (batch_size, horizon, self.state_dim)
+        x = torch.randn(shape, device=device)
+        self.model.prepare_time_table(self.n_diffusion_steps)
+        self._prepare_scene(obstacle_pts.to(self._device()))
+        eps = torch.empty((batch_size * self._n_rp(), horizon, self.state_dim), device=self._device())
+        with torch.cuda.device(self._device()):
+            _lib.check(_lib.load().ramp_score(self.model.ctx(), _lib.ptr(x.contiguous()), batch_size, self._n_rp(), 1,
+                                              None, _lib.ptr(eps), _lib.current_stream()), "ramp_score")
+
+    @torch.no_grad()
+    def run_inference(self, context=None, hard_conds=None, n_samples=1, return_chain=False, traj_normalized=None,
+                      obstacle_pts=None, **diffusion_kwargs):
+        """diffusion_model_static.py:437-463: returns (steps+1, B, H, S) if return_chain else (B, H, S)."""
+        hard_conds = copy(hard_conds)
+        for k, v in hard_conds.items():
+            hard_conds[k] = v.to(self._device()).unsqueeze(0).expand(n_samples, -1) if v.dim() == 1 else v
+        for k in ('guide', 'n_guide_steps', 't_start_guide'):
+            diffusion_kwargs.pop(k, None)           # accepted and unused by the reference samplers
+        samples, chain = self.conditional_sample(hard_conds, context=context, batch_size=n_samples, ddim=False,
+                                                 return_chain=True, traj_normalized=traj_normalized,
+                                                 obstacle_pts=obstacle_pts.to(self._device()), **diffusion_kwargs)
+        chain = chain.permute(1, 0, 2, 3)           # 'b diffsteps h d -> diffsteps b h d'
+        if return_chain:
+            return chain
+        return chain[-1]
+
+    # ------------------------------------------------------------------ single-step compat API
+    @torch.no_grad()
+    def p_mean_variance(self, x, hard_conds, context, t, traj_normalized=None, obstacle_pts=None, forward_t=None,
+                        compose=False):
+        """One p_mean_variance on the HIP kernels (diffusion_model_static.py:149-186); obstacle_pts is the
+        un-batched cloud as passed by the loops.  Returns what the reference returns for the current mode."""
+        dev = self._device()
+        B = x.shape[0]
+        ti = int(t.reshape(-1)[0])
+        self.model.prepare_time_table(self.n_diffusion_steps)
+        pts = obstacle_pts
+        if not self.compose and pts.dim() == 4 and pts.shape[0] == 1:
+            pts = pts[0]
+        self._prepare_scene(pts.to(dev))
+        xx = x.detach().to(dev, torch.float32).contiguous()
+        n_rp = self._n_rp()
+        eps = torch.empty((B * n_rp,) + tuple(x.shape[1:]), device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ramp_score(self.model.ctx(), _lib.ptr(xx), B, n_rp, ti, None, _lib.ptr(eps),
+                                      _lib.current_stream()), "ramp_score")
+            x0 = torch.empty_like(xx); mean = torch.empty_like(xx); ec = torch.empty_like(xx)
+            w0, w1 = (self.compose_weights if self.compose else (self.cfg_weight, 0.0))
+            _lib.check(lib.ramp_cfg_mean(_lib.ptr(xx), _lib.ptr(eps), B, xx[0].numel(), n_rp, float(w0), float(w1),
+                                         float(self.sqrt_recip_alphas_cumprod[ti]),
+                                         float(self.sqrt_recipm1_alphas_cumprod[ti]),
+                                         float(self.posterior_mean_coef1[ti]), float(self.posterior_mean_coef2[ti]),
+                                         int(bool(self.clip_denoised)), _lib.ptr(x0), _lib.ptr(mean), _lib.ptr(ec),
+                                         _lib.current_stream()), "ramp_cfg_mean")
+        pv = extract(self.posterior_variance, t, x.shape)
+        plv = extract(self.posterior_log_variance_clipped, t, x.shape)
+        if self.ddim:
+            return mean, pv, plv, x0, ec
+        if self.APF and self._supports_apf and forward_t is not None and forward_t > self.apf_ddpm['after']:
+            from .apf import ObstacleField, avoidance
+            field = ObstacleField(pts.reshape(-1, 2), distance_threshold=self.apf_ddpm['threshold'])
+            mean = avoidance(mean, field, avoidance_window=self.apf_ddpm['window'],
+                             avoidance_strength=self.apf_ddpm['strength'])
+        return mean, pv, plv
+
+    _supports_apf = True
+
+
+class StaticGaussianDiffusionModel(_GaussianDiffusionBase):
+    """2-D sampler: CFG w = 2, compose w1 = w2 = 2, DDIM-5 by default, APF hook."""
+    _default_cfg_weight = 2.0          # diffusion_model_static.py:163
+    _default_compose = (2.0, 2.0)      # diffusion_model_static.py:205
+    _default_ddim = True               # diffusion_model_static.py:41
+
+
+class GaussianDiffusionModel3d(_GaussianDiffusionBase):
+    """3-D sampler: always DDPM, CFG w = 5.75, compose w1 = w2 = 5, no APF (diffusion_model_3d.py:147-218)."""
+    _default_cfg_weight = 5.75         # diffusion_model_3d.py:150
+    _default_compose = (5.0, 5.0)      # diffusion_model_3d.py:170-171
+    _default_ddim = False
+    _supports_apf = False

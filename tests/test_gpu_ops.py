@@ -1,0 +1,202 @@
+"""Kernel-level parity: each HIP kernel (through the C ABI) against the oracle's function of the same name,
+and against the reference fixtures where they exist (APF, costs)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ramp_oracle as O
+from ramp_amd import _lib
+from util import GOLDEN, dev, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def S():
+    return _lib.current_stream()
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+@pytest.mark.parametrize("M,N,K,taps,L", [
+    (96, 256, 256, 1, 1), (1000, 768, 256, 1, 1), (333, 2048, 256, 1, 1), (257, 256, 1024, 1, 1),
+    (48 * 5, 32, 32, 5, 48), (24 * 7, 64, 32, 5, 24), (6 * 11, 128, 512, 5, 6), (12 * 9, 64, 128, 5, 12),
+    (130, 32, 256, 1, 1), (64 * 3, 32, 32, 5, 64),
+])
+@pytest.mark.parametrize("backward", [False, True])
+def test_gemm_taps(M, N, K, taps, L, backward):
+    """C = sum_tap shift(A) W_tap^T + bias + resid, exact-fp32 MFMA: vs float64 numpy within fp32 rounding."""
+    g = rng(M + N + K)
+    A = g.standard_normal((M, K), dtype=np.float32)
+    W = (g.standard_normal((taps, N, K), dtype=np.float32) / np.sqrt(K * taps)).astype(np.float32)
+    bias = g.standard_normal(N, dtype=np.float32)
+    resid = g.standard_normal((M, N), dtype=np.float32)
+    shift0, step = ((taps // 2, -1) if backward else (-(taps // 2), 1)) if taps > 1 else (0, 0)
+    ref = np.zeros((M, N))
+    A3 = A.reshape(M // L, L, K).astype(np.float64)
+    for j in range(taps):
+        sh = shift0 + j * step
+        Ash = np.zeros_like(A3)
+        if sh >= 0:
+            Ash[:, :L - sh] = A3[:, sh:]
+        else:
+            Ash[:, -sh:] = A3[:, :L + sh]
+        ref += Ash.reshape(M, K) @ W[j].astype(np.float64).T
+    ref += bias + resid
+    out = torch.empty((M, N), device="cuda")
+    dA, dW, db, dr = dev(A), dev(W), dev(bias), dev(resid)
+    _lib.check(_lib.load().ramp_op_gemm(_lib.ptr(dA), _lib.ptr(dW), _lib.ptr(db), _lib.ptr(dr), _lib.ptr(out),
+                                        M, N, K, taps, shift0, step, L, S()))
+    assert rel(out.cpu().numpy(), ref) < 3e-6
+
+
+@pytest.mark.parametrize("R,L,C", [(3, 48, 32), (5, 24, 64), (2, 12, 128), (7, 6, 256), (2, 64, 32), (3, 8, 256), (2, 24, 32)])
+@pytest.mark.parametrize("mish", [0, 1])
+def test_groupnorm_fwd_bwd(R, L, C, mish):
+    g = rng(R * L + C + mish)
+    x = (g.standard_normal((R, L, C)) * 1.5 + 0.3).astype(np.float32)
+    gam = (1 + 0.1 * g.standard_normal(C)).astype(np.float32); bet = (0.1 * g.standard_normal(C)).astype(np.float32)
+    tb = g.standard_normal(C).astype(np.float32); res = g.standard_normal((R, L, C)).astype(np.float32)
+    dy = g.standard_normal((R, L, C)).astype(np.float32)
+    eps = 1e-6 if not mish else 1e-5
+    n, cache = O.groupnorm_fwd(x.astype(np.float64), gam, bet, 8, eps)
+    y_ref = (O.mish(n) if mish else n) + tb + res
+    dn = dy * (O.mish_grad(n) if mish else 1.0)
+    dx_ref = O.groupnorm_bwd(dn, gam.astype(np.float64), cache) + res
+    y = torch.empty((R, L, C), device="cuda"); st = torch.empty((R, 8, 2), device="cuda"); dx = torch.empty_like(y)
+    lib = _lib.load()
+    d = {k: dev(v) for k, v in dict(x=x, gam=gam, bet=bet, tb=tb, res=res, dy=dy).items()}
+    _lib.check(lib.ramp_op_groupnorm(_lib.ptr(d["x"]), _lib.ptr(d["gam"]), _lib.ptr(d["bet"]), _lib.ptr(d["tb"]),
+                                     _lib.ptr(d["res"]), _lib.ptr(y), _lib.ptr(st), R, L, C, eps, mish, S()))
+    _lib.check(lib.ramp_op_groupnorm_bwd(_lib.ptr(d["dy"]), _lib.ptr(d["x"]), _lib.ptr(st), _lib.ptr(d["gam"]),
+                                         _lib.ptr(d["bet"]), _lib.ptr(d["res"]), _lib.ptr(dx), R, L, C, mish, S()))
+    assert rel(y.cpu().numpy(), y_ref) < 3e-6
+    assert rel(dx.cpu().numpy(), dx_ref) < 5e-6
+
+
+@pytest.mark.parametrize("n_tok", [1, 5, 4097])
+def test_layernorm_fwd_bwd(n_tok):
+    g = rng(n_tok)
+    x = (g.standard_normal((n_tok, 256)) * 2 + 0.5).astype(np.float32)
+    gam = (1 + 0.1 * g.standard_normal(256)).astype(np.float32); bet = (0.1 * g.standard_normal(256)).astype(np.float32)
+    dy = g.standard_normal((n_tok, 256)).astype(np.float32); add = g.standard_normal((n_tok, 256)).astype(np.float32)
+    y_ref, cache = O.layernorm_fwd(x.astype(np.float64), gam, bet)
+    dx_ref = O.layernorm_bwd(dy.astype(np.float64), gam, cache) + add
+    y = torch.empty((n_tok, 256), device="cuda"); dx = torch.empty_like(y)
+    lib = _lib.load()
+    d = {k: dev(v) for k, v in dict(x=x, gam=gam, bet=bet, dy=dy, add=add).items()}
+    _lib.check(lib.ramp_op_layernorm(_lib.ptr(d["x"]), _lib.ptr(d["gam"]), _lib.ptr(d["bet"]), _lib.ptr(y), n_tok, S()))
+    _lib.check(lib.ramp_op_layernorm_bwd(_lib.ptr(d["dy"]), _lib.ptr(d["x"]), _lib.ptr(d["gam"]), _lib.ptr(d["add"]),
+                                         _lib.ptr(dx), n_tok, S()))
+    assert rel(y.cpu().numpy(), y_ref) < 2e-6
+    assert rel(dx.cpu().numpy(), dx_ref) < 3e-6
+
+
+def test_geglu_fwd_bwd():
+    g = rng(3)
+    n_tok, F = 37, 1024
+    ag = (g.standard_normal((n_tok, 2 * F)) * 2).astype(np.float32)
+    dh = g.standard_normal((n_tok, F)).astype(np.float32)
+    a, gg = ag[:, :F].astype(np.float64), ag[:, F:].astype(np.float64)
+    hg_ref = a * O.gelu(gg)
+    dag_ref = np.concatenate([dh * O.gelu(gg), dh * a * O.gelu_grad(gg)], axis=-1)
+    hg = torch.empty((n_tok, F), device="cuda"); dag = torch.empty((n_tok, 2 * F), device="cuda")
+    lib = _lib.load(); dag_in = dev(ag); ddh = dev(dh)
+    _lib.check(lib.ramp_op_geglu(_lib.ptr(dag_in), _lib.ptr(hg), n_tok, F, S()))
+    _lib.check(lib.ramp_op_geglu_bwd(_lib.ptr(ddh), _lib.ptr(dag_in), _lib.ptr(dag), n_tok, F, S()))
+    assert rel(hg.cpu().numpy(), hg_ref) < 2e-6
+    assert rel(dag.cpu().numpy(), dag_ref) < 2e-6
+
+
+@pytest.mark.parametrize("L", [6, 8, 12, 16, 24, 32, 48, 64])
+@pytest.mark.parametrize("R", [1, 7])
+def test_attention_fwd_bwd(L, R):
+    """4 x 64 softmax attention within each row of L tokens, forward and (dq, dk, dv)."""
+    g = rng(L * 10 + R)
+    qkv = g.standard_normal((R, L, 768)).astype(np.float32)
+    do = g.standard_normal((R, L, 256)).astype(np.float32)
+    q, k, v = (qkv[..., i * 256:(i + 1) * 256].astype(np.float64).reshape(R, L, 4, 64).transpose(0, 2, 1, 3) for i in range(3))
+    P = O.softmax_last((q @ k.transpose(0, 1, 3, 2)) * 0.125)
+    o_ref = (P @ v).transpose(0, 2, 1, 3).reshape(R, L, 256)
+    d_o = do.astype(np.float64).reshape(R, L, 4, 64).transpose(0, 2, 1, 3)
+    dv = P.transpose(0, 1, 3, 2) @ d_o
+    dP = d_o @ v.transpose(0, 1, 3, 2)
+    dS = P * (dP - (dP * P).sum(-1, keepdims=True))
+    dq = dS @ k * 0.125; dk = dS.transpose(0, 1, 3, 2) @ q * 0.125
+    dqkv_ref = np.concatenate([u.transpose(0, 2, 1, 3).reshape(R, L, 256) for u in (dq, dk, dv)], axis=-1)
+    o = torch.empty((R, L, 256), device="cuda"); dqkv = torch.empty((R, L, 768), device="cuda")
+    lib = _lib.load(); dq_in = dev(qkv); ddo = dev(do)
+    _lib.check(lib.ramp_op_attention(_lib.ptr(dq_in), _lib.ptr(o), R, L, S()))
+    _lib.check(lib.ramp_op_attention_bwd(_lib.ptr(dq_in), _lib.ptr(ddo), _lib.ptr(dqkv), R, L, S()))
+    assert rel(o.cpu().numpy(), o_ref) < 3e-6
+    assert rel(dqkv.cpu().numpy(), dqkv_ref) < 5e-6
+
+
+@pytest.mark.parametrize("name", ["rand", "line", "nohit", "ends", "big"])
+def test_apf_against_reference_fixture(name):
+    """avoidance() in/out pairs captured from the reference (APFhelper.py:37-104)."""
+    from ramp_amd.apf import ObstacleField, avoidance
+    g = np.load(f"{GOLDEN}/apf_cases.npz")
+    thr, strength, win = g[name + "/params"]
+    traj = dev(g[name + "/traj"])
+    out = avoidance(traj, ObstacleField(g[name + "/cloud"], distance_threshold=float(thr)),
+                    avoidance_window=int(win), avoidance_strength=float(strength)).cpu().numpy()
+    assert np.array_equal(traj.cpu().numpy(), g[name + "/traj"])        # input untouched (returns a copy)
+    assert np.abs(out - g[name + "/out"]).max() < 5e-7
+    assert np.array_equal(out[..., 2:], g[name + "/traj"][..., 2:])
+    if name == "nohit":
+        assert np.array_equal(out, g[name + "/traj"])
+
+
+def test_apf_large_cloud_and_oracle():
+    """8k-point cloud (streams through LDS in 8 tiles), B=64, H=64, S=6 vs the oracle."""
+    from ramp_amd.apf import ObstacleField, avoidance
+    from ramp_amd import synth
+    g = rng(11)
+    cloud = synth.make_cloud(40, 200, 2, seed=5).reshape(-1, 2)
+    traj = g.uniform(-1, 1, size=(64, 64, 6)).astype(np.float32)
+    ref = O.apf_avoidance(traj.copy(), cloud, 0.07, 0.1, 7)
+    out = avoidance(dev(traj), ObstacleField(cloud, 0.07), avoidance_window=7, avoidance_strength=0.1).cpu().numpy()
+    assert (ref != traj).sum() > 100
+    assert np.abs(out - ref).max() < 5e-7
+
+
+def test_costs_against_reference_fixture():
+    from ramp_amd import cost
+    g = np.load(f"{GOLDEN}/cost_cases.npz")
+    tr, cl = dev(g["trajs"]), dev(g["cloud"])
+    for thr in (0.02, 0.05, 0.1):
+        assert np.array_equal(cost.compute_collision_with_pointcloud(tr, cl, thr).cpu().numpy(), g[f"mask_{thr}"])
+    assert rel(cost.compute_path_length(tr).cpu().numpy(), g["path_length"]) < 1e-6
+    assert rel(cost.compute_smoothness(tr).cpu().numpy(), g["smoothness"]) < 1e-6
+    best, best_cost, total, free, idx = cost.compute_trajectory_costs(tr, cl, collision_threshold=0.05)
+    assert np.array_equal(free.cpu().numpy(), g["free_mask"]) and int(idx) == int(g["best_index"])
+    assert rel(total.cpu().numpy(), g["total_costs"]) < 1e-5
+    assert np.array_equal(best.cpu().numpy(), g["best"])
+
+
+def test_hard_conditioning_and_cfg_mean():
+    from ramp_amd.sample_functions import apply_hard_conditioning
+    g = rng(5)
+    x = g.standard_normal((5, 48, 4)).astype(np.float32)
+    start = g.standard_normal(4).astype(np.float32); goal = g.standard_normal((5, 4)).astype(np.float32)
+    xd = dev(x)
+    apply_hard_conditioning(xd, {0: torch.from_numpy(start), 47: torch.from_numpy(goal), -2: torch.from_numpy(start)})
+    want = x.copy(); want[:, 0] = start; want[:, 47] = goal; want[:, 46] = start
+    assert np.array_equal(xd.cpu().numpy(), want)
+    # CFG combine / x0 / clamp / posterior mean: bitwise vs the same float32 expression order in numpy
+    eps = g.standard_normal((10, 48, 4)).astype(np.float32) * 3
+    A, Bc, c1, c2, w = np.float32(1.7), np.float32(2.9), np.float32(0.3), np.float32(0.69), 2.0
+    e = np.float32(1 + w) * eps[0::2] - np.float32(w) * eps[1::2]
+    x0 = np.clip(A * x - Bc * e, -1, 1).astype(np.float32)
+    mean = c1 * x0 + c2 * x
+    o0 = torch.empty((5, 48, 4), device="cuda"); om = torch.empty_like(o0); oe = torch.empty_like(o0)
+    de, dx = dev(eps), dev(x)
+    _lib.check(_lib.load().ramp_cfg_mean(_lib.ptr(dx), _lib.ptr(de), 5, 192, 2, w, 0.0, A, Bc, c1, c2, 1,
+                                         _lib.ptr(o0), _lib.ptr(om), _lib.ptr(oe), S()))
+    assert np.array_equal(oe.cpu().numpy(), e) and np.array_equal(o0.cpu().numpy(), x0)
+    assert np.array_equal(om.cpu().numpy(), mean)
+    assert (np.abs(x0) == 1).sum() > 10          # the clamp was exercised

@@ -1,0 +1,120 @@
+"""CPU-only checks of the host side: C-ABI symbols, state_dict contract, scene encoders, schedule tables."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from ramp_amd import _lib, synth
+from ramp_amd.spec import SCHEDULE_BUFFERS, make_unet_spec, unet_param_shapes
+from util import GOLDEN, rel, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/ramp_hip.h is exported by the built .so and bound in _lib."""
+    hdr = open(os.path.join(ROOT, "include", "ramp_hip.h")).read()
+    declared = set(re.findall(r"\b(ramp_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ramp_ctx"}
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} not exported"
+        assert name in _lib.PROTOTYPES, f"{name} not bound in ramp_amd/_lib.py"
+    assert lib.ramp_version() >= 1
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device context creation fails loudly instead of silently computing on the host."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    cfg = _lib.RampConfig(4, 48, 32, 4, 320, 16, 0, 0)
+    h = C.c_void_p()
+    assert lib.ramp_create(C.byref(cfg), C.byref(h)) != 0
+    assert b"device" in lib.ramp_last_error().lower()
+    from ramp_amd.apf import ObstacleField, avoidance
+    with pytest.raises(_lib.RampHipError):
+        avoidance(torch.zeros(1, 48, 4), ObstacleField(np.zeros((4, 2), np.float32)))
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors of the C structs have the sizes the C compiler gives them."""
+    import subprocess, tempfile
+    src = '#include "ramp_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n", sizeof(ramp_config), sizeof(ramp_apf_params), sizeof(ramp_sample_params));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
+    assert [int(v) for v in out] == [C.sizeof(_lib.RampConfig), C.sizeof(_lib.RampApfParams), C.sizeof(_lib.RampSampleParams)]
+
+
+@pytest.mark.parametrize("S,o3,n", [(4, False, 684), (6, True, 608)])
+def test_state_dict_contract(S, o3, n):
+    """Key names/shapes follow the reference checkpoint contract; the wrapper adds the
+    12 schedule buffers and the 'model.' prefix."""
+    from ramp_amd.models import StaticGaussianDiffusionModel, TemporalUnetInference
+    from ramp_amd.unet import load_numpy_state_dict
+    sp = make_unet_spec(S, 48, obstacle_3d=o3)
+    shapes = unet_param_shapes(sp)
+    assert len(shapes) == n
+    sd = weights(S, 48, o3)
+    u = TemporalUnetInference(n_support_points=48, state_dim=S, obstacle_3d=o3)
+    load_numpy_state_dict(u, sd)
+    back = u.state_dict()
+    assert set(back) == set(shapes)
+    for k in shapes:
+        assert tuple(back[k].shape) == tuple(shapes[k]), k
+        assert np.array_equal(back[k].numpy(), sd[k]), k
+    dm = StaticGaussianDiffusionModel(model=u, n_diffusion_steps=25, predict_epsilon=True)
+    full = dm.state_dict()
+    assert set(full) == set(SCHEDULE_BUFFERS) | {"model." + k for k in shapes}
+    dm2 = StaticGaussianDiffusionModel(model=TemporalUnetInference(n_support_points=48, state_dim=S, obstacle_3d=o3),
+                                       n_diffusion_steps=25, predict_epsilon=True)
+    dm2.load_state_dict(full)                      # wrapper-level load with 'model.' prefix
+    assert np.array_equal(dm2.model.state_dict()["time_mlp.encoder.1.weight"].numpy(), sd["time_mlp.encoder.1.weight"])
+    with pytest.raises(RuntimeError):
+        bad = dict(full); bad.pop("model.downs.0.0.cond_mlp.1.bias")
+        dm2.load_state_dict(bad)
+
+
+@pytest.mark.parametrize("T", [25, 50, 100])
+def test_schedule_buffers_bitwise(T):
+    """The wrapper computes its tables with the reference's own torch expressions: bitwise equal."""
+    from ramp_amd.models import StaticGaussianDiffusionModel, TemporalUnetInference
+    g = np.load(f"{GOLDEN}/schedule_T{T}.npz")
+    dm = StaticGaussianDiffusionModel(model=TemporalUnetInference(n_support_points=48, state_dim=4),
+                                      n_diffusion_steps=T, predict_epsilon=True)
+    for k in SCHEDULE_BUFFERS:
+        assert np.array_equal(getattr(dm, k).numpy(), g[k]), k
+
+
+def test_scene_encoders_match_golden():
+    """The torch scene encoders (run once per scene above the C ABI) against the reference's latents."""
+    from ramp_amd.models import TemporalUnetInference
+    from ramp_amd.unet import load_numpy_state_dict
+    g = np.load(f"{GOLDEN}/scene_latents.npz")
+    u2 = load_numpy_state_dict(TemporalUnetInference(n_support_points=48, state_dim=4), weights(4, 48, False)).eval()
+    u3 = load_numpy_state_dict(TemporalUnetInference(n_support_points=48, state_dim=6, obstacle_3d=True),
+                               weights(6, 48, True)).eval()
+    with torch.no_grad():
+        for k in ("2d_6x64", "2d_16x64"):
+            lat = u2.scene_encoder(torch.from_numpy(g["cloud" + k])[None])[0].numpy()
+            assert rel(lat, g["lat" + k]) < 2e-6
+        for k in ("3d_5x50", "3d_20x200"):
+            lat = u3.scene_encoder(torch.from_numpy(g["cloud" + k])[None])[0].numpy()
+            assert rel(lat, g["lat" + k]) < 2e-6
+
+
+def test_synthetic_inputs_are_deterministic():
+    a = synth.make_cloud(16, 64, 2, seed=43)
+    b = synth.make_cloud(16, 64, 2, seed=43)
+    assert np.array_equal(a, b) and a.shape == (16, 64, 2) and a.dtype == np.float32
+    assert np.abs(a).max() < 0.9
+    n1 = synth.make_noise((3, 2, 48, 4), seed=7)
+    assert np.array_equal(n1, synth.make_noise((3, 2, 48, 4), seed=7))
+    g = np.load(f"{GOLDEN}/scene_latents.npz")
+    assert np.array_equal(g["cloud2d_16x64"], a)      # fixtures were generated from the same generator
