@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sampled trajectories/sec of the RAMP energy-based diffusion sampler on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE whole sampling job of the workload BASELINE.json quotes the metric on
+(configs[1]: Maze2D static, B = 4096 trajectories, H = 48, S = 4, T = 25 DDPM reverse steps with
+CFG (2 network rows per trajectory), 1k-point cloud, APF on for forward_t > 20): 25 x 8192 score-net
+forward+backward evaluations, the sampler arithmetic, the final RCCL all-gather (N > 1).  Inputs
+(weights, scene latent, noise, hard conditions) are resident in HBM when the timed region starts.
+Weak scaling: every rank samples its own B trajectories; value = N*B*K / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event timing of
+the dominant kernel, the fp32-MFMA GEMM, on its launch stream) and `cpu_baseline` (the numpy oracle —
+a CPU port of the reference algorithm — timed on this host on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# reduced algorithmic FLOPs per sample-eval (fwd + bwd), 2-D S=4 H=48
+FLOP_PER_ROW_EVAL = 1.324e9
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (BASELINE configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="trajectories in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def build_model(B, device):
+    import torch
+    from ramp_amd import synth
+    from ramp_amd.models import StaticGaussianDiffusionModel, TemporalUnetInference
+    from ramp_amd.spec import make_unet_spec
+    from ramp_amd.unet import load_numpy_state_dict
+    sp = make_unet_spec(4, 48)
+    sd = synth.make_unet_state_dict(sp, seed=0)
+    unet = TemporalUnetInference(n_support_points=48, state_dim=4, unet_input_dim=32, dim_mults=(1, 2, 4, 8),
+                                 max_rows=2 * B)
+    load_numpy_state_dict(unet, sd)
+    dm = StaticGaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=25,
+                                      predict_epsilon=True, compose=False, use_apf=True, sampler="ddpm",
+                                      use_graph=True)
+    dm = dm.eval().to(device)
+    return dm, sd
+
+
+def run_job(dm, B, cloud, hard_conds, world, x_all=None):
+    """One step = one run_inference of B trajectories + the final all-gather."""
+    import torch
+    from ramp_amd import dist as rdist
+    x = dm.run_inference(None, hard_conds, n_samples=B, horizon=48, return_chain=False, traj_normalized=None,
+                         obstacle_pts=cloud, sample_fn=None, guide=None, n_guide_steps=1, t_start_guide=7,
+                         noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=0)
+    if world > 1:
+        x = rdist.all_gather_trajectories(x.contiguous(), B * world)
+    return x
+
+
+def profile_gemm(dm, B, cloud, hard_conds):
+    """HIP-event timing of every kernel launch of ONE eager (non-graph) step on the launch stream."""
+    import torch
+    from ramp_amd import _lib
+    lib = _lib.load()
+    ctx = dm.model.ctx()
+    dm.use_graph = False
+    run_job(dm, B, cloud, hard_conds, 1)              # eager warm-up
+    torch.cuda.synchronize()
+    _lib.check(lib.ramp_profile(ctx, 1))
+    run_job(dm, B, cloud, hard_conds, 1)
+    ms = (C.c_double * 5)(); fl = (C.c_double * 5)(); cnt = (C.c_int64 * 5)()
+    _lib.check(lib.ramp_profile_read(ctx, ms, fl, cnt))
+    _lib.check(lib.ramp_profile(ctx, 0))
+    dm.use_graph = True
+    names = ["gemm_f32_mfma", "attention", "norm_rows", "small_convs", "sampler"]
+    return {n: {"ms": ms[i], "flops": fl[i], "launches": int(cnt[i])} for i, n in enumerate(names)}
+
+
+def cpu_baseline(sd, cloud_np, n_traj):
+    """The oracle (numpy restatement of the reference algorithm) on the host cores, bounded sample."""
+    from oracle import ramp_oracle as O
+    from ramp_amd import synth
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    u = O.UNetOracle(sd, 4, 48, dtype=np.float32)
+    sm = O.SamplerOracle(u, 25, 2.0, dtype=np.float32)
+    lat = u.encode_scene(cloud_np)
+    noise = synth.make_noise((26, n_traj, 48, 4), seed=1234)
+    t0 = time.time()
+    sm.ddpm(noise, synth.default_hard_conds(4, 48), lat, cloud=cloud_np.reshape(-1, 2), use_apf=True)
+    dt = time.time() - t0
+    return {"value": n_traj / dt, "unit": "trajectories/s", "cores": int(threads), "kind": "port",
+            "sample": f"numpy oracle, B={n_traj} trajectories, full T=25 DDPM chain + APF, fp32, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from ramp_amd import dist as rdist
+    from ramp_amd import synth
+
+    rank, world, local = rdist.env_rank()
+    if world > 1:
+        torch.cuda.set_device(local)
+        rdist.init_process_group("nccl")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the RAMP sampler has no CPU path")
+    device = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(device)
+    B = args.batch
+    torch.manual_seed(1234 + rank)
+
+    dm, sd = build_model(B, device)
+    cloud_np = synth.make_cloud(16, 64, 2, seed=42)                 # 16 x 64 = 1024 points
+    cloud = torch.from_numpy(cloud_np).to(device)
+    hard_conds = {k: torch.from_numpy(v).to(device) for k, v in synth.default_hard_conds(4, 48).items()}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_job(dm, B, cloud, hard_conds, world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run_job(dm, B, cloud, hard_conds, world)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert out.shape == (B * world, 48, 4) and bool(torch.isfinite(out).all())
+
+    value = world * B * args.steps / dt
+    ms_per_step = dt / args.steps * 1e3
+    e2e_tflops_per_gpu = B * 2 * 25 * FLOP_PER_ROW_EVAL / (dt / args.steps) / 1e12
+
+    result = {
+        "metric": "sampled trajectories/sec (H=48, T=25)", "value": value, "unit": "trajectories/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Maze2D static DDPM, B=4096 trajectories/GPU x 2 CFG rows, "
+                               "H=48, S=4, T=25, 1024-pt cloud, APF forward_t>20, hipGraph replay",
+                   "trajectories_per_gpu": B, "horizon": 48, "state_dim": 4, "n_diffusion_steps": 25,
+                   "cloud_points": 1024, "sharding": f"sample-batch x{world}, final all-gather only"},
+        "e2e_algorithmic_tflops_per_gpu": e2e_tflops_per_gpu,
+        "e2e_frac_of_fp32_mfma_peak": e2e_tflops_per_gpu / PEAK_FP32_MFMA_TFLOPS,
+        "workspace_gb": dm.model.workspace_bytes() / 2 ** 30,
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        prof = profile_gemm(dm, B, cloud, hard_conds)
+        g = prof["gemm_f32_mfma"]
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        total_ms = sum(v["ms"] for v in prof.values())
+        result["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "kernel": "ramp::gemm_kernel<*> (fp32 v_mfma_f32_32x32x2: linears + k5/k1 convs, fwd and dX)",
+            "launches_per_step": g["launches"], "avg_launch_us": g["ms"] * 1e3 / max(g["launches"], 1),
+            "algorithmic_gflop_per_launch": g["flops"] / max(g["launches"], 1) / 1e9,
+            "share_of_kernel_time": g["ms"] / total_ms,
+            "kernel_time_ms_by_class": {k: round(v["ms"], 3) for k, v in prof.items()},
+        }
+    elif rank == 0:
+        result["roofline"] = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sd, cloud_np, args.cpu_sample)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

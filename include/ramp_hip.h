@@ -162,6 +162,12 @@ int ramp_debug_read(ramp_ctx* ctx, const char* kind, const char* module, float* 
                     int64_t* n_copied, void* stream);
 
 /* bookkeeping for bench / profiling */
+/* per-launch HIP-event timing (eager, non-graph calls only).  Categories: 0 = MFMA GEMM (linears + k5/k1
+ * convs), 1 = attention, 2 = GroupNorm/LayerNorm/GEGLU rows, 3 = stride-2 / first / last convs, 4 = sampler
+ * (CFG, DDPM/DDIM update, APF).  ramp_profile_read sums elapsed ms, algorithmic FLOPs and launch counts
+ * per category since ramp_profile(ctx, 1); arrays of length 5. */
+int ramp_profile(ramp_ctx* ctx, int32_t enable);
+int ramp_profile_read(ramp_ctx* ctx, double* ms, double* flops, int64_t* count);
 int ramp_workspace_bytes(ramp_ctx* ctx, int64_t* bytes);
 int ramp_launch_count(ramp_ctx* ctx, int64_t* kernels_last_score);
 

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "ramp_op_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ramp_op_attention_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ramp_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64, c_i64p, C.c_void_p]),
+    "ramp_profile": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ramp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64p]),
     "ramp_workspace_bytes": (C.c_int, [C.c_void_p, c_i64p]),
     "ramp_launch_count": (C.c_int, [C.c_void_p, c_i64p]),
 }
@@ -87,6 +89,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; the process must hold ONE HIP runtime (torch's
+    # streams and allocations are handed to this library), so torch is always imported first and this library's
+    # NEEDED libamdhip64.so.7 then resolves to the copy already mapped.  Loaded the other way round the second
+    # runtime finds no device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RampHipError(f"{LIB_PATH} not found: build it with `python -m ramp_amd.build` "
                            "(hipcc --offload-arch=gfx950). The RAMP sampler has no CPU fallback.")

@@ -133,7 +133,37 @@ struct ramp_ctx {
   // debug
   std::map<std::string, std::pair<float*, size_t>> dbg;
   int64_t launches = 0;
+  // per-launch HIP-event profiler (eager mode only): category, algorithmic flops, start/stop events
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev; size_t prof_used = 0;
+  std::vector<int> prof_cat; std::vector<double> prof_flops;
 };
+
+enum { CAT_GEMM = 0, CAT_ATTN = 1, CAT_ROW = 2, CAT_SMALLCONV = 3, CAT_SAMPLER = 4, CAT_N = 5 };
+
+static void prof_pre(ramp_ctx* c, hipStream_t s, int cat, double flops) {
+  if (!c->prof_on) return;
+  if (c->prof_used + 2 > c->prof_ev.size()) {
+    const size_t old = c->prof_ev.size();
+    c->prof_ev.resize(old + 4096);
+    for (size_t i = old; i < c->prof_ev.size(); ++i) (void)hipEventCreate(&c->prof_ev[i]);
+  }
+  c->prof_cat.push_back(cat); c->prof_flops.push_back(flops);
+  (void)hipEventRecord(c->prof_ev[c->prof_used++], s);
+}
+static void prof_post(ramp_ctx* c, hipStream_t s) {
+  if (!c->prof_on) return;
+  (void)hipEventRecord(c->prof_ev[c->prof_used++], s);
+}
+// run one kernel launch expression with launch counting and optional event bracketing
+#define LAUNCH(ctx_, stream_, cat_, flops_, expr_)                     \
+  do {                                                                 \
+    prof_pre((ctx_), (stream_), (cat_), (double)(flops_));             \
+    int _rc = (expr_);                                                 \
+    prof_post((ctx_), (stream_));                                      \
+    (ctx_)->launches++;                                                \
+    if (_rc != 0) return _rc;                                          \
+  } while (0)
 
 namespace {
 
@@ -258,7 +288,10 @@ int build_st(ramp_ctx* c, ST& s) {
 // ---- op wrappers that count launches -----------------------------------------------------------
 struct Run {
   ramp_ctx* c; hipStream_t s; int R; int row0;
-  int gemm(const GemmArgs& a) { c->launches++; return launch_gemm(a, s); }
+  int gemm(const GemmArgs& a) {
+    LAUNCH(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, launch_gemm(a, s));
+    return 0;
+  }
 };
 
 GemmArgs lin(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K) {
@@ -294,8 +327,7 @@ int rtb_forward(Run& r, RTB& m, const float* xa, int ca, const float* xb, int cb
   const float* tbias = c->time_table + (size_t)t * c->tt_stride + m.tb_off;
   const float* resid;
   if (m.first) {
-    c->launches++;
-    CK(launch_conv_in_fwd(x_first, m.w5in, m.c1.bias, m.w1in, m.res_bias, m.a_c1, c->t_res, R, n_rp, m.L, m.cin, r.s));
+    LAUNCH(c, r.s, CAT_SMALLCONV, 0, launch_conv_in_fwd(x_first, m.w5in, m.c1.bias, m.w1in, m.res_bias, m.a_c1, c->t_res, R, n_rp, m.L, m.cin, r.s));
     resid = c->t_res;
   } else {
     GemmArgs a = conv5(xa, ca, m.c1.fwd, m.c1.bias, m.a_c1, m.cout, M, m.cout, m.cin, m.L, false);
@@ -312,10 +344,10 @@ int rtb_forward(Run& r, RTB& m, const float* xa, int ca, const float* xb, int cb
   }
   GnArgs g; g.x = m.a_c1; g.gamma = m.g1; g.beta = m.b1; g.tbias = tbias; g.resid = nullptr; g.y = m.a_h;
   g.stats = m.a_st1; g.R = R; g.L = m.L; g.C = m.cout; g.eps = 1e-5f; g.mish = 1;
-  c->launches++; CK(launch_gn_fwd(g, r.s));
+  LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_fwd(g, r.s));
   CK(r.gemm(conv5(m.a_h, m.cout, m.c2.fwd, m.c2.bias, m.a_c2, m.cout, M, m.cout, m.cout, m.L, false)));
   g.x = m.a_c2; g.gamma = m.g2; g.beta = m.b2; g.tbias = nullptr; g.resid = resid; g.y = m.a_out; g.stats = m.a_st2;
-  c->launches++; CK(launch_gn_fwd(g, r.s));
+  LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_fwd(g, r.s));
   CK(dbg_store(c, "out/" + m.name, m.a_out, (size_t)M * m.cout, r.s));
   return 0;
 }
@@ -327,13 +359,12 @@ int rtb_backward(Run& r, RTB& m, const float* dy, float* dxa, int ca, float* dxb
   CK(dbg_store(c, "gout/" + m.name, dy, (size_t)M * m.cout, r.s));
   GnBwdArgs g; g.dy = dy; g.x = m.a_c2; g.stats = m.a_st2; g.gamma = m.g2; g.beta = m.b2; g.add = nullptr;
   g.dx = c->g_t1; g.R = R; g.L = m.L; g.C = m.cout; g.mish = 1;
-  c->launches++; CK(launch_gn_bwd(g, r.s));                                                     // dc2
+  LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));                                                     // dc2
   CK(r.gemm(conv5(c->g_t1, m.cout, m.c2.bwd, nullptr, c->g_t2, m.cout, M, m.cout, m.cout, m.L, true)));   // dh
   g.dy = c->g_t2; g.x = m.a_c1; g.stats = m.a_st1; g.gamma = m.g1; g.beta = m.b1; g.dx = c->g_t1;
-  c->launches++; CK(launch_gn_bwd(g, r.s));                                                     // dc1
+  LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));                                                     // dc1
   if (m.first) {
-    c->launches++;
-    CK(launch_conv_in_bwd(c->g_t1, dy, m.w5in, m.w1in, eps_out, R, m.L, m.cin, r.s));
+    LAUNCH(c, r.s, CAT_SMALLCONV, 0, launch_conv_in_bwd(c->g_t1, dy, m.w5in, m.w1in, eps_out, R, m.L, m.cin, r.s));
     return 0;
   }
   const float* resid; int ldr;
@@ -356,22 +387,22 @@ int st_forward(Run& r, ST& m, const float* x) {
   ramp_ctx* c = r.c; const int R = r.R, M = R * m.L, D = 256;
   GnArgs g; g.x = x; g.gamma = m.gn_g; g.beta = m.gn_b; g.y = c->t_xn; g.stats = m.a_gst; g.R = R; g.L = m.L;
   g.C = m.C; g.eps = 1e-6f; g.mish = 0;
-  c->launches++; CK(launch_gn_fwd(g, r.s));
+  LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_fwd(g, r.s));
   CK(r.gemm(lin(c->t_xn, m.C, m.wpi_f, m.bpi, m.a_z0, D, M, D, m.C)));
   const float* zin = m.a_z0;
   for (int b = 0; b < 2; ++b) {
     STBlock& k = m.blk[b];
-    c->launches++; CK(launch_ln_fwd(zin, k.ln1_g, k.ln1_b, c->t_ln, M, r.s));
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(zin, k.ln1_g, k.ln1_b, c->t_ln, M, r.s));
     CK(r.gemm(lin(c->t_ln, D, k.wqkv_f, nullptr, k.a_qkv, 768, M, 768, D)));
-    c->launches++; CK(launch_attn_fwd(k.a_qkv, c->t_o, R, m.L, r.s));
+    LAUNCH(c, r.s, CAT_ATTN, 16.0 * R * m.L * m.L * 64, launch_attn_fwd(k.a_qkv, c->t_o, R, m.L, r.s));
     GemmArgs a = lin(c->t_o, D, k.wo_f, k.bo, k.a_z1, D, M, D, D);
     a.resid = zin; a.ldr = D; a.L = m.L;
     a.rowbias = c->cross_bias + (size_t)(m.blk0 + b) * D; a.rb_stride = c->n_blocks_total * D;
     a.rowvar = c->row_variant; a.row0 = r.row0;
     CK(r.gemm(a));
-    c->launches++; CK(launch_ln_fwd(k.a_z1, k.ln3_g, k.ln3_b, c->t_ln, M, r.s));
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(k.a_z1, k.ln3_g, k.ln3_b, c->t_ln, M, r.s));
     CK(r.gemm(lin(c->t_ln, D, k.w1_f, k.b1, k.a_ag, 2048, M, 2048, D)));
-    c->launches++; CK(launch_geglu_fwd(k.a_ag, c->t_hg, M, 1024, r.s));
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_geglu_fwd(k.a_ag, c->t_hg, M, 1024, r.s));
     GemmArgs f = lin(c->t_hg, 1024, k.w2_f, k.b2, k.a_z2, D, M, D, 1024);
     f.resid = k.a_z1; f.ldr = D;
     CK(r.gemm(f));
@@ -393,18 +424,18 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx) {
     STBlock& k = m.blk[b];
     const float* zin = (b == 0) ? m.a_z0 : m.blk[0].a_z2;
     CK(r.gemm(lin(dz, D, k.w2_b, nullptr, c->t_hg, 1024, M, 1024, D)));                 // d(hg)
-    c->launches++; CK(launch_geglu_bwd(c->t_hg, k.a_ag, c->t_dag, M, 1024, r.s));        // d(ag)
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_geglu_bwd(c->t_hg, k.a_ag, c->t_dag, M, 1024, r.s));        // d(ag)
     CK(r.gemm(lin(c->t_dag, 2048, k.w1_b, nullptr, c->t_dln, D, M, D, 2048)));          // d(ln3)
-    c->launches++; CK(launch_ln_bwd(c->t_dln, k.a_z1, k.ln3_g, dz, dz1, M, r.s));         // dz1
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, k.a_z1, k.ln3_g, dz, dz1, M, r.s));         // dz1
     CK(r.gemm(lin(dz1, D, k.wo_b, nullptr, c->t_o, D, M, D, D)));                       // d(o)
-    c->launches++; CK(launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, R, m.L, r.s));
+    LAUNCH(c, r.s, CAT_ATTN, 32.0 * R * m.L * m.L * 64, launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, R, m.L, r.s));
     CK(r.gemm(lin(c->t_dqkv, 768, k.wqkv_b, nullptr, c->t_dln, D, M, D, 768)));         // d(ln1)
-    c->launches++; CK(launch_ln_bwd(c->t_dln, zin, k.ln1_g, dz1, dz, M, r.s));            // dz (block input)
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, zin, k.ln1_g, dz1, dz, M, r.s));            // dz (block input)
   }
   CK(r.gemm(lin(dz, D, m.wpi_b, nullptr, c->t_xn, m.C, M, m.C, D)));                    // d(xn)
   GnBwdArgs g; g.dy = c->t_xn; g.x = x; g.stats = m.a_gst; g.gamma = m.gn_g; g.beta = m.gn_b; g.add = dy; g.dx = dx;
   g.R = R; g.L = m.L; g.C = m.C; g.mish = 0;
-  c->launches++; CK(launch_gn_bwd(g, r.s));
+  LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));
   return 0;
 }
 
@@ -424,7 +455,7 @@ int net_forward(ramp_ctx* c, const float* x_chunk, int row0, int R, int n_rp, in
       Resample& d = c->downs[k];
       ResampleArgs ra; ra.x = st.a_y; ra.W = d.w_f; ra.bias = d.bias; ra.y = d.a_y; ra.R = R; ra.Lin = d.Lin;
       ra.Lout = d.Lout; ra.Cin = d.C; ra.Cout = d.C; ra.taps = 3; ra.mode = 0;
-      c->launches++; CK(launch_resample(ra, s));
+      LAUNCH(c, s, CAT_SMALLCONV, 0, launch_resample(ra, s));
       CK(dbg_store(c, "out/" + d.name, d.a_y, (size_t)R * d.Lout * d.C, s));
       cur = d.a_y; cc = d.C;
     } else {
@@ -445,7 +476,7 @@ int net_forward(ramp_ctx* c, const float* x_chunk, int row0, int R, int n_rp, in
     Resample& u = c->ups[k];
     ResampleArgs ra; ra.x = st.a_y; ra.W = u.w_f; ra.bias = u.bias; ra.y = u.a_y; ra.R = R; ra.Lin = u.Lin;
     ra.Lout = u.Lout; ra.Cin = u.C; ra.Cout = u.C; ra.taps = 4; ra.mode = 1;
-    c->launches++; CK(launch_resample(ra, s));
+    LAUNCH(c, s, CAT_SMALLCONV, 0, launch_resample(ra, s));
     CK(dbg_store(c, "out/" + u.name, u.a_y, (size_t)R * u.Lout * u.C, s));
     cur = u.a_y; cc = u.C;
   }
@@ -453,9 +484,8 @@ int net_forward(ramp_ctx* c, const float* x_chunk, int row0, int R, int n_rp, in
   CK(r.gemm(conv5(cur, cc, c->final_conv.fwd, c->final_conv.bias, c->a_fin_c, C0, M, C0, C0, H, false)));
   GnArgs g; g.x = c->a_fin_c; g.gamma = c->fin_g; g.beta = c->fin_b; g.y = c->a_fin_a; g.stats = c->a_fin_st;
   g.R = R; g.L = H; g.C = C0; g.eps = 1e-5f; g.mish = 1;
-  c->launches++; CK(launch_gn_fwd(g, s));
-  c->launches++;
-  CK(launch_conv_out(c->a_fin_a, c->fin_w, c->fin_bias, f_out, want_grad ? c->a_fin_da : nullptr, M, c->cfg.state_dim, s));
+  LAUNCH(c, s, CAT_ROW, 0, launch_gn_fwd(g, s));
+  LAUNCH(c, s, CAT_SMALLCONV, 0, launch_conv_out(c->a_fin_a, c->fin_w, c->fin_bias, f_out, want_grad ? c->a_fin_da : nullptr, M, c->cfg.state_dim, s));
   return 0;
 }
 
@@ -464,7 +494,7 @@ int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s) {
   const int nl = c->cfg.n_levels, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim, M = R * H;
   GnBwdArgs g; g.dy = c->a_fin_da; g.x = c->a_fin_c; g.stats = c->a_fin_st; g.gamma = c->fin_g; g.beta = c->fin_b;
   g.dx = c->g_t1; g.R = R; g.L = H; g.C = C0; g.mish = 1;
-  c->launches++; CK(launch_gn_bwd(g, s));
+  LAUNCH(c, s, CAT_ROW, 0, launch_gn_bwd(g, s));
   float* d = c->g_a; float* e = c->g_b;
   CK(r.gemm(conv5(c->g_t1, C0, c->final_conv.bwd, nullptr, d, C0, M, C0, C0, H, true)));
   for (int k = nl - 2; k >= 0; --k) {
@@ -473,7 +503,7 @@ int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s) {
     CK(dbg_store(c, "gout/" + u.name, d, (size_t)R * u.Lout * u.C, s));
     ResampleArgs ra; ra.x = d; ra.W = u.w_b; ra.y = e; ra.R = R; ra.Lin = u.Lout; ra.Lout = u.Lin; ra.Cin = u.C;
     ra.Cout = u.C; ra.taps = 4; ra.mode = 0;
-    c->launches++; CK(launch_resample(ra, s)); std::swap(d, e);
+    LAUNCH(c, s, CAT_SMALLCONV, 0, launch_resample(ra, s)); std::swap(d, e);
     CK(st_backward(r, st, b.a_out, d, e)); std::swap(d, e);
     CK(rtb_backward(r, b, d, e, b.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e);
     const int lvl = nl - 1 - k;                      // the skip consumed by ups.k
@@ -492,7 +522,7 @@ int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s) {
       CK(dbg_store(c, "gout/" + dn.name, d, (size_t)R * dn.Lout * dn.C, s));
       ResampleArgs ra; ra.x = d; ra.W = dn.w_b; ra.y = e; ra.R = R; ra.Lin = dn.Lout; ra.Lout = dn.Lin; ra.Cin = dn.C;
       ra.Cout = dn.C; ra.taps = 3; ra.mode = 1; ra.add = (k >= 1) ? c->skip_grad[k] : nullptr;
-      c->launches++; CK(launch_resample(ra, s)); std::swap(d, e);
+      LAUNCH(c, s, CAT_SMALLCONV, 0, launch_resample(ra, s)); std::swap(d, e);
     }
     CK(st_backward(r, st, b.a_out, d, e)); std::swap(d, e);
     CK(rtb_backward(r, b, d, e, b.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e);
@@ -767,7 +797,7 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
   HardConds hc; hc.idx = c->s_hard_idx; hc.val = c->s_hard_val; hc.n = p->n_hard;
   // x_T = noise[0]; apply_hard_conditioning; chain[0]
   RAMP_HIP_CHECK(hipMemcpyAsync(c->s_x, c->s_noise, n * 4, hipMemcpyDeviceToDevice, s));
-  CK(launch_hard_cond(c->s_x, hc, B, H, S, s));
+  LAUNCH(c, s, CAT_SAMPLER, 0, launch_hard_cond(c->s_x, hc, B, H, S, s));
   if (chain) RAMP_HIP_CHECK(hipMemcpyAsync(c->s_chain, c->s_x, n * 4, hipMemcpyDeviceToDevice, s));
   ApfArgs ap; ap.cloud = c->s_cloud; ap.window = c->s_window; ap.B = B; ap.H = H; ap.S = S; ap.P = p->apf.n_points;
   ap.win = p->apf.window; ap.thr = p->apf.threshold; ap.strength = p->apf.strength;
@@ -780,18 +810,18 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
     const bool apf = p->apf.cloud != nullptr && p->apply_apf && p->apply_apf[j];
     if (!p->ddim) {
       m.coef1 = p->coef1[j]; m.coef2 = p->coef2[j]; m.mean = c->s_mean; m.x0 = nullptr;
-      CK(launch_cfg_mean(m, s));
-      if (apf) { ap.traj = c->s_mean; for (int q = 0; q < std::max(1, p->apf.passes); ++q) CK(launch_apf(ap, s)); }
-      CK(launch_ddpm_finish(c->s_mean, c->s_noise + (size_t)(j + 1) * n, p->stdv[j], p->noise_scale ? p->noise_scale[j] : 1.f, p->use_noise[j],
+      LAUNCH(c, s, CAT_SAMPLER, 0, launch_cfg_mean(m, s));
+      if (apf) { ap.traj = c->s_mean; for (int q = 0; q < std::max(1, p->apf.passes); ++q) LAUNCH(c, s, CAT_SAMPLER, 0, launch_apf(ap, s)); }
+      LAUNCH(c, s, CAT_SAMPLER, 0, launch_ddpm_finish(c->s_mean, c->s_noise + (size_t)(j + 1) * n, p->stdv[j], p->noise_scale ? p->noise_scale[j] : 1.f, p->use_noise[j],
                             hc, c->s_x, chain_j, B, H, S, s));
     } else {
       m.mean = nullptr; m.x0 = c->s_x0;
-      CK(launch_cfg_mean(m, s));
+      LAUNCH(c, s, CAT_SAMPLER, 0, launch_cfg_mean(m, s));
       if (apf) {
         ap.traj = c->s_x0;
-        for (int q = 0; q < std::max(1, p->apf.passes); ++q) { CK(launch_apf(ap, s)); CK(launch_hard_cond(c->s_x0, hc, B, H, S, s)); }
+        for (int q = 0; q < std::max(1, p->apf.passes); ++q) { LAUNCH(c, s, CAT_SAMPLER, 0, launch_apf(ap, s)); LAUNCH(c, s, CAT_SAMPLER, 0, launch_hard_cond(c->s_x0, hc, B, H, S, s)); }
       }
-      CK(launch_ddim_finish(c->s_x, c->s_x0, p->sqrt_a_t[j], p->sqrt_1m_a_t[j], p->sqrt_a_prev[j], p->dir_coef[j], hc,
+      LAUNCH(c, s, CAT_SAMPLER, 0, launch_ddim_finish(c->s_x, c->s_x0, p->sqrt_a_t[j], p->sqrt_1m_a_t[j], p->sqrt_a_prev[j], p->dir_coef[j], hc,
                             c->s_x, chain_j, B, H, S, s));
     }
   }
@@ -975,6 +1005,24 @@ int ramp_debug_read(ramp_ctx* c, const char* kind, const char* module, float* ou
   const size_t n = std::min<size_t>((size_t)n_floats, it->second.second);
   RAMP_HIP_CHECK(hipMemcpyAsync(out, it->second.first, n * 4, hipMemcpyDeviceToDevice, as_stream(stream)));
   *n_copied = (int64_t)n;
+  return 0;
+}
+
+int ramp_profile(ramp_ctx* c, int32_t enable) {
+  RAMP_REQUIRE(c, "null argument");
+  c->prof_on = enable != 0;
+  c->prof_used = 0; c->prof_cat.clear(); c->prof_flops.clear();
+  return 0;
+}
+int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
+  RAMP_REQUIRE(c && ms && flops && count, "null argument");
+  RAMP_HIP_CHECK(hipDeviceSynchronize());
+  for (int i = 0; i < CAT_N; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
+  for (size_t i = 0; i < c->prof_cat.size(); ++i) {
+    float t = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    ms[c->prof_cat[i]] += t; flops[c->prof_cat[i]] += c->prof_flops[i]; count[c->prof_cat[i]]++;
+  }
   return 0;
 }
 

@@ -1,0 +1,62 @@
+"""world_size-2 sharding / all-gather on CPU with the gloo backend (the GPU box runs the same code on RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ramp_amd import dist as rdist
+
+
+def test_shard_counts():
+    assert rdist.shard_counts(10, 4) == [3, 3, 2, 2]
+    assert rdist.shard_counts(8, 8) == [1] * 8
+    assert rdist.shard_counts(3, 4) == [1, 1, 1, 0]
+    for n, w in ((4096, 8), (65536, 8), (35, 2), (1, 2)):
+        c = rdist.shard_counts(n, w)
+        assert sum(c) == n and max(c) - min(c) <= 1
+        spans = [rdist.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    rdist.init_process_group("gloo")
+    truth = torch.arange(n_total * 48 * 4, dtype=torch.float32).reshape(n_total, 48, 4)
+
+    def sample_local(start, stop):      # stands in for the per-GPU sampler: rows are a function of the global index
+        return truth[start:stop].clone() * 2.0
+
+    out = rdist.sample_sharded(sample_local, n_total)
+    ok = bool(torch.equal(out, truth * 2.0))
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, ok, float(t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 7])
+def test_sharded_sampling_allgather_world2(n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res) and all(r[2] == 2.0 for r in res)
