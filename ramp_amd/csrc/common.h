@@ -49,7 +49,20 @@ struct GemmArgs {
   float* C2 = nullptr; int ldc2 = 0; int N1 = 0;            // N1 == N when C2 unused
   int M = 0, N = 0, K = 0;
   int taps = 1, shift0 = 0, shift_step = 0, L = 1;
+  // strided rows: source row of output token (seg, l) is seg*(L*a_stride) + l*a_stride + shift (stride-2
+  // convs); output/residual row is m*c_rstride + c_roff (the even / odd phases of a transposed conv)
+  int a_stride = 1, c_rstride = 1, c_roff = 0;
+  // fused epilogues
+  int epi = 0;                       // EPI_*
+  const float* aux_in = nullptr;     // EPI_GEGLU_BWD: ag (M, 2N)
+  float* aux_out = nullptr;          // EPI_GEGLU_FWD: hg (M, N/2)
+  int ld_aux = 0;
 };
+// EPI_LINEAR:    C = acc + bias + rowbias + resid + resid2
+// EPI_GEGLU_FWD: weights packed so that each 128-column tile is [64 a-columns | the 64 matching g-columns];
+//                C (M, N) receives ag = acc + bias in the natural [a | g] layout, aux_out (M, N/2) = a * gelu(g)
+// EPI_GEGLU_BWD: acc = d(hg) (M, N); C (M, 2N) = [acc * gelu(g) | acc * a * gelu'(g)] with (a, g) from aux_in
+enum { EPI_LINEAR = 0, EPI_GEGLU_FWD = 1, EPI_GEGLU_BWD = 2 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int init_gemm_attributes();        // raise the dynamic-LDS limit of every GEMM instantiation (once)
 int init_attention_attributes();   // same for the attention kernels

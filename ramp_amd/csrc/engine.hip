@@ -10,6 +10,7 @@
 #include "../../include/ramp_hip.h"
 
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -37,6 +38,16 @@ __global__ void permute3_kernel(const float* __restrict__ in, float* __restrict_
     int i[3];
     i[2] = (int)(idx % D2); i[1] = (int)((idx / D2) % D1); i[0] = (int)(idx / ((long)D1 * D2));
     out[((long)i[p0] * O1 + i[p1]) * O2 + i[p2]] = in[idx];
+  }
+}
+// rows of ff.net.0.proj (2F, K) -> tiles of [64 a-rows | 64 matching g-rows] (EPI_GEGLU_FWD); K = 1 for the bias
+__global__ void geglu_pack_kernel(const float* __restrict__ in, float* __restrict__ out, int F, int K) {
+  const long n = (long)2 * F * K;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int p = (int)(idx / K), k = (int)(idx - (long)p * K);
+    const int t = p >> 7, c = p & 127;
+    const int src = c < 64 ? 64 * t + c : F + 64 * t + (c - 64);
+    out[idx] = in[(long)src * K + k];
   }
 }
 __global__ void fill_pattern_kernel(int* out, const int* pat, int n_pat, int n) {
@@ -77,6 +88,7 @@ struct RTB {
 struct STBlock {
   float *wqkv_f = nullptr, *wqkv_b = nullptr, *wo_f = nullptr, *wo_b = nullptr, *bo = nullptr;
   float *w1_f = nullptr, *w1_b = nullptr, *b1 = nullptr, *w2_f = nullptr, *w2_b = nullptr, *b2 = nullptr;
+  float *w1_pk = nullptr, *b1_pk = nullptr;        // GEGLU-packed forward weight / bias
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
   const float *wv2 = nullptr, *wo2 = nullptr, *bo2 = nullptr;    // attn2 (cross) raw
   float *a_qkv = nullptr, *a_z1 = nullptr, *a_ag = nullptr, *a_z2 = nullptr;
@@ -136,13 +148,14 @@ struct ramp_ctx {
   // per-launch HIP-event profiler (eager mode only): category, algorithmic flops, start/stop events
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev; size_t prof_used = 0;
-  std::vector<int> prof_cat; std::vector<double> prof_flops;
+  std::vector<int> prof_cat; std::vector<double> prof_flops; std::vector<std::array<int, 4>> prof_shape;
 };
 
 enum { CAT_GEMM = 0, CAT_ATTN = 1, CAT_ROW = 2, CAT_SMALLCONV = 3, CAT_SAMPLER = 4, CAT_N = 5 };
 
-static void prof_pre(ramp_ctx* c, hipStream_t s, int cat, double flops) {
+static void prof_pre(ramp_ctx* c, hipStream_t s, int cat, double flops, std::array<int, 4> shape = {0, 0, 0, 0}) {
   if (!c->prof_on) return;
+  c->prof_shape.push_back(shape);
   if (c->prof_used + 2 > c->prof_ev.size()) {
     const size_t old = c->prof_ev.size();
     c->prof_ev.resize(old + 4096);
@@ -267,6 +280,10 @@ int build_st(ramp_ctx* c, ST& s) {
     CK(get_raw(c, t + ".attn1.to_out.0.bias", {D}, &k.bo));
     CK(pack_linear(c, t + ".ff.net.0.proj.weight", 2048, D, false, &k.w1_f, &k.w1_b));
     CK(get_raw(c, t + ".ff.net.0.proj.bias", {2048}, &k.b1));
+    CK(dev_alloc(c, &k.w1_pk, 2048 * D)); CK(dev_alloc(c, &k.b1_pk, 2048));
+    hipLaunchKernelGGL(geglu_pack_kernel, dim3(1024), dim3(256), 0, 0, k.w1_f, k.w1_pk, 1024, D);
+    hipLaunchKernelGGL(geglu_pack_kernel, dim3(8), dim3(256), 0, 0, k.b1, k.b1_pk, 1024, 1);
+    RAMP_HIP_CHECK(hipGetLastError());
     CK(pack_linear(c, t + ".ff.net.2.weight", D, 1024, false, &k.w2_f, &k.w2_b));
     CK(get_raw(c, t + ".ff.net.2.bias", {D}, &k.b2));
     CK(get_raw(c, t + ".norm1.weight", {D}, &k.ln1_g)); CK(get_raw(c, t + ".norm1.bias", {D}, &k.ln1_b));
@@ -289,8 +306,11 @@ int build_st(ramp_ctx* c, ST& s) {
 struct Run {
   ramp_ctx* c; hipStream_t s; int R; int row0;
   int gemm(const GemmArgs& a) {
-    LAUNCH(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, launch_gemm(a, s));
-    return 0;
+    prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, a.taps});
+    int rc = launch_gemm(a, s);
+    prof_post(c, s);
+    c->launches++;
+    return rc;
   }
 };
 
@@ -401,8 +421,9 @@ int st_forward(Run& r, ST& m, const float* x) {
     a.rowvar = c->row_variant; a.row0 = r.row0;
     CK(r.gemm(a));
     LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(k.a_z1, k.ln3_g, k.ln3_b, c->t_ln, M, r.s));
-    CK(r.gemm(lin(c->t_ln, D, k.w1_f, k.b1, k.a_ag, 2048, M, 2048, D)));
-    LAUNCH(c, r.s, CAT_ROW, 0, launch_geglu_fwd(k.a_ag, c->t_hg, M, 1024, r.s));
+    GemmArgs u = lin(c->t_ln, D, k.w1_pk, k.b1_pk, k.a_ag, 2048, M, 2048, D);
+    u.epi = EPI_GEGLU_FWD; u.aux_out = c->t_hg; u.ld_aux = 1024;        // writes ag (stash) and hg = a * gelu(g)
+    CK(r.gemm(u));
     GemmArgs f = lin(c->t_hg, 1024, k.w2_f, k.b2, k.a_z2, D, M, D, 1024);
     f.resid = k.a_z1; f.ldr = D;
     CK(r.gemm(f));
@@ -423,8 +444,9 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx) {
   for (int b = 1; b >= 0; --b) {
     STBlock& k = m.blk[b];
     const float* zin = (b == 0) ? m.a_z0 : m.blk[0].a_z2;
-    CK(r.gemm(lin(dz, D, k.w2_b, nullptr, c->t_hg, 1024, M, 1024, D)));                 // d(hg)
-    LAUNCH(c, r.s, CAT_ROW, 0, launch_geglu_bwd(c->t_hg, k.a_ag, c->t_dag, M, 1024, r.s));        // d(ag)
+    GemmArgs w = lin(dz, D, k.w2_b, nullptr, c->t_dag, 2048, M, 1024, D);     // d(hg) -> d(ag) in the epilogue
+    w.epi = EPI_GEGLU_BWD; w.aux_in = k.a_ag; w.ld_aux = 2048;
+    CK(r.gemm(w));
     CK(r.gemm(lin(c->t_dag, 2048, k.w1_b, nullptr, c->t_dln, D, M, D, 2048)));          // d(ln3)
     LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, k.a_z1, k.ln3_g, dz, dz1, M, r.s));         // dz1
     CK(r.gemm(lin(dz1, D, k.wo_b, nullptr, c->t_o, D, M, D, D)));                       // d(o)
@@ -453,9 +475,10 @@ int net_forward(ramp_ctx* c, const float* x_chunk, int row0, int R, int n_rp, in
     CK(st_forward(r, st, b.a_out));
     if (k < nl - 1) {
       Resample& d = c->downs[k];
-      ResampleArgs ra; ra.x = st.a_y; ra.W = d.w_f; ra.bias = d.bias; ra.y = d.a_y; ra.R = R; ra.Lin = d.Lin;
-      ra.Lout = d.Lout; ra.Cin = d.C; ra.Cout = d.C; ra.taps = 3; ra.mode = 0;
-      LAUNCH(c, s, CAT_SMALLCONV, 0, launch_resample(ra, s));
+      // Downsample1d: y[lo] = b + sum_j x[2 lo + j - 1] W_j^T  -> 3 taps over stride-2 source rows
+      GemmArgs ga = lin(st.a_y, d.C, d.w_f, d.bias, d.a_y, d.C, R * d.Lout, d.C, d.C);
+      ga.taps = 3; ga.shift0 = -1; ga.shift_step = 1; ga.L = d.Lout; ga.a_stride = 2;
+      CK(r.gemm(ga));
       CK(dbg_store(c, "out/" + d.name, d.a_y, (size_t)R * d.Lout * d.C, s));
       cur = d.a_y; cc = d.C;
     } else {
@@ -474,9 +497,12 @@ int net_forward(ramp_ctx* c, const float* x_chunk, int row0, int R, int n_rp, in
     CK(rtb_forward(r, b, a.a_out, a.cout, nullptr, 0, nullptr, n_rp, t));
     CK(st_forward(r, st, b.a_out));
     Resample& u = c->ups[k];
-    ResampleArgs ra; ra.x = st.a_y; ra.W = u.w_f; ra.bias = u.bias; ra.y = u.a_y; ra.R = R; ra.Lin = u.Lin;
-    ra.Lout = u.Lout; ra.Cin = u.C; ra.Cout = u.C; ra.taps = 4; ra.mode = 1;
-    LAUNCH(c, s, CAT_SMALLCONV, 0, launch_resample(ra, s));
+    // Upsample1d (ConvTranspose1d k4 s2 p1): y[2i] = b + x[i] W_1 + x[i-1] W_3 ; y[2i+1] = b + x[i+1] W_0 + x[i] W_2
+    for (int par = 0; par < 2; ++par) {
+      GemmArgs ga = lin(st.a_y, u.C, u.w_f + (size_t)par * 2 * u.C * u.C, u.bias, u.a_y, u.C, R * u.Lin, u.C, u.C);
+      ga.taps = 2; ga.shift0 = par; ga.shift_step = -1; ga.L = u.Lin; ga.c_rstride = 2; ga.c_roff = par;
+      CK(r.gemm(ga));
+    }
     CK(dbg_store(c, "out/" + u.name, u.a_y, (size_t)R * u.Lout * u.C, s));
     cur = u.a_y; cc = u.C;
   }
@@ -501,9 +527,11 @@ int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s) {
     RTB& a = c->rtbs[2 * nl + 2 + 2 * k]; RTB& b = c->rtbs[2 * nl + 3 + 2 * k]; ST& st = c->sts[nl + 1 + k];
     Resample& u = c->ups[k];
     CK(dbg_store(c, "gout/" + u.name, d, (size_t)R * u.Lout * u.C, s));
-    ResampleArgs ra; ra.x = d; ra.W = u.w_b; ra.y = e; ra.R = R; ra.Lin = u.Lout; ra.Lout = u.Lin; ra.Cin = u.C;
-    ra.Cout = u.C; ra.taps = 4; ra.mode = 0;
-    LAUNCH(c, s, CAT_SMALLCONV, 0, launch_resample(ra, s)); std::swap(d, e);
+    {   // dX of Upsample1d: dx[i] = sum_j dy[2i - 1 + j] W_j^T   (4 taps over stride-2 source rows)
+      GemmArgs ga = lin(d, u.C, u.w_b, nullptr, e, u.C, R * u.Lin, u.C, u.C);
+      ga.taps = 4; ga.shift0 = -1; ga.shift_step = 1; ga.L = u.Lin; ga.a_stride = 2;
+      CK(r.gemm(ga)); std::swap(d, e);
+    }
     CK(st_backward(r, st, b.a_out, d, e)); std::swap(d, e);
     CK(rtb_backward(r, b, d, e, b.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e);
     const int lvl = nl - 1 - k;                      // the skip consumed by ups.k
@@ -520,9 +548,14 @@ int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s) {
     if (k < nl - 1) {
       Resample& dn = c->downs[k];
       CK(dbg_store(c, "gout/" + dn.name, d, (size_t)R * dn.Lout * dn.C, s));
-      ResampleArgs ra; ra.x = d; ra.W = dn.w_b; ra.y = e; ra.R = R; ra.Lin = dn.Lout; ra.Lout = dn.Lin; ra.Cin = dn.C;
-      ra.Cout = dn.C; ra.taps = 3; ra.mode = 1; ra.add = (k >= 1) ? c->skip_grad[k] : nullptr;
-      LAUNCH(c, s, CAT_SMALLCONV, 0, launch_resample(ra, s)); std::swap(d, e);
+      // dX of Downsample1d: dx[2i] = dy[i] W_1 ; dx[2i+1] = dy[i+1] W_0 + dy[i] W_2   (+ skip gradient)
+      for (int par = 0; par < 2; ++par) {
+        GemmArgs ga = lin(d, dn.C, dn.w_b + (size_t)par * dn.C * dn.C, nullptr, e, dn.C, R * dn.Lout, dn.C, dn.C);
+        ga.taps = par ? 2 : 1; ga.shift0 = par; ga.shift_step = -1; ga.L = dn.Lout; ga.c_rstride = 2; ga.c_roff = par;
+        if (k >= 1) { ga.resid = c->skip_grad[k]; ga.ldr = dn.C; }
+        CK(r.gemm(ga));
+      }
+      std::swap(d, e);
     }
     CK(st_backward(r, st, b.a_out, d, e)); std::swap(d, e);
     CK(rtb_backward(r, b, d, e, b.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e);
@@ -664,19 +697,31 @@ int ramp_finalize_weights(ramp_ctx* c) {
   for (auto& r : c->rtbs) CK(build_rtb(c, r));
   for (auto& s : c->sts) CK(build_st(c, s));
   for (auto& d : c->downs) {
-    float* raw;
+    float *raw, *t;
     CK(get_raw(c, d.name + ".conv.weight", {d.C, d.C, 3}, &raw));
     CK(get_raw(c, d.name + ".conv.bias", {d.C}, &d.bias));
-    CK(permute3(c, raw, d.C, d.C, 3, 2, 1, 0, &d.w_f));      // [j][ci][co] = W[co][ci][j]
-    CK(permute3(c, raw, d.C, d.C, 3, 2, 0, 1, &d.w_b));      // [j][co][ci]
+    CK(permute3(c, raw, d.C, d.C, 3, 2, 0, 1, &d.w_f));      // forward taps [j][co][ci] = W[co][ci][j]
+    CK(permute3(c, raw, d.C, d.C, 3, 2, 1, 0, &t));          // dX taps      [j][ci][co]
+    // even output rows use tap 1, odd rows taps (0, 2): store [W_1 | W_0 | W_2]
+    const size_t cc2 = (size_t)d.C * d.C;
+    CK(dev_alloc(c, &d.w_b, 3 * cc2));
+    RAMP_HIP_CHECK(hipMemcpy(d.w_b, t + cc2, cc2 * 4, hipMemcpyDeviceToDevice));
+    RAMP_HIP_CHECK(hipMemcpy(d.w_b + cc2, t, cc2 * 4, hipMemcpyDeviceToDevice));
+    RAMP_HIP_CHECK(hipMemcpy(d.w_b + 2 * cc2, t + 2 * cc2, cc2 * 4, hipMemcpyDeviceToDevice));
     CK(dev_alloc(c, &d.a_y, cap * d.Lout * d.C));
   }
   for (auto& u : c->ups) {
-    float* raw;
+    float *raw, *t;
     CK(get_raw(c, u.name + ".conv.weight", {u.C, u.C, 4}, &raw));   // ConvTranspose1d (Cin,Cout,4)
     CK(get_raw(c, u.name + ".conv.bias", {u.C}, &u.bias));
-    CK(permute3(c, raw, u.C, u.C, 4, 2, 0, 1, &u.w_f));      // [j][ci][co] = W[ci][co][j]
-    CK(permute3(c, raw, u.C, u.C, 4, 2, 1, 0, &u.w_b));      // [j][co][ci]
+    CK(permute3(c, raw, u.C, u.C, 4, 2, 1, 0, &t));          // forward taps [j][co][ci] = W[ci][co][j]
+    // even output rows use taps (1, 3), odd rows taps (0, 2): store [W_1 | W_3 | W_0 | W_2]
+    const size_t cc2 = (size_t)u.C * u.C;
+    CK(dev_alloc(c, &u.w_f, 4 * cc2));
+    const int order[4] = {1, 3, 0, 2};
+    for (int q = 0; q < 4; ++q)
+      RAMP_HIP_CHECK(hipMemcpy(u.w_f + q * cc2, t + order[q] * cc2, cc2 * 4, hipMemcpyDeviceToDevice));
+    CK(permute3(c, raw, u.C, u.C, 4, 2, 0, 1, &u.w_b));      // dX taps [j][ci][co] = W[ci][co][j]
     CK(dev_alloc(c, &u.a_y, cap * u.Lout * u.C));
   }
   CK(pack_conv5(c, "final_conv.0.block.0", C0, C0, &c->final_conv));
@@ -1011,7 +1056,7 @@ int ramp_debug_read(ramp_ctx* c, const char* kind, const char* module, float* ou
 int ramp_profile(ramp_ctx* c, int32_t enable) {
   RAMP_REQUIRE(c, "null argument");
   c->prof_on = enable != 0;
-  c->prof_used = 0; c->prof_cat.clear(); c->prof_flops.clear();
+  c->prof_used = 0; c->prof_cat.clear(); c->prof_flops.clear(); c->prof_shape.clear();
   return 0;
 }
 int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
@@ -1022,6 +1067,20 @@ int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
     float t = 0.f;
     RAMP_HIP_CHECK(hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
     ms[c->prof_cat[i]] += t; flops[c->prof_cat[i]] += c->prof_flops[i]; count[c->prof_cat[i]]++;
+  }
+  if (getenv("RAMP_PROFILE_DUMP")) {      // per-shape GEMM table on stderr
+    std::map<std::array<int, 4>, std::pair<double, int>> agg;
+    for (size_t i = 0; i < c->prof_cat.size(); ++i) {
+      if (c->prof_cat[i] != CAT_GEMM) continue;
+      float t = 0.f; (void)hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]);
+      auto& e = agg[c->prof_shape[i]]; e.first += t; e.second++;
+    }
+    fprintf(stderr, "[ramp profile] %8s %5s %5s %4s %6s %10s %9s %8s\n", "M", "N", "K", "taps", "calls", "total_ms", "avg_us", "TFLOP/s");
+    for (auto& kv : agg) {
+      const auto& sh = kv.first; const double fl = 2.0 * sh[0] * sh[1] * sh[2] * sh[3];
+      fprintf(stderr, "[ramp profile] %8d %5d %5d %4d %6d %10.2f %9.1f %8.1f\n", sh[0], sh[1], sh[2], sh[3], kv.second.second,
+              kv.second.first, kv.second.first * 1e3 / kv.second.second, fl * kv.second.second / (kv.second.first * 1e-3) / 1e12);
+    }
   }
   return 0;
 }

@@ -1,17 +1,26 @@
 // fp32 MFMA GEMM with conv taps for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains).
 //
 // Serves every dense contraction on the sampler hot path: the transformer linears
-// (layers_attention_mini.py:83-127, 38-45), Conv1d k=5 / k=1 as shifted-tap GEMMs in the
-// channels-last layout (layers.py:280-297, 327-361) and all of their dX products
-// (UnetInference.py:27 — autograd.grad w.r.t. the input only, weights are frozen).
+// (layers_attention_mini.py:83-127, 38-45), Conv1d k=5 / k=1 and the stride-2 resampling convs as
+// shifted-tap GEMMs in the channels-last layout (layers.py:262-297, 327-361) and all of their dX
+// products (UnetInference.py:27 — autograd.grad w.r.t. the input only, weights are frozen).
 //
-// Tile: BM x BN x 32, 256 threads = 4 waves, each wave owns (MI*32) x (NI*32) as MI*NI
-// 32x32 accumulators.  Both operands are K-contiguous ([M][K] activations, [N][K] weights =
-// nn.Linear layout), staged global -> registers -> LDS with one 16-byte pad per row, so every
-// lane feeds four MFMAs from a single conflict-free ds_read_b128 per operand (the k order
-// inside a 32-chunk is permuted identically for A and B).  Double-buffered LDS, one barrier
-// per K-tile; the next tile's global loads are in flight during the current tile's MFMAs.
+// Structure
+//  * Tile BM x BN x 32, 4 waves, each wave owns (MI*32) x (NI*32) as MI*NI 32x32 accumulators.
+//    Both operands are K-contiguous ([M][K] activations, [N][K] weights = nn.Linear layout),
+//    staged global -> registers -> LDS with one 16-byte pad per row, so every lane feeds four
+//    MFMAs from a single conflict-free ds_read_b128 per operand (the k order inside a 32-chunk is
+//    permuted identically for A and B).  Double-buffered LDS, one barrier per K-tile.
+//  * PERSISTENT blocks: each block walks a contiguous run of logical tiles (XCD-aware: the runs of
+//    one XCD are adjacent, so the N-tiles of one M-tile hit the same L2).  The global loads of the
+//    next tile's first K-slab are issued before the current tile's epilogue and parked in
+//    registers, so the short-K shapes of this network (K = 256) do not pay a cold prologue per tile.
+//  * Epilogue through LDS: accumulators are transposed in LDS and leave as coalesced float4 rows;
+//    bias, per-row-variant bias, up to two residuals, and the GEGLU forward / backward elementwise
+//    math are applied there (no separate elementwise passes over the 2048-wide hidden).
 #include "common.h"
+
+#include <algorithm>
 
 namespace ramp {
 
@@ -21,21 +30,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;   // floats per LDS row (16-byte pad: conflict-free ds_read_b128)
 
-template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
+  return cdf + x * pdf;
+}
+
+// GEN = false: plain linear (1 tap, unit strides, single source / destination, no second residual), the hot
+//               transformer shapes; operand rows outside M / N are clamped, never masked (they only feed
+//               outputs that are never stored) and K % 32 == 0, so the loader is 8 unconditional 16-byte loads.
+// GEN = true:  conv taps with zero padding at segment ends, stride-2 sources, split-K source (channel concat),
+//               split-N / strided destination, second residual.
+template <int WM, int WN, int MI, int NI, int EPI, bool GEN>
 __global__ __launch_bounds__(WM * WN * 64)
-void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles, int chunk) {
+void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
-  constexpr int AI = BM * 8 / NT, BI = BN * 8 / NT;   // float4 loads per thread per tile
-  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/thread mismatch");
+  constexpr int AI = BM * 8 / NT, BI = (BN * 8 + NT - 1) / NT;   // float4 loads per thread per tile
+  constexpr int CLD = BN + 4;                                      // C staging row stride (floats)
+  static_assert(BM * 8 % NT == 0, "tile/thread mismatch");
+  static_assert(BM * CLD <= 2 * (BM + BN) * LDS_LD, "C staging must fit in the operand stages");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
-  // XCD a contiguous run of logical tiles; N-tiles of one M-tile then hit the same L2.
-  const int bid = blockIdx.x;
-  const int logical = (bid & 7) * chunk + (bid >> 3);
-  if (logical >= n_tiles) return;
-  const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // ---- persistent tile range of this block (XCD-aware) ----
+  const int bid = blockIdx.x, nb = gridDim.x;          // nb is a multiple of 8
+  const int xcd = bid & 7, slot = bid >> 3, bpx = nb >> 3;
+  const long xlo = (long)xcd * n_tiles / 8, xhi = (long)(xcd + 1) * n_tiles / 8;
+  const int t_begin = (int)(xlo + (xhi - xlo) * slot / bpx);
+  const int t_end = (int)(xlo + (xhi - xlo) * (slot + 1) / bpx);
+  if (t_begin >= t_end) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -46,37 +69,63 @@ void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles, int chunk) {
   float* Bs0 = smem + BM * LDS_LD;
   constexpr int STAGE = (BM + BN) * LDS_LD;
 
-  // per-thread staging rows
-  int a_l[AI]; long a_m[AI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    int m = m0 + r0 + RSTEP * i;
-    a_m[i] = (m < a.M) ? m : -1;
-    a_l[i] = (m < a.M) ? (m % a.L) : 0;
-  }
+  const int nk = a.K / BK;                             // K % 32 == 0 (checked on the host)
+  const int total = GEN ? a.taps * nk : nk;
 
-  const int nk = (a.K + BK - 1) / BK;
-  const int total = a.taps * nk;
-
-  f32x4 ra[AI], rb[BI];
-  auto load_tile = [&](int it) {
-    const int tap = it / nk, k0 = (it - tap * nk) * BK;
-    const int sh = a.shift0 + tap * a.shift_step;
-    const int kk = k0 + c4 * 4;
-    const bool kval = kk < a.K;
-    const float* Ab; int ld, kc;
-    if (kk < a.K1) { Ab = a.A; ld = a.lda; kc = kk; } else { Ab = a.A2; ld = a.lda2; kc = kk - a.K1; }
+  // ---- loader state: (tile, k-iteration) one step ahead of the MFMA loop ----
+  int ld_tile = t_begin, ld_it = 0;
+  const float* ap[AI];                                 // row base pointers (+ float4 column) of this thread
+  const float* bp[BI];
+  int a_l[GEN ? AI : 1]; long a_m[GEN ? AI : 1];       // GEN: in-segment position / source row (no shift)
+  const int Lin = GEN ? a.L * a.a_stride : 0;
+  auto setup_rows = [&](int tile) {
+    const int tile_m = tile / tiles_n;
+    const int n0 = (tile - tile_m * tiles_n) * BN;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int l = a_l[i] + sh;
-      const bool ok = kval && a_m[i] >= 0 && l >= 0 && l < a.L;
-      ra[i] = ok ? *reinterpret_cast<const f32x4*>(Ab + (a_m[i] + sh) * ld + kc) : f32x4{0, 0, 0, 0};
+      int m = tile_m * BM + r0 + RSTEP * i;
+      if (!GEN) {
+        m = m < a.M ? m : a.M - 1;
+        ap[i] = a.A + (long)m * a.lda + c4 * 4;
+      } else {
+        const bool mv = m < a.M;
+        m = mv ? m : 0;
+        const int seg = m / a.L, l = m - seg * a.L;
+        a_l[i] = mv ? l * a.a_stride : -(1 << 28);    // invalid rows fail every range test
+        a_m[i] = (long)seg * Lin + l * a.a_stride;
+      }
     }
-    const float* Wb = a.W + (long)tap * a.N * a.K;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int n = n0 + r0 + RSTEP * i;
-      rb[i] = (kval && n < a.N) ? *reinterpret_cast<const f32x4*>(Wb + (long)n * a.K + kk) : f32x4{0, 0, 0, 0};
+      int n = n0 + r0 + RSTEP * i;
+      n = n < a.N ? n : a.N - 1;
+      bp[i] = a.W + (long)n * a.K + c4 * 4;
+    }
+  };
+  f32x4 ra[AI], rb[BI];
+  auto load_tile = [&]() {                             // straight-line: every address is valid
+    if (!GEN) {
+      const int k0 = ld_it * BK;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+#pragma unroll
+      for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i] + k0);
+    } else {
+      const int tap = ld_it / nk, k0 = (ld_it - tap * nk) * BK;
+      const int sh = a.shift0 + tap * a.shift_step;
+      const float* Ab; int ld, kc;
+      if (k0 < a.K1) { Ab = a.A; ld = a.lda; kc = k0; } else { Ab = a.A2; ld = a.lda2; kc = k0 - a.K1; }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int l = a_l[i] + sh;
+        const bool ok = l >= 0 && l < Lin;
+        const long row = ok ? a_m[i] + sh : a_m[i];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Ab + row * ld + kc + c4 * 4);
+        ra[i] = ok ? v : f32x4{0, 0, 0, 0};
+      }
+      const long woff = (long)tap * a.N * a.K + k0;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i] + woff);
     }
   };
   auto store_tile = [&](int st) {
@@ -87,100 +136,173 @@ void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles, int chunk) {
       *reinterpret_cast<f32x4*>(As + (r0 + RSTEP * i) * LDS_LD + c4 * 4) = ra[i];
 #pragma unroll
     for (int i = 0; i < BI; ++i)
-      *reinterpret_cast<f32x4*>(Bs + (r0 + RSTEP * i) * LDS_LD + c4 * 4) = rb[i];
+      if (BN * 8 % NT == 0 || r0 + RSTEP * i < BN) *reinterpret_cast<f32x4*>(Bs + (r0 + RSTEP * i) * LDS_LD + c4 * 4) = rb[i];
   };
-
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  auto advance_loader = [&]() {          // after the last tile the loader idles on it (loads are harmless)
+    if (++ld_it == total) {
+      ld_it = 0;
+      if (ld_tile + 1 < t_end) { ++ld_tile; setup_rows(ld_tile); }
+    }
+  };
 
   const int r = lane & 31, h = lane >> 5;
   const int arow = (wm * MI * 32 + r) * LDS_LD + h * 4;
   const int brow = (wn * NI * 32 + r) * LDS_LD + h * 4;
 
-  load_tile(0);
+  setup_rows(ld_tile);
+  load_tile();
   store_tile(0);
+  advance_loader();
   __syncthreads();
-  for (int it = 0; it < total; ++it) {
-    const int st = it & 1;
-    if (it + 1 < total) load_tile(it + 1);
-    const float* As = As0 + st * STAGE;
-    const float* Bs = Bs0 + st * STAGE;
+  int st = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 av[MI], bv[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        av[mi] = *reinterpret_cast<const f32x4*>(As + arow + mi * 32 * LDS_LD + q * 8);
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        bv[ni] = *reinterpret_cast<const f32x4*>(Bs + brow + ni * 32 * LDS_LD + q * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    for (int it = 0; it < total; ++it) {
+      load_tile();                       // next slab (of this or the next tile) into registers
+      const float* As = As0 + st * STAGE;
+      const float* Bs = Bs0 + st * STAGE;
+      f32x4 av[4][MI], bv[4][NI];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
+          av[q][mi] = *reinterpret_cast<const f32x4*>(As + arow + mi * 32 * LDS_LD + q * 8);
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][e], bv[ni][e], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni)
+          bv[q][ni] = *reinterpret_cast<const f32x4*>(Bs + brow + ni * 32 * LDS_LD + q * 8);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][mi][e], bv[q][ni][e], acc[mi][ni], 0, 0, 0);
+      if (it + 1 < total) { store_tile(st ^ 1); advance_loader(); }   // else: parked in registers over the epilogue
+      __syncthreads();
+      st ^= 1;
     }
-    if (it + 1 < total) store_tile(st ^ 1);
-    __syncthreads();
-  }
 
-  // epilogue: lane holds column j = lane&31, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---------------- epilogue: accumulators -> LDS -> coalesced float4 rows ----------------
+    const int tile_m = tile / tiles_n;
+    const int m0 = tile_m * BM, n0 = (tile - tile_m * tiles_n) * BN;
+    float* Cs = smem;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int m = m0 + wm * MI * 32 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      if (m >= a.M) continue;
-      const float* rbp = nullptr;
-      if (a.rowbias) rbp = a.rowbias + (long)a.rowvar[a.row0 + m / a.L] * a.rb_stride;
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + wn * NI * 32 + ni * 32 + r;
-        if (n >= a.N) continue;
-        float v = acc[mi][ni][reg];
-        if (a.bias) v += a.bias[n];
-        if (rbp) v += rbp[n];
-        if (a.resid) v += a.resid[(long)m * a.ldr + n];
-        if (a.resid2) v += a.resid2[(long)m * a.ldr2 + n];
-        if (n < a.N1) a.C[(long)m * a.ldc + n] = v;
-        else a.C2[(long)m * a.ldc2 + (n - a.N1)] = v;
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = wm * MI * 32 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          Cs[row * CLD + wn * NI * 32 + ni * 32 + r] = acc[mi][ni][reg];
+        }
+    __syncthreads();
+    if (EPI == EPI_LINEAR || EPI == EPI_GEGLU_BWD) {
+      constexpr int C4N = BN / 4, RP = NT / C4N, PASSES = BM / RP;
+      const int cc = tid % C4N, rr = tid / C4N;
+      const int n = n0 + cc * 4;
+      const bool nok = n < a.N;
+      const int nc = nok ? n : 0;
+      f32x4 b4 = {0, 0, 0, 0};
+      if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + nc);
+#pragma unroll 4
+      for (int p = 0; p < PASSES; ++p) {
+        const int row = p * RP + rr;
+        const int m = m0 + row;
+        const bool ok = nok && m < a.M;
+        const int mc = m < a.M ? m : 0;
+        const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + b4;
+        if (EPI == EPI_LINEAR) {
+          if (a.rowbias) v += *reinterpret_cast<const f32x4*>(a.rowbias + (long)a.rowvar[a.row0 + mc / a.L] * a.rb_stride + nc);
+          if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + orow * a.ldr + nc);
+          if (GEN && a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + orow * a.ldr2 + nc);
+          if (ok) {
+            if (!GEN || n < a.N1) *reinterpret_cast<f32x4*>(a.C + orow * a.ldc + n) = v;
+            else *reinterpret_cast<f32x4*>(a.C2 + orow * a.ldc2 + (n - a.N1)) = v;
+          }
+        } else {
+          // v = d(hg)[m][n]; with ag = [a | g] (n_tok, 2N): d(ag) = [v * gelu(g) | v * a * gelu'(g)]
+          const f32x4 av = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + nc);
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + a.N + nc);
+          f32x4 da, dg;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { da[e] = v[e] * gelu_f(gv[e]); dg[e] = v[e] * av[e] * gelu_grad_f(gv[e]); }
+          if (ok) {
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + n) = da;
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + a.N + n) = dg;
+          }
+        }
+      }
+    } else {   // EPI_GEGLU_FWD: tile columns [0, BN/2) hold a_j, [BN/2, BN) the matching g_j (weights packed so)
+      constexpr int C4N = BN / 8, RP = NT / C4N, PASSES = BM / RP;
+      const int cc = tid % C4N, rr = tid / C4N;
+      const int half = a.N >> 1;
+      const int j = (n0 >> 1) + cc * 4;                // index inside the a- (and g-) half
+      f32x4 ba = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+      if (a.bias) {
+        ba = *reinterpret_cast<const f32x4*>(a.bias + n0 + cc * 4);
+        bg = *reinterpret_cast<const f32x4*>(a.bias + n0 + BN / 2 + cc * 4);
+      }
+#pragma unroll 4
+      for (int p = 0; p < PASSES; ++p) {
+        const int row = p * RP + rr;
+        const int m = m0 + row;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + ba;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(Cs + row * CLD + BN / 2 + cc * 4) + bg;
+        f32x4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = av[e] * gelu_f(gv[e]);
+        if (m < a.M) {
+          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + j) = av;            // stash ag in natural [a | g] layout
+          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + half + j) = gv;
+          *reinterpret_cast<f32x4*>(a.aux_out + (long)m * a.ld_aux + j) = hv;   // hg = a * gelu(g)
+        }
       }
     }
+    __syncthreads();
+    if (tile + 1 < t_end) { store_tile(st); advance_loader(); __syncthreads(); }
   }
 }
 
-template <int WM, int WN, int MI, int NI>
-static int launch_cfg(const GemmArgs& a, hipStream_t s) {
-  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+template <int WM, int WN, int MI, int NI> struct Cfg {
+  static constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  static constexpr size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+};
+
+template <int WM, int WN, int MI, int NI, int EPI, bool GEN>
+static int launch_cfg(const GemmArgs& a, int blocks_per_cu, hipStream_t s) {
+  using C = Cfg<WM, WN, MI, NI>;
+  const int tiles_m = (a.M + C::BM - 1) / C::BM, tiles_n = (a.N + C::BN - 1) / C::BN;
   const int n_tiles = tiles_m * tiles_n;
-  const int chunk = (n_tiles + 7) / 8;
-  const size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
-  hipLaunchKernelGGL((gemm_kernel<WM, WN, MI, NI>), dim3(chunk * 8), dim3(WM * WN * 64), lds, s, a, tiles_n,
-                     n_tiles, chunk);
+  const int nb = std::min(((n_tiles + 7) / 8) * 8, 256 * blocks_per_cu);
+  hipLaunchKernelGGL((gemm_kernel<WM, WN, MI, NI, EPI, GEN>), dim3(nb), dim3(WM * WN * 64), C::lds, s, a, tiles_n, n_tiles);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
-template <int WM, int WN, int MI, int NI>
+template <int WM, int WN, int MI, int NI, int EPI, bool GEN>
 static int set_attr() {
-  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-  const size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
-  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, MI, NI>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, MI, NI, EPI, GEN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg<WM, WN, MI, NI>::lds));
   return 0;
 }
 int init_gemm_attributes() {
-  if (int e = set_attr<2, 2, 2, 2>()) return e;
-  if (int e = set_attr<2, 2, 2, 1>()) return e;
-  return set_attr<4, 1, 2, 1>();
+  if (int e = set_attr<2, 2, 2, 2, EPI_LINEAR, false>()) return e;
+  if (int e = set_attr<2, 2, 2, 2, EPI_LINEAR, true>()) return e;
+  if (int e = set_attr<2, 2, 2, 2, EPI_GEGLU_FWD, false>()) return e;
+  if (int e = set_attr<2, 2, 2, 2, EPI_GEGLU_BWD, false>()) return e;
+  if (int e = set_attr<2, 2, 2, 1, EPI_LINEAR, true>()) return e;
+  return set_attr<4, 1, 1, 1, EPI_LINEAR, true>();
 }
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
@@ -188,15 +310,35 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if (a.A2 == nullptr) a.K1 = a.K;
   if (a.C2 == nullptr) a.N1 = a.N;
   if (a.rb_stride == 0) a.rb_stride = a.N;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   RAMP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.taps >= 1 && a.L >= 1, "bad GEMM dims");
-  RAMP_REQUIRE(a.K % 4 == 0 && a.lda % 4 == 0 && a.K1 % 4 == 0, "K, K1 and lda must be multiples of 4 floats");
+  RAMP_REQUIRE(a.K % BK == 0 && a.lda % 4 == 0 && a.N % 4 == 0 && a.N1 % 4 == 0,
+               "K must be a multiple of 32, N, N1 and lda multiples of 4 floats");
   RAMP_REQUIRE(a.A2 == nullptr || (a.lda2 % 4 == 0 && a.K1 % BK == 0), "split-K source must start on a K tile");
-  RAMP_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.W) & 15) == 0 &&
-               (reinterpret_cast<uintptr_t>(a.A2) & 15) == 0, "A/W must be 16-byte aligned");
+  RAMP_REQUIRE(al16(a.A) && al16(a.W) && al16(a.A2) && al16(a.C) && al16(a.C2) && al16(a.resid) && al16(a.resid2) &&
+               al16(a.bias) && al16(a.rowbias) && al16(a.aux_in) && al16(a.aux_out), "GEMM operands must be 16-byte aligned");
+  RAMP_REQUIRE(a.ldc % 4 == 0 && a.ldc2 % 4 == 0 && a.ldr % 4 == 0 && a.ldr2 % 4 == 0 && a.ld_aux % 4 == 0 &&
+               a.rb_stride % 4 == 0, "leading dimensions must be multiples of 4 floats");
   RAMP_REQUIRE(a.rowbias == nullptr || a.rowvar != nullptr, "rowbias needs rowvar");
-  if (a.N >= 128) return launch_cfg<2, 2, 2, 2>(a, s);     // 128 x 128
-  if (a.N >= 64) return launch_cfg<2, 2, 2, 1>(a, s);      // 128 x 64
-  return launch_cfg<4, 1, 2, 1>(a, s);                      // 256 x 32
+  RAMP_REQUIRE(a.a_stride >= 1 && a.c_rstride >= 1, "bad strides");
+  const bool gen = a.taps > 1 || a.a_stride != 1 || a.c_rstride != 1 || a.c_roff != 0 || a.A2 || a.C2 || a.resid2 ||
+                   a.shift0 != 0;
+  if (a.epi == EPI_GEGLU_FWD) {
+    RAMP_REQUIRE(!gen && a.N % 256 == 0 && a.aux_out && !a.resid && !a.rowbias,
+                 "GEGLU-forward epilogue needs a plain linear with N % 256 == 0 and aux_out");
+    return launch_cfg<2, 2, 2, 2, EPI_GEGLU_FWD, false>(a, 2, s);
+  }
+  if (a.epi == EPI_GEGLU_BWD) {
+    RAMP_REQUIRE(!gen && a.N >= 128 && a.aux_in && !a.resid && !a.rowbias && !a.bias,
+                 "GEGLU-backward epilogue needs a plain linear with aux_in");
+    return launch_cfg<2, 2, 2, 2, EPI_GEGLU_BWD, false>(a, 2, s);
+  }
+  if (a.N >= 128) {                                              // 128 x 128, 2 blocks / CU
+    if (!gen) return launch_cfg<2, 2, 2, 2, EPI_LINEAR, false>(a, 2, s);
+    return launch_cfg<2, 2, 2, 2, EPI_LINEAR, true>(a, 2, s);
+  }
+  if (a.N >= 64) return launch_cfg<2, 2, 2, 1, EPI_LINEAR, true>(a, 2, s);      // 128 x 64
+  return launch_cfg<4, 1, 1, 1, EPI_LINEAR, true>(a, 3, s);                      // 128 x 32
 }
 
 }  // namespace ramp
