@@ -35,7 +35,7 @@ typedef struct ramp_config {
   int32_t context_dim;     /* 320 (2-D scene encoder) or 256 (3-D)                     */
   int32_t max_rows;        /* capacity in network rows per chunk (rows = B * n_rp)     */
   int32_t debug_taps;      /* 1: keep per-module outputs / output-grads for ramp_debug_read */
-  int32_t reserved;
+  int32_t gemm_mode;       /* 0 = library default (env RAMP_GEMM_MODE=fp32|bf16x6), 1 = exact fp32 MFMA, 2 = bf16x6 split */
 } ramp_config;
 
 const char* ramp_last_error(void);

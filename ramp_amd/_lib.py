@@ -19,7 +19,7 @@ c_i64p = C.POINTER(C.c_int64)
 class RampConfig(C.Structure):
     _fields_ = [("state_dim", C.c_int32), ("horizon", C.c_int32), ("unet_input_dim", C.c_int32),
                 ("n_levels", C.c_int32), ("context_dim", C.c_int32), ("max_rows", C.c_int32),
-                ("debug_taps", C.c_int32), ("reserved", C.c_int32)]
+                ("debug_taps", C.c_int32), ("gemm_mode", C.c_int32)]
 
 
 class RampApfParams(C.Structure):

@@ -41,6 +41,7 @@ struct GemmArgs {
   const float* A = nullptr;  int lda = 0;
   const float* A2 = nullptr; int lda2 = 0; int K1 = 0;    // K1 == K when A2 unused
   const float* W = nullptr;                                 // [taps][N][K], K contiguous
+  const unsigned short* Wx = nullptr; long wx_plane = 0;    // optional bf16x6 planes [3][taps][N][K] (plane stride in elements)
   const float* bias = nullptr;                              // [N]
   const float* rowbias = nullptr; const int* rowvar = nullptr; int row0 = 0; int rb_stride = 0;  // [n_var][rb_stride]
   const float* resid = nullptr;  int ldr = 0;
@@ -60,10 +61,12 @@ struct GemmArgs {
 };
 // EPI_LINEAR:    C = acc + bias + rowbias + resid + resid2
 // EPI_GEGLU_FWD: weights packed so that each 128-column tile is [64 a-columns | the 64 matching g-columns];
-//                C (M, N) receives ag = acc + bias in the natural [a | g] layout, aux_out (M, N/2) = a * gelu(g)
-// EPI_GEGLU_BWD: acc = d(hg) (M, N); C (M, 2N) = [acc * gelu(g) | acc * a * gelu'(g)] with (a, g) from aux_in
+//                with [a | g] = acc + bias: aux_out (M, N/2) = a * gelu(g), and C (M, N) receives the VJP stash
+//                [gelu(g) | a * gelu'(g)]
+// EPI_GEGLU_BWD: acc = d(hg) (M, N); C (M, 2N) = d[a | g] = [acc * s1 | acc * s2] with the stash [s1 | s2] in aux_in
 enum { EPI_LINEAR = 0, EPI_GEGLU_FWD = 1, EPI_GEGLU_BWD = 2 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+int launch_split3(const float* in, unsigned short* out, long n, hipStream_t s);   // fp32 -> 3 bf16 planes
 int init_gemm_attributes();        // raise the dynamic-LDS limit of every GEMM instantiation (once)
 int init_attention_attributes();   // same for the attention kernels
 

@@ -112,6 +112,10 @@ struct Resample {
 
 using namespace ramp;
 
+#ifndef RAMP_DEFAULT_GEMM_MODE
+#define RAMP_DEFAULT_GEMM_MODE 0
+#endif
+
 struct ramp_ctx {
   ramp_config cfg{};
   int device = 0;
@@ -142,6 +146,9 @@ struct ramp_ctx {
   float* s_cloud = nullptr; size_t s_cloud_cap = 0;
   // graph cache
   hipGraphExec_t graph_exec = nullptr; std::string graph_key;
+  // bf16x6 weight planes: fp32 weight base pointer -> (planes, element count)
+  int gemm_mode = 0;                 // 0 = exact fp32 MFMA, 1 = bf16x6 split on the bf16 matrix cores
+  std::map<const float*, std::pair<unsigned short*, size_t>> x6;
   // debug
   std::map<std::string, std::pair<float*, size_t>> dbg;
   int64_t launches = 0;
@@ -307,7 +314,18 @@ struct Run {
   ramp_ctx* c; hipStream_t s; int R; int row0;
   int gemm(const GemmArgs& a) {
     prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, a.taps});
-    int rc = launch_gemm(a, s);
+    GemmArgs b = a;
+    if (c->gemm_mode == 1 && b.N >= 128) {
+      auto it = c->x6.upper_bound(b.W);
+      if (it != c->x6.begin()) {
+        --it;
+        if (b.W >= it->first && b.W < it->first + it->second.second) {
+          b.Wx = it->second.first + (b.W - it->first);
+          b.wx_plane = (long)it->second.second;
+        }
+      }
+    }
+    int rc = launch_gemm(b, s);
     prof_post(c, s);
     c->launches++;
     return rc;
@@ -748,6 +766,37 @@ int ramp_finalize_weights(ramp_ctx* c) {
   CK(dev_alloc(c, &c->g_t1, cap * max_lc)); CK(dev_alloc(c, &c->g_t2, cap * max_lc)); CK(dev_alloc(c, &c->g_tr, cap * max_lc));
   c->skip_grad.assign(nl, nullptr);
   for (int k = 1; k < nl; ++k) CK(dev_alloc(c, &c->skip_grad[k], cap * c->sts[k].L * c->sts[k].C));
+  // bf16x6 planes of every GEMM weight with N >= 128
+  {
+    const char* env = getenv("RAMP_GEMM_MODE");
+    c->gemm_mode = c->cfg.gemm_mode == 1 ? 0 : c->cfg.gemm_mode == 2 ? 1 : (env && std::string(env) == "bf16x6") ? 1 : (env && std::string(env) == "fp32") ? 0 : RAMP_DEFAULT_GEMM_MODE;
+  }
+  if (c->gemm_mode == 1) {
+    auto reg = [&](const float* w, size_t n) -> int {
+      if (!w || c->x6.count(w)) return 0;
+      float* p; CK(dev_alloc(c, &p, (3 * n + 1) / 2 + 4));
+      CK(launch_split3(w, reinterpret_cast<unsigned short*>(p), (long)n, 0));
+      c->x6[w] = {reinterpret_cast<unsigned short*>(p), n};
+      return 0;
+    };
+    for (auto& r : c->rtbs) {
+      if (!r.first) { CK(reg(r.c1.fwd, 5ul * r.cin * r.cout)); CK(reg(r.c1.bwd, 5ul * r.cin * r.cout)); }
+      CK(reg(r.c2.fwd, 5ul * r.cout * r.cout)); CK(reg(r.c2.bwd, 5ul * r.cout * r.cout));
+      if (r.has_res && !r.first) { CK(reg(r.res_f, (size_t)r.cin * r.cout)); CK(reg(r.res_b, (size_t)r.cin * r.cout)); }
+    }
+    for (auto& st : c->sts) {
+      CK(reg(st.wpi_f, 256ul * st.C)); CK(reg(st.wpi_b, 256ul * st.C));
+      CK(reg(st.wpo_f, 256ul * st.C)); CK(reg(st.wpo_b, 256ul * st.C));
+      for (auto& k : st.blk) {
+        CK(reg(k.wqkv_f, 768ul * 256)); CK(reg(k.wqkv_b, 768ul * 256));
+        CK(reg(k.wo_f, 256ul * 256)); CK(reg(k.wo_b, 256ul * 256));
+        CK(reg(k.w1_pk, 2048ul * 256)); CK(reg(k.w1_b, 2048ul * 256));
+        CK(reg(k.w2_f, 1024ul * 256)); CK(reg(k.w2_b, 1024ul * 256));
+      }
+    }
+    for (auto& d : c->downs) { CK(reg(d.w_f, 3ul * d.C * d.C)); CK(reg(d.w_b, 3ul * d.C * d.C)); }
+    for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C)); CK(reg(u.w_b, 4ul * u.C * u.C)); }
+  }
   RAMP_HIP_CHECK(hipDeviceSynchronize());
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
   CK(init_attention_attributes());
@@ -1000,6 +1049,19 @@ int ramp_op_gemm(const float* A, const float* W, const float* bias, const float*
   RAMP_REQUIRE(A && W && C, "null argument");
   GemmArgs a; a.A = A; a.lda = K; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.C = C; a.ldc = N;
   a.M = M; a.N = N; a.K = K; a.taps = taps; a.shift0 = shift0; a.shift_step = shift_step; a.L = L;
+  const char* env = getenv("RAMP_GEMM_MODE");
+  if (env && std::string(env) == "bf16x6" && N >= 128) {       // test / micro-benchmark path: split W on the fly
+    static std::map<const float*, unsigned short*> cache;
+    const long n = (long)taps * N * K;
+    auto it = cache.find(W);
+    if (it == cache.end()) {
+      unsigned short* p = nullptr;
+      RAMP_HIP_CHECK(hipMalloc(&p, 3 * n * sizeof(unsigned short)));
+      it = cache.emplace(W, p).first;
+    }
+    if (int rc = launch_split3(W, it->second, n, as_stream(stream))) return rc;
+    a.Wx = it->second; a.wx_plane = n;
+  }
   return launch_gemm(a, as_stream(stream));
 }
 int ramp_op_groupnorm(const float* x, const float* gamma, const float* beta, const float* tbias, const float* resid,

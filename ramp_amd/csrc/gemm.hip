@@ -37,6 +37,97 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// Accumulators -> LDS -> coalesced float4 rows, with the fused epilogue math.  The caller guarantees that no
+// wave still reads operand tiles from `smem` (a barrier precedes the call); ends with the C tile fully consumed
+// by this thread's own reads only (the caller issues the next barrier before reusing `smem`).
+template <int WM, int WN, int MI, int NI, int EPI, bool GEN>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[MI][NI], float* smem, int tile, int tiles_n,
+                                         int tid, int wm, int wn, int r, int h) {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
+  constexpr int CLD = BN + 4;
+  // ---------------- epilogue: accumulators -> LDS -> coalesced float4 rows ----------------
+  const int tile_m = tile / tiles_n;
+  const int m0 = tile_m * BM, n0 = (tile - tile_m * tiles_n) * BN;
+  float* Cs = smem;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wm * MI * 32 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        Cs[row * CLD + wn * NI * 32 + ni * 32 + r] = acc[mi][ni][reg];
+      }
+  __syncthreads();
+  if (EPI == EPI_LINEAR || EPI == EPI_GEGLU_BWD) {
+    constexpr int C4N = BN / 4, RP = NT / C4N, PASSES = BM / RP;
+    const int cc = tid % C4N, rr = tid / C4N;
+    const int n = n0 + cc * 4;
+    const bool nok = n < a.N;
+    const int nc = nok ? n : 0;
+    f32x4 b4 = {0, 0, 0, 0};
+    if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + nc);
+#pragma unroll 4
+    for (int p = 0; p < PASSES; ++p) {
+      const int row = p * RP + rr;
+      const int m = m0 + row;
+      const bool ok = nok && m < a.M;
+      const int mc = m < a.M ? m : 0;
+      const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + b4;
+      if (EPI == EPI_LINEAR) {
+        if (a.rowbias) v += *reinterpret_cast<const f32x4*>(a.rowbias + (long)a.rowvar[a.row0 + mc / a.L] * a.rb_stride + nc);
+        if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + orow * a.ldr + nc);
+        if (GEN && a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + orow * a.ldr2 + nc);
+        if (ok) {
+          if (!GEN || n < a.N1) *reinterpret_cast<f32x4*>(a.C + orow * a.ldc + n) = v;
+          else *reinterpret_cast<f32x4*>(a.C2 + orow * a.ldc2 + (n - a.N1)) = v;
+        }
+      } else {
+        // v = d(hg)[m][n]; the forward stashed s = [gelu(g) | a * gelu'(g)] (n_tok, 2N): d(ag) = [v * s1 | v * s2]
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + nc);
+        const f32x4 s2 = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + a.N + nc);
+        const f32x4 da = v * s1, dg = v * s2;
+        if (ok) {
+          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + n) = da;
+          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + a.N + n) = dg;
+        }
+      }
+    }
+  } else {   // EPI_GEGLU_FWD: tile columns [0, BN/2) hold a_j, [BN/2, BN) the matching g_j (weights packed so)
+    constexpr int C4N = BN / 8, RP = NT / C4N, PASSES = BM / RP;
+    const int cc = tid % C4N, rr = tid / C4N;
+    const int half = a.N >> 1;
+    const int j = (n0 >> 1) + cc * 4;                // index inside the a- (and g-) half
+    f32x4 ba = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+    if (a.bias) {
+      ba = *reinterpret_cast<const f32x4*>(a.bias + n0 + cc * 4);
+      bg = *reinterpret_cast<const f32x4*>(a.bias + n0 + BN / 2 + cc * 4);
+    }
+#pragma unroll 4
+    for (int p = 0; p < PASSES; ++p) {
+      const int row = p * RP + rr;
+      const int m = m0 + row;
+      const f32x4 av = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + ba;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(Cs + row * CLD + BN / 2 + cc * 4) + bg;
+      f32x4 hv, s1, s2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float cdf = 0.5f * (1.f + erff(gv[e] * 0.70710678118654752440f));
+        const float pdf = expf(-0.5f * gv[e] * gv[e]) * 0.39894228040143267794f;
+        s1[e] = gv[e] * cdf;                           // gelu(g)
+        s2[e] = av[e] * (cdf + gv[e] * pdf);           // a * gelu'(g)
+        hv[e] = av[e] * s1[e];                         // hg = a * gelu(g)
+      }
+      if (m < a.M) {
+        *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + j) = s1;            // stash for the VJP: no transcendental
+        *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + half + j) = s2;     // is needed in the backward epilogue
+        *reinterpret_cast<f32x4*>(a.aux_out + (long)m * a.ld_aux + j) = hv;
+      }
+    }
+  }
+}
+
 // GEN = false: plain linear (1 tap, unit strides, single source / destination, no second residual), the hot
 //               transformer shapes; operand rows outside M / N are clamped, never masked (they only feed
 //               outputs that are never stored) and K % 32 == 0, so the loader is 8 unconditional 16-byte loads.
@@ -192,86 +283,254 @@ void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles) {
       st ^= 1;
     }
 
-    // ---------------- epilogue: accumulators -> LDS -> coalesced float4 rows ----------------
+    epilogue<WM, WN, MI, NI, EPI, GEN>(a, acc, smem, tile, tiles_n, tid, wm, wn, r, h);
+    __syncthreads();
+    if (tile + 1 < t_end) { store_tile(st); advance_loader(); __syncthreads(); }
+  }
+}
+
+// =================================================================================================
+// bf16x6 variant: fp32-accurate products on the bf16 matrix cores.
+//
+// Every fp32 operand is split into three bf16 planes x = x1 + x2 + x3 (8 + 8 + 8 significand bits, residual
+// <= 2^-25 |x|); a*b is accumulated in fp32 as a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 (each bf16*bf16 product
+// is exact in fp32; the dropped terms a2b3 + a3b2 + a3b3 are <= 2^-25 |ab|, i.e. below fp32 rounding).  Six
+// v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate) replace eight v_mfma_f32_32x32x2_f32: 2.7x less matrix-core
+// time at fp32-level accuracy.  Weights are split once at load (planes [3][taps][N][K] bf16); activations are
+// split while they are staged into LDS (once per element, by the staging thread).
+// Single LDS stage (3 A planes + 3 B planes, 80-byte padded rows, conflict-free ds_read_b128), two blocks per
+// CU; the next slab always waits in registers (global loads in flight during the MFMAs and the epilogue).
+// =================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XLD = 40;          // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+// x (4 floats) -> three planes of 4 bf16 (2 dwords each)
+__device__ __forceinline__ void split3(const f32x4 x, u32x2& p1, u32x2& p2, u32x2& p3) {
+  f32x4 r1, r2;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const unsigned q = pk_bf16(x[2 * e], x[2 * e + 1]);
+    p1[e] = q;
+    r1[2 * e] = x[2 * e] - __builtin_bit_cast(float, q << 16);
+    r1[2 * e + 1] = x[2 * e + 1] - __builtin_bit_cast(float, q & 0xffff0000u);
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const unsigned q = pk_bf16(r1[2 * e], r1[2 * e + 1]);
+    p2[e] = q;
+    r2[2 * e] = r1[2 * e] - __builtin_bit_cast(float, q << 16);
+    r2[2 * e + 1] = r1[2 * e + 1] - __builtin_bit_cast(float, q & 0xffff0000u);
+  }
+  p3[0] = pk_bf16(r2[0], r2[1]);
+  p3[1] = pk_bf16(r2[2], r2[3]);
+}
+
+__global__ void split3_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, long n4, long plane) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(in)[i];
+    u32x2 p1, p2, p3;
+    split3(v, p1, p2, p3);
+    reinterpret_cast<u32x2*>(out)[i] = p1;
+    reinterpret_cast<u32x2*>(out + plane)[i] = p2;
+    reinterpret_cast<u32x2*>(out + 2 * plane)[i] = p3;
+  }
+}
+int launch_split3(const float* in, unsigned short* out, long n, hipStream_t s) {
+  RAMP_REQUIRE(n > 0 && n % 4 == 0, "split3 needs a multiple of 4 elements");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(split3_kernel, dim3((int)std::min<long>((n4 + 255) / 256, 8192)), dim3(256), 0, s, in, out, n4, n);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <int EPI, bool GEN>
+__global__ __launch_bounds__(256)
+void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
+  constexpr int WM = 2, WN = 2, MI = 2, NI = 2;
+  constexpr int BM = 128, BN = 128, NT = 256;
+  constexpr int AI = 4;                               // fp32 float4 loads per thread (A)
+  constexpr int BI = 2;                               // 16-byte bf16 loads per thread per plane (B)
+  constexpr int PLANE = BM * XLD;                     // bf16 elements per LDS plane
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* Ax = reinterpret_cast<unsigned short*>(smem);           // [3][BM][XLD]
+  unsigned short* Bx = Ax + 3 * PLANE;                                     // [3][BN][XLD]
+
+  const int bid = blockIdx.x, nb = gridDim.x;
+  const int xcd = bid & 7, slot = bid >> 3, bpx = nb >> 3;
+  const long xlo = (long)xcd * n_tiles / 8, xhi = (long)(xcd + 1) * n_tiles / 8;
+  const int t_begin = (int)(xlo + (xhi - xlo) * slot / bpx);
+  const int t_end = (int)(xlo + (xhi - xlo) * (slot + 1) / bpx);
+  if (t_begin >= t_end) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int c4 = tid & 7, r0 = tid >> 3;              // A staging: float4 column / first row (rows r0 + 32 i)
+  const int bq = tid & 3, br = tid >> 2;              // B staging: 8-element k segment / first row (rows br + 64 i)
+
+  const int nk = a.K / BK;
+  const int total = GEN ? a.taps * nk : nk;
+  const long wplane = a.wx_plane;
+
+  int ld_tile = t_begin, ld_it = 0;
+  const float* ap[AI];
+  const unsigned short* bp[BI];
+  int a_l[GEN ? AI : 1]; long a_m[GEN ? AI : 1];
+  const int Lin = GEN ? a.L * a.a_stride : 0;
+  auto setup_rows = [&](int tile) {
     const int tile_m = tile / tiles_n;
-    const int m0 = tile_m * BM, n0 = (tile - tile_m * tiles_n) * BN;
-    float* Cs = smem;
+    const int n0 = (tile - tile_m * tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int m = tile_m * BM + r0 + 32 * i;
+      if (!GEN) {
+        m = m < a.M ? m : a.M - 1;
+        ap[i] = a.A + (long)m * a.lda + c4 * 4;
+      } else {
+        const bool mv = m < a.M;
+        m = mv ? m : 0;
+        const int seg = m / a.L, l = m - seg * a.L;
+        a_l[i] = mv ? l * a.a_stride : -(1 << 28);
+        a_m[i] = (long)seg * Lin + l * a.a_stride;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int n = n0 + br + 64 * i;
+      n = n < a.N ? n : a.N - 1;
+      bp[i] = a.Wx + (long)n * a.K + bq * 8;
+    }
+  };
+  f32x4 ra[AI];
+  u32x4 rb[3][BI];
+  auto load_tile = [&]() {
+    int k0; long woff;
+    if (!GEN) {
+      k0 = ld_it * BK; woff = k0;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+    } else {
+      const int tap = ld_it / nk;
+      k0 = (ld_it - tap * nk) * BK;
+      const int sh = a.shift0 + tap * a.shift_step;
+      const float* Ab; int ld, kc;
+      if (k0 < a.K1) { Ab = a.A; ld = a.lda; kc = k0; } else { Ab = a.A2; ld = a.lda2; kc = k0 - a.K1; }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int l = a_l[i] + sh;
+        const bool ok = l >= 0 && l < Lin;
+        const long row = ok ? a_m[i] + sh : a_m[i];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Ab + row * ld + kc + c4 * 4);
+        ra[i] = ok ? v : f32x4{0, 0, 0, 0};
+      }
+      woff = (long)tap * a.N * a.K + k0;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < BI; ++i) rb[p][i] = *reinterpret_cast<const u32x4*>(bp[i] + p * wplane + woff);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      u32x2 p1, p2, p3;
+      split3(ra[i], p1, p2, p3);
+      const int off = (r0 + 32 * i) * XLD + c4 * 4;
+      *reinterpret_cast<u32x2*>(Ax + off) = p1;
+      *reinterpret_cast<u32x2*>(Ax + PLANE + off) = p2;
+      *reinterpret_cast<u32x2*>(Ax + 2 * PLANE + off) = p3;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < BI; ++i)
+        *reinterpret_cast<u32x4*>(Bx + p * PLANE + (br + 64 * i) * XLD + bq * 8) = rb[p][i];
+  };
+  auto advance_loader = [&]() {
+    if (++ld_it == total) {
+      ld_it = 0;
+      if (ld_tile + 1 < t_end) { ++ld_tile; setup_rows(ld_tile); }
+    }
+  };
+
+  const int r = lane & 31, h = lane >> 5;
+  const int arow = (wm * 64 + r) * XLD + h * 8;
+  const int brow = (wn * 64 + r) * XLD + h * 8;
+
+  setup_rows(ld_tile);
+  load_tile();
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = wm * MI * 32 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          Cs[row * CLD + wn * NI * 32 + ni * 32 + r] = acc[mi][ni][reg];
-        }
-    __syncthreads();
-    if (EPI == EPI_LINEAR || EPI == EPI_GEGLU_BWD) {
-      constexpr int C4N = BN / 4, RP = NT / C4N, PASSES = BM / RP;
-      const int cc = tid % C4N, rr = tid / C4N;
-      const int n = n0 + cc * 4;
-      const bool nok = n < a.N;
-      const int nc = nok ? n : 0;
-      f32x4 b4 = {0, 0, 0, 0};
-      if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + nc);
-#pragma unroll 4
-      for (int p = 0; p < PASSES; ++p) {
-        const int row = p * RP + rr;
-        const int m = m0 + row;
-        const bool ok = nok && m < a.M;
-        const int mc = m < a.M ? m : 0;
-        const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
-        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + b4;
-        if (EPI == EPI_LINEAR) {
-          if (a.rowbias) v += *reinterpret_cast<const f32x4*>(a.rowbias + (long)a.rowvar[a.row0 + mc / a.L] * a.rb_stride + nc);
-          if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + orow * a.ldr + nc);
-          if (GEN && a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + orow * a.ldr2 + nc);
-          if (ok) {
-            if (!GEN || n < a.N1) *reinterpret_cast<f32x4*>(a.C + orow * a.ldc + n) = v;
-            else *reinterpret_cast<f32x4*>(a.C2 + orow * a.ldc2 + (n - a.N1)) = v;
-          }
-        } else {
-          // v = d(hg)[m][n]; with ag = [a | g] (n_tok, 2N): d(ag) = [v * gelu(g) | v * a * gelu'(g)]
-          const f32x4 av = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + nc);
-          const f32x4 gv = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + a.N + nc);
-          f32x4 da, dg;
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    for (int it = 0; it < total; ++it) {
+      __syncthreads();                   // readers of the previous slab (or of the C tile) are done
+      store_tile();                      // split + registers -> LDS
+      __syncthreads();
+      advance_loader();
+      load_tile();                       // next slab -> registers, in flight during the MFMAs below
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { da[e] = v[e] * gelu_f(gv[e]); dg[e] = v[e] * av[e] * gelu_grad_f(gv[e]); }
-          if (ok) {
-            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + n) = da;
-            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + a.N + n) = dg;
-          }
-        }
-      }
-    } else {   // EPI_GEGLU_FWD: tile columns [0, BN/2) hold a_j, [BN/2, BN) the matching g_j (weights packed so)
-      constexpr int C4N = BN / 8, RP = NT / C4N, PASSES = BM / RP;
-      const int cc = tid % C4N, rr = tid / C4N;
-      const int half = a.N >> 1;
-      const int j = (n0 >> 1) + cc * 4;                // index inside the a- (and g-) half
-      f32x4 ba = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-      if (a.bias) {
-        ba = *reinterpret_cast<const f32x4*>(a.bias + n0 + cc * 4);
-        bg = *reinterpret_cast<const f32x4*>(a.bias + n0 + BN / 2 + cc * 4);
-      }
-#pragma unroll 4
-      for (int p = 0; p < PASSES; ++p) {
-        const int row = p * RP + rr;
-        const int m = m0 + row;
-        const f32x4 av = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + ba;
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(Cs + row * CLD + BN / 2 + cc * 4) + bg;
-        f32x4 hv;
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 av[3][MI], bv[3][NI];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = av[e] * gelu_f(gv[e]);
-        if (m < a.M) {
-          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + j) = av;            // stash ag in natural [a | g] layout
-          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + half + j) = gv;
-          *reinterpret_cast<f32x4*>(a.aux_out + (long)m * a.ld_aux + j) = hv;   // hg = a * gelu(g)
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            av[p][mi] = *reinterpret_cast<const bf16x8*>(Ax + p * PLANE + arow + mi * 32 * XLD + s2 * 16);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            bv[p][ni] = *reinterpret_cast<const bf16x8*>(Bx + p * PLANE + brow + ni * 32 * XLD + s2 * 16);
         }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            f32x16 c = acc[mi][ni];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][mi], bv[0][ni], c, 0, 0, 0);   // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[2][ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][mi], bv[1][ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][mi], bv[0][ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[1][ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[0][ni], c, 0, 0, 0);
+            acc[mi][ni] = c;
+          }
       }
     }
-    __syncthreads();
-    if (tile + 1 < t_end) { store_tile(st); advance_loader(); __syncthreads(); }
+    __syncthreads();                     // every wave is done with the operand planes
+    epilogue<WM, WN, MI, NI, EPI, GEN>(a, acc, smem, tile, tiles_n, tid, wm, wn, r, h);
   }
+}
+
+constexpr size_t X6_LDS = std::max<size_t>(6 * (size_t)128 * XLD * 2, (size_t)128 * 132 * 4);
+
+template <int EPI, bool GEN>
+static int launch_x6(const GemmArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + 127) / 128, tiles_n = (a.N + 127) / 128;
+  const int n_tiles = tiles_m * tiles_n;
+  const int slots = 512;
+  const int rounds = (n_tiles + slots - 1) / slots;
+  const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
+  hipLaunchKernelGGL((gemm_x6_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+template <int EPI, bool GEN>
+static int set_attr_x6() {
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<EPI, GEN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
+  return 0;
 }
 
 template <int WM, int WN, int MI, int NI> struct Cfg {
@@ -284,7 +543,10 @@ static int launch_cfg(const GemmArgs& a, int blocks_per_cu, hipStream_t s) {
   using C = Cfg<WM, WN, MI, NI>;
   const int tiles_m = (a.M + C::BM - 1) / C::BM, tiles_n = (a.N + C::BN - 1) / C::BN;
   const int n_tiles = tiles_m * tiles_n;
-  const int nb = std::min(((n_tiles + 7) / 8) * 8, 256 * blocks_per_cu);
+  // fewest rounds the resident slots allow, then the fewest blocks that still finish in that many rounds
+  const int slots = 256 * blocks_per_cu;
+  const int rounds = (n_tiles + slots - 1) / slots;
+  const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
   hipLaunchKernelGGL((gemm_kernel<WM, WN, MI, NI, EPI, GEN>), dim3(nb), dim3(WM * WN * 64), C::lds, s, a, tiles_n, n_tiles);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
@@ -302,7 +564,11 @@ int init_gemm_attributes() {
   if (int e = set_attr<2, 2, 2, 2, EPI_GEGLU_FWD, false>()) return e;
   if (int e = set_attr<2, 2, 2, 2, EPI_GEGLU_BWD, false>()) return e;
   if (int e = set_attr<2, 2, 2, 1, EPI_LINEAR, true>()) return e;
-  return set_attr<4, 1, 1, 1, EPI_LINEAR, true>();
+  if (int e = set_attr<4, 1, 1, 1, EPI_LINEAR, true>()) return e;
+  if (int e = set_attr_x6<EPI_LINEAR, false>()) return e;
+  if (int e = set_attr_x6<EPI_LINEAR, true>()) return e;
+  if (int e = set_attr_x6<EPI_GEGLU_FWD, false>()) return e;
+  return set_attr_x6<EPI_GEGLU_BWD, false>();
 }
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
@@ -323,17 +589,22 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   RAMP_REQUIRE(a.a_stride >= 1 && a.c_rstride >= 1, "bad strides");
   const bool gen = a.taps > 1 || a.a_stride != 1 || a.c_rstride != 1 || a.c_roff != 0 || a.A2 || a.C2 || a.resid2 ||
                    a.shift0 != 0;
+  const bool x6 = a.Wx != nullptr && a.N >= 128;
+  RAMP_REQUIRE(!x6 || (al16(a.Wx) && a.K % 8 == 0 && a.wx_plane > 0), "bad bf16x6 weight planes");
   if (a.epi == EPI_GEGLU_FWD) {
     RAMP_REQUIRE(!gen && a.N % 256 == 0 && a.aux_out && !a.resid && !a.rowbias,
                  "GEGLU-forward epilogue needs a plain linear with N % 256 == 0 and aux_out");
+    if (x6) return launch_x6<EPI_GEGLU_FWD, false>(a, s);
     return launch_cfg<2, 2, 2, 2, EPI_GEGLU_FWD, false>(a, 2, s);
   }
   if (a.epi == EPI_GEGLU_BWD) {
     RAMP_REQUIRE(!gen && a.N >= 128 && a.aux_in && !a.resid && !a.rowbias && !a.bias,
                  "GEGLU-backward epilogue needs a plain linear with aux_in");
+    if (x6) return launch_x6<EPI_GEGLU_BWD, false>(a, s);
     return launch_cfg<2, 2, 2, 2, EPI_GEGLU_BWD, false>(a, 2, s);
   }
   if (a.N >= 128) {                                              // 128 x 128, 2 blocks / CU
+    if (x6) return gen ? launch_x6<EPI_LINEAR, true>(a, s) : launch_x6<EPI_LINEAR, false>(a, s);
     if (!gen) return launch_cfg<2, 2, 2, 2, EPI_LINEAR, false>(a, 2, s);
     return launch_cfg<2, 2, 2, 2, EPI_LINEAR, true>(a, 2, s);
   }

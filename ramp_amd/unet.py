@@ -27,7 +27,7 @@ class TemporalUnetInference(nn.Module):
     def __init__(self, n_support_points=None, state_dim=None, unet_input_dim=32, dim_mults=(1, 2, 4, 8),
                  time_emb_dim=32, self_attention=False, conditioning_embed_dim=4, conditioning_type='attention',
                  attention_num_heads=4, attention_dim_head=64, obstacle_3d=False, max_rows: int = 8192,
-                 debug_taps: bool = False, **kwargs):
+                 debug_taps: bool = False, gemm_mode: str = "default", **kwargs):
         super().__init__()
         if self_attention:
             raise NotImplementedError("self_attention=True (LinearAttention) is never used by the reference drivers")
@@ -47,6 +47,7 @@ class TemporalUnetInference(nn.Module):
         self.scene_encoder = ObstacleEncoder() if obstacle_3d else ObstacleEncoderSet()
         self.max_rows = int(max_rows)
         self.debug_taps = bool(debug_taps)
+        self.gemm_mode = {"default": 0, "fp32": 1, "bf16x6": 2}[gemm_mode]
         self._unet_keys = [k for k in unet_param_shapes(self.spec, with_scene_encoder=False)]
         self._unet_shapes = unet_param_shapes(self.spec, with_scene_encoder=False)
         self._weights: "OrderedDict[str, torch.Tensor]" = OrderedDict()   # host fp32 copies (checkpoint truth)
@@ -116,7 +117,8 @@ class TemporalUnetInference(nn.Module):
         lib = _lib.load()
         with torch.cuda.device(dev):
             cfg = _lib.RampConfig(self.state_dim, self.n_support_points, self.spec.unet_input_dim,
-                                  len(self.spec.dim_mults), self.context_dim, self.max_rows, int(self.debug_taps), 0)
+                                  len(self.spec.dim_mults), self.context_dim, self.max_rows, int(self.debug_taps),
+                                  self.gemm_mode)
             h = C.c_void_p()
             _lib.check(lib.ramp_create(C.byref(cfg), C.byref(h)), "ramp_create")
             for k in self._unet_keys:
