@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libramp_hip.so")
-SOURCES = ["gemm.hip", "rowops.hip", "sampler.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "sampler.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # sampler.hip mirrors the reference's elementwise fp32 expressions rounding for rounding: hipcc's default
 # -ffp-contract=fast would fuse a*b - c*d into an FMA (HIP's __fmul_rn is a plain multiply), so it is off there.

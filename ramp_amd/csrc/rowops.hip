@@ -3,7 +3,7 @@
 //   GroupNorm(+Mish,+time bias,+residual) fwd / dX   layers.py:280-297, 327-361; layers_attention_mini.py:78-80
 //   LayerNorm fwd / dX                                 layers_attention_mini.py:137-139
 //   GEGLU fwd / dX                                     layers_attention_mini.py:38-45
-//   4x64 softmax self-attention fwd / dX               layers_attention_mini.py:101-127
+//   (4x64 softmax self-attention lives in attention.hip)
 //   Downsample1d / Upsample1d fwd / dX                 layers.py:262-277
 //   first conv (S -> 32, k5 + 1x1 residual) fwd / dX   layers.py:337-361 for downs.0.0
 //   last conv (32 -> S, 1x1) fwd + energy-gradient seed  UnetInference.py:142-145, 26-27
@@ -285,317 +285,6 @@ int launch_geglu_bwd(const float* dhg, const float* ag, float* dag, int n_tok, i
   hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, dhg, ag, dag, n4, F / 4);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// Self-attention, 4 heads x 64, softmax over the L <= 64 tokens of one row.
-// One lane per query token; P = 64 / L (row, head) pairs share a wave.  K (then V) of the
-// wave's pairs sit in LDS; all lanes of a pair read the same 16-byte key slice (broadcast) and
-// pairs are offset by one 16-byte slot, so the ds_read_b128 are conflict-free.
-// ------------------------------------------------------------------------------------------
-template <int L> struct AttnCfg {
-  static constexpr int P = 64 / L;            // pairs per wave
-  static constexpr int LP = P * L;            // active lanes
-  static constexpr int PSTR = L * 64 + 4;     // floats per pair tile in LDS
-  static constexpr int TILE = P * PSTR;       // floats per wave tile
-};
-
-// cooperative wave load of a (LP tokens x 64) slice of qkv/dout-like tensor into the wave's LDS tile
-template <int L>
-__device__ __forceinline__ void wave_load_tile(float* tile, const float* __restrict__ src, int ld, int coff,
-                                               int pair0, int n_pairs, int lane) {
-  using Cf = AttnCfg<L>;
-  for (int idx = lane; idx < Cf::LP * 16; idx += 64) {
-    const int tok = idx >> 4, q4 = idx & 15;
-    const int pp = tok / L, jj = tok - pp * L;
-    const int pr = pair0 + pp;
-    f32x4 v = {0, 0, 0, 0};
-    if (pr < n_pairs) v = *reinterpret_cast<const f32x4*>(src + ((long)(pr >> 2) * L + jj) * ld + coff + (pr & 3) * 64 + q4 * 4);
-    *reinterpret_cast<f32x4*>(tile + pp * Cf::PSTR + jj * 64 + q4 * 4) = v;
-  }
-}
-
-template <int L>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, int n_pairs) {
-  using Cf = AttnCfg<L>;
-  extern __shared__ __attribute__((aligned(16))) float lds[];      // 4 * Cf::TILE floats
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* tile = lds + wave * Cf::TILE;
-  const int pair0 = (blockIdx.x * 4 + wave) * Cf::P;
-  const int p = lane / L, i = lane - p * L;
-  const int pair = pair0 + p;
-  const bool valid = lane < Cf::LP && pair < n_pairs;
-  const int row = pair >> 2, head = pair & 3;
-  const float* kt = tile + (valid ? p : 0) * Cf::PSTR;
-
-  wave_load_tile<L>(tile, qkv, 768, 256, pair0, n_pairs, lane);      // K
-  f32x4 q[16];
-#pragma unroll
-  for (int d = 0; d < 16; ++d)
-    q[d] = valid ? *reinterpret_cast<const f32x4*>(qkv + ((long)row * L + i) * 768 + head * 64 + d * 4) : f32x4{0, 0, 0, 0};
-  __syncthreads();
-  float s[L];
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-      const f32x4 kk = *reinterpret_cast<const f32x4*>(kt + j * 64 + d * 4);
-      acc += q[d][0] * kk[0]; acc += q[d][1] * kk[1]; acc += q[d][2] * kk[2]; acc += q[d][3] * kk[3];
-    }
-    s[j] = acc * 0.125f;
-    mx = fmaxf(mx, s[j]);
-  }
-  float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < L; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
-  const float inv = 1.f / sum;
-  __syncthreads();
-  wave_load_tile<L>(tile, qkv, 768, 512, pair0, n_pairs, lane);      // V
-  __syncthreads();
-  f32x4 acc[16];
-#pragma unroll
-  for (int d = 0; d < 16; ++d) acc[d] = f32x4{0, 0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    const float pj = s[j] * inv;
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-      const f32x4 vv = *reinterpret_cast<const f32x4*>(kt + j * 64 + d * 4);
-      acc[d] += pj * vv;
-    }
-  }
-  if (valid) {
-    float* op = o + ((long)row * L + i) * 256 + head * 64;
-#pragma unroll
-    for (int d = 0; d < 16; ++d) *reinterpret_cast<f32x4*>(op + d * 4) = acc[d];
-  }
-}
-
-// Backward.  One K/V/Q/dO tile plus one (L x L) score tile T per wave in LDS; the probabilities
-// never live in registers.  Phases:
-//   1. K tile : T[j][i] = p_ij                        (softmax recomputed from q, k)
-//   2. dO tile: dv_j = sum_i p_ij dO_i                (lane = key j reads row j of T)
-//   3. V tile : o_i = sum_j p_ij v_j, delta_i = dO_i . o_i  (flash-attention identity),
-//               T[j][i] = dS_ij = p_ij (dO_i . v_j - delta_i)
-//   4. K tile : dq_i = sum_j dS_ij k_j / 8
-//   5. Q tile : dk_j = sum_i dS_ij q_i / 8            (lane = key j)
-template <int L>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                        float* __restrict__ dqkv, int n_pairs) {
-  using Cf = AttnCfg<L>;
-  constexpr int TS = L + 1;                       // score tile row stride (conflict-free both ways)
-  extern __shared__ __attribute__((aligned(16))) float lds[];      // 4*TILE + 4*P*L*TS floats
-  float* tlds = lds + 4 * Cf::TILE;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* tile = lds + wave * Cf::TILE;
-  const int pair0 = (blockIdx.x * 4 + wave) * Cf::P;
-  const int p = lane / L, i = lane - p * L;
-  const int pair = pair0 + p;
-  const bool valid = lane < Cf::LP && pair < n_pairs;
-  const int row = pair >> 2, head = pair & 3;
-  const int pz = valid ? p : 0, iz = valid ? i : 0;
-  const float* kt = tile + pz * Cf::PSTR;
-  float* tt = tlds + (wave * Cf::P + pz) * L * TS;
-  const long tokbase = (long)row * L + i;
-
-  // ---- phase 1: probabilities into T
-  wave_load_tile<L>(tile, qkv, 768, 256, pair0, n_pairs, lane);      // K
-  f32x4 r[16];                                                        // q, later dO
-#pragma unroll
-  for (int d = 0; d < 16; ++d)
-    r[d] = valid ? *reinterpret_cast<const f32x4*>(qkv + tokbase * 768 + head * 64 + d * 4) : f32x4{0, 0, 0, 0};
-  __syncthreads();
-  float mx = -3.0e38f;
-#pragma unroll 2
-  for (int j = 0; j < L; ++j) {
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-      const f32x4 kk = *reinterpret_cast<const f32x4*>(kt + j * 64 + d * 4);
-      acc += r[d][0] * kk[0]; acc += r[d][1] * kk[1]; acc += r[d][2] * kk[2]; acc += r[d][3] * kk[3];
-    }
-    acc *= 0.125f;
-    if (valid) tt[j * TS + i] = acc;
-    mx = fmaxf(mx, acc);
-  }
-  float sum = 0.f;
-  if (valid) {
-    for (int j = 0; j < L; ++j) { const float e = expf(tt[j * TS + i] - mx); tt[j * TS + i] = e; sum += e; }
-    const float inv = 1.f / sum;
-    for (int j = 0; j < L; ++j) tt[j * TS + i] *= inv;
-  }
-  __syncthreads();
-
-  // ---- phase 2: dv_j = sum_i p_ij dO_i   (lane index i plays the key role)
-  wave_load_tile<L>(tile, dout, 256, 0, pair0, n_pairs, lane);       // dO
-#pragma unroll
-  for (int d = 0; d < 16; ++d)
-    r[d] = valid ? *reinterpret_cast<const f32x4*>(dout + tokbase * 256 + head * 64 + d * 4) : f32x4{0, 0, 0, 0};
-  __syncthreads();
-  {
-    f32x4 acc[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) acc[d] = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-    for (int ii = 0; ii < L; ++ii) {
-      const float w = tt[iz * TS + ii];
-#pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(kt + ii * 64 + d * 4);
-        acc[d] += w * vv;
-      }
-    }
-    if (valid) {
-      float* op = dqkv + tokbase * 768 + 512 + head * 64;
-#pragma unroll
-      for (int d = 0; d < 16; ++d) *reinterpret_cast<f32x4*>(op + d * 4) = acc[d];
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 3: delta_i and dS (V tile)
-  wave_load_tile<L>(tile, qkv, 768, 512, pair0, n_pairs, lane);      // V
-  __syncthreads();
-  {
-    f32x4 acc[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) acc[d] = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-    for (int j = 0; j < L; ++j) {
-      const float w = tt[j * TS + iz];
-#pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(kt + j * 64 + d * 4);
-        acc[d] += w * vv;
-      }
-    }
-    float delta = 0.f;
-#pragma unroll
-    for (int d = 0; d < 16; ++d)
-      delta += (r[d][0] * acc[d][0] + r[d][1] * acc[d][1]) + (r[d][2] * acc[d][2] + r[d][3] * acc[d][3]);
-#pragma unroll 2
-    for (int j = 0; j < L; ++j) {
-      float dp = 0.f;
-#pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(kt + j * 64 + d * 4);
-        dp += r[d][0] * vv[0]; dp += r[d][1] * vv[1]; dp += r[d][2] * vv[2]; dp += r[d][3] * vv[3];
-      }
-      if (valid) tt[j * TS + i] *= (dp - delta);
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 4: dq_i = sum_j dS_ij k_j * scale   (K tile)
-  wave_load_tile<L>(tile, qkv, 768, 256, pair0, n_pairs, lane);      // K
-  __syncthreads();
-  {
-    f32x4 acc[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) acc[d] = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-    for (int j = 0; j < L; ++j) {
-      const float w = tt[j * TS + iz];
-#pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        const f32x4 kk = *reinterpret_cast<const f32x4*>(kt + j * 64 + d * 4);
-        acc[d] += w * kk;
-      }
-    }
-    if (valid) {
-      float* op = dqkv + tokbase * 768 + head * 64;
-#pragma unroll
-      for (int d = 0; d < 16; ++d) *reinterpret_cast<f32x4*>(op + d * 4) = acc[d] * 0.125f;
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 5: dk_j = sum_i dS_ij q_i * scale   (Q tile, lane = key j)
-  wave_load_tile<L>(tile, qkv, 768, 0, pair0, n_pairs, lane);        // Q
-  __syncthreads();
-  {
-    f32x4 acc[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) acc[d] = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-    for (int ii = 0; ii < L; ++ii) {
-      const float w = tt[iz * TS + ii];
-#pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        const f32x4 qq = *reinterpret_cast<const f32x4*>(kt + ii * 64 + d * 4);
-        acc[d] += w * qq;
-      }
-    }
-    if (valid) {
-      float* op = dqkv + tokbase * 768 + 256 + head * 64;
-#pragma unroll
-      for (int d = 0; d < 16; ++d) *reinterpret_cast<f32x4*>(op + d * 4) = acc[d] * 0.125f;
-    }
-  }
-}
-
-template <int L> static int attn_fwd_launch(const float* qkv, float* o, int R, hipStream_t s) {
-  const int n_pairs = R * 4;
-  const int per_block = 4 * AttnCfg<L>::P;
-  const size_t lds = 4 * (size_t)AttnCfg<L>::TILE * sizeof(float);
-  hipLaunchKernelGGL(attn_fwd_kernel<L>, dim3((n_pairs + per_block - 1) / per_block), dim3(256), lds, s, qkv, o, n_pairs);
-  RAMP_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-template <int L> static int attn_bwd_launch(const float* qkv, const float* dout, float* dqkv, int R, hipStream_t s) {
-  const int n_pairs = R * 4;
-  const int per_block = 4 * AttnCfg<L>::P;
-  const size_t lds = 4 * (size_t)(AttnCfg<L>::TILE + AttnCfg<L>::P * L * (L + 1)) * sizeof(float);  // <= 132 KB at L = 64
-  hipLaunchKernelGGL(attn_bwd_kernel<L>, dim3((n_pairs + per_block - 1) / per_block), dim3(256), lds, s, qkv, dout, dqkv,
-                     n_pairs);
-  RAMP_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
-template <int L> static int attn_set_attr() {
-  const size_t f = 4 * (size_t)AttnCfg<L>::TILE * sizeof(float);
-  const size_t b = 4 * (size_t)(AttnCfg<L>::TILE + AttnCfg<L>::P * L * (L + 1)) * sizeof(float);
-  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<L>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)f));
-  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<L>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
-  return 0;
-}
-int init_attention_attributes() {
-  if (int e = attn_set_attr<6>()) return e;
-  if (int e = attn_set_attr<8>()) return e;
-  if (int e = attn_set_attr<12>()) return e;
-  if (int e = attn_set_attr<16>()) return e;
-  if (int e = attn_set_attr<24>()) return e;
-  if (int e = attn_set_attr<32>()) return e;
-  if (int e = attn_set_attr<48>()) return e;
-  return attn_set_attr<64>();
-}
-
-#define RAMP_ATTN_DISPATCH(FN, ...)                      \
-  switch (L) {                                           \
-    case 6: return FN<6>(__VA_ARGS__);                   \
-    case 8: return FN<8>(__VA_ARGS__);                   \
-    case 12: return FN<12>(__VA_ARGS__);                 \
-    case 16: return FN<16>(__VA_ARGS__);                 \
-    case 24: return FN<24>(__VA_ARGS__);                 \
-    case 32: return FN<32>(__VA_ARGS__);                 \
-    case 48: return FN<48>(__VA_ARGS__);                 \
-    case 64: return FN<64>(__VA_ARGS__);                 \
-    default: break;                                      \
-  }
-
-int launch_attn_fwd(const float* qkv, float* o, int R, int L, hipStream_t s) {
-  RAMP_REQUIRE(R > 0, "empty attention");
-  RAMP_ATTN_DISPATCH(attn_fwd_launch, qkv, o, R, s)
-  RAMP_REQUIRE(false, "attention kernel instantiated for L in {6,8,12,16,24,32,48,64} only");
-}
-int launch_attn_bwd(const float* qkv, const float* dout, float* dqkv, int R, int L, hipStream_t s) {
-  RAMP_REQUIRE(R > 0, "empty attention");
-  RAMP_ATTN_DISPATCH(attn_bwd_launch, qkv, dout, dqkv, R, s)
-  RAMP_REQUIRE(false, "attention kernel instantiated for L in {6,8,12,16,24,32,48,64} only");
 }
 
 // ------------------------------------------------------------------------------------------
