@@ -47,7 +47,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_model(B, device):
+def build_model(B, device, gemm_mode="default"):
     import torch
     from ramp_amd import synth
     from ramp_amd.models import StaticGaussianDiffusionModel, TemporalUnetInference
@@ -56,7 +56,7 @@ def build_model(B, device):
     sp = make_unet_spec(4, 48)
     sd = synth.make_unet_state_dict(sp, seed=0)
     unet = TemporalUnetInference(n_support_points=48, state_dim=4, unet_input_dim=32, dim_mults=(1, 2, 4, 8),
-                                 max_rows=2 * B)
+                                 max_rows=2 * B, gemm_mode=gemm_mode)
     load_numpy_state_dict(unet, sd)
     dm = StaticGaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=25,
                                       predict_epsilon=True, compose=False, use_apf=True, sampler="ddpm",
@@ -168,6 +168,8 @@ def main():
         "metric": "sampled trajectories/sec (H=48, T=25)", "value": value, "unit": "trajectories/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "gemm_mode": "bf16x6: every fp32 operand split into 3 bf16 planes, 6 bf16 MFMA products accumulated in fp32 "
+                     "(fp32-level accuracy, parity tests run in this mode); the exact fp32-MFMA mode is timed below",
         "config": {"workload": "BASELINE configs[1]: Maze2D static DDPM, B=4096 trajectories/GPU x 2 CFG rows, "
                                "H=48, S=4, T=25, 1024-pt cloud, APF forward_t>20, hipGraph replay",
                    "trajectories_per_gpu": B, "horizon": 48, "state_dim": 4, "n_diffusion_steps": 25,
@@ -185,7 +187,10 @@ def main():
         result["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-            "kernel": "ramp::gemm_kernel<*> (fp32 v_mfma_f32_32x32x2: linears + k5/k1 convs, fwd and dX)",
+            "kernel": "ramp::gemm_x6_kernel<*> + gemm_kernel<*> (linears + k5/k1/stride-2 convs, fwd and dX)",
+            "peak_note": "peak = fp32 matrix peak (the arithmetic contract is fp32); the bf16x6 kernel executes 6 bf16 "
+                         "MFMA products per fp32 product, i.e. 6x the algorithmic FLOPs against the 2500 TFLOP/s bf16 peak",
+            "executed_bf16_tflops": 6 * achieved, "frac_of_bf16_peak": 6 * achieved / 2500.0,
             "launches_per_step": g["launches"], "avg_launch_us": g["ms"] * 1e3 / max(g["launches"], 1),
             "algorithmic_gflop_per_launch": g["flops"] / max(g["launches"], 1) / 1e9,
             "share_of_kernel_time": g["ms"] / total_ms,
@@ -193,6 +198,18 @@ def main():
         }
     elif rank == 0:
         result["roofline"] = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # the same job with exact fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs, one step, for reference
+        del dm
+        torch.cuda.empty_cache()
+        dm2, _ = build_model(B, device, gemm_mode="fp32")
+        run_job(dm2, B, cloud, hard_conds, 1)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        run_job(dm2, B, cloud, hard_conds, 1)
+        torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
+        result["fp32_mfma_mode"] = {"value": B / dt2, "unit": "trajectories/s", "ms_per_step": dt2 * 1e3,
+                                    "e2e_frac_of_fp32_mfma_peak": B * 2 * 25 * FLOP_PER_ROW_EVAL / dt2 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        del dm2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sd, cloud_np, args.cpu_sample)
     elif rank == 0:

@@ -11,7 +11,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libramp_hip.so")
 SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "sampler.hip", "engine.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# default GEMM mode 1 = bf16x6 split on the bf16 matrix cores (fp32-accurate, see gemm.hip); 0 = exact fp32 MFMA
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DRAMP_DEFAULT_GEMM_MODE=1"]
 # sampler.hip mirrors the reference's elementwise fp32 expressions rounding for rounding: hipcc's default
 # -ffp-contract=fast would fuse a*b - c*d into an FMA (HIP's __fmul_rn is a plain multiply), so it is off there.
 EXTRA_FLAGS = {"sampler.hip": ["-ffp-contract=off"]}

@@ -298,8 +298,9 @@ void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 // v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate) replace eight v_mfma_f32_32x32x2_f32: 2.7x less matrix-core
 // time at fp32-level accuracy.  Weights are split once at load (planes [3][taps][N][K] bf16); activations are
 // split while they are staged into LDS (once per element, by the staging thread).
-// Single LDS stage (3 A planes + 3 B planes, 80-byte padded rows, conflict-free ds_read_b128), two blocks per
-// CU; the next slab always waits in registers (global loads in flight during the MFMAs and the epilogue).
+// Single LDS stage (3 A planes + 3 B planes; rows of 64 bytes whose four 16-byte slots are XOR-swizzled with
+// (row >> 2) & 3, which makes the b64 / b128 staging writes and the ds_read_b128 fragment reads conflict-free),
+// two blocks per CU; the next slab always waits in registers (global loads in flight during the MFMAs and the epilogue).
 // =================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -307,7 +308,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int XLD = 40;          // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
+constexpr int XLD = 32;          // bf16 elements per LDS row (64 bytes, unpadded; 16-byte slots XOR-swizzled by (row >> 2) & 3)
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
@@ -442,7 +443,8 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
     for (int i = 0; i < AI; ++i) {
       u32x2 p1, p2, p3;
       split3(ra[i], p1, p2, p3);
-      const int off = (r0 + 32 * i) * XLD + c4 * 4;
+      const int rowa = r0 + 32 * i;
+      const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
       *reinterpret_cast<u32x2*>(Ax + off) = p1;
       *reinterpret_cast<u32x2*>(Ax + PLANE + off) = p2;
       *reinterpret_cast<u32x2*>(Ax + 2 * PLANE + off) = p3;
@@ -451,7 +453,7 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int i = 0; i < BI; ++i)
-        *reinterpret_cast<u32x4*>(Bx + p * PLANE + (br + 64 * i) * XLD + bq * 8) = rb[p][i];
+        *reinterpret_cast<u32x4*>(Bx + p * PLANE + (br + 64 * i) * XLD + (((bq ^ ((br + 64 * i) >> 2)) & 3) << 3)) = rb[p][i];
   };
   auto advance_loader = [&]() {
     if (++ld_it == total) {
@@ -461,8 +463,10 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   };
 
   const int r = lane & 31, h = lane >> 5;
-  const int arow = (wm * 64 + r) * XLD + h * 8;
-  const int brow = (wn * 64 + r) * XLD + h * 8;
+  // fragment of k-step s2: logical slot 2 s2 + h of row (base + 32 mi + r); (row >> 2) & 3 == (r >> 2) & 3
+  const int arow = (wm * 64 + r) * XLD;
+  const int brow = (wn * 64 + r) * XLD;
+  const int sw = (r >> 2) & 3;
 
   setup_rows(ld_tile);
   load_tile();
@@ -481,32 +485,29 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
       __syncthreads();
       advance_loader();
       load_tile();                       // next slab -> registers, in flight during the MFMAs below
+      bf16x8 av[2][3][MI], bv[2][3][NI];          // all fragments of the slab first: one exposed LDS latency
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 av[3][MI], bv[3][NI];
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-            av[p][mi] = *reinterpret_cast<const bf16x8*>(Ax + p * PLANE + arow + mi * 32 * XLD + s2 * 16);
+            av[s2][p][mi] = *reinterpret_cast<const bf16x8*>(Ax + p * PLANE + arow + mi * 32 * XLD + (((2 * s2 + h) ^ sw) << 3));
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            bv[p][ni] = *reinterpret_cast<const bf16x8*>(Bx + p * PLANE + brow + ni * 32 * XLD + s2 * 16);
+            bv[s2][p][ni] = *reinterpret_cast<const bf16x8*>(Bx + p * PLANE + brow + ni * 32 * XLD + (((2 * s2 + h) ^ sw) << 3));
         }
+      // small terms first; consecutive MFMAs hit different accumulators
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            f32x16 c = acc[mi][ni];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][mi], bv[0][ni], c, 0, 0, 0);   // small terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[2][ni], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][mi], bv[1][ni], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][mi], bv[0][ni], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[1][ni], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[0][ni], c, 0, 0, 0);
-            acc[mi][ni] = c;
-          }
-      }
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][PA[term]][mi], bv[s2][PB[term]][ni], acc[mi][ni], 0, 0, 0);
     }
     __syncthreads();                     // every wave is done with the operand planes
     epilogue<WM, WN, MI, NI, EPI, GEN>(a, acc, smem, tile, tiles_n, tid, wm, wn, r, h);

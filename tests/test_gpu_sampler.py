@@ -11,9 +11,9 @@ from util import GOLDEN, NoiseInjector, build_unet, dev, rel, weights
 pytestmark = pytest.mark.gpu
 
 
-def make_static(T, use_apf=False, sampler="ddpm", use_graph=True, max_rows=64):
+def make_static(T, use_apf=False, sampler="ddpm", use_graph=True, max_rows=64, gemm_mode="default"):
     from ramp_amd.models import StaticGaussianDiffusionModel
-    u = build_unet(4, 48, False, max_rows=max_rows)
+    u = build_unet(4, 48, False, max_rows=max_rows, gemm_mode=gemm_mode)
     dm = StaticGaussianDiffusionModel(model=u, variance_schedule="exponential", n_diffusion_steps=T,
                                       predict_epsilon=True, compose=False, use_apf=use_apf, sampler=sampler,
                                       use_graph=use_graph)
@@ -46,6 +46,15 @@ def test_ddpm_chain_free_running(tag, nwn, graph):
     assert err.max() < 1e-4
     assert np.array_equal(chain[:, :, 0], np.broadcast_to(synth.default_hard_conds(4, 48)[0], chain[:, :, 0].shape))
     assert np.array_equal(chain[:, :, 47], np.broadcast_to(synth.default_hard_conds(4, 48)[47], chain[:, :, 47].shape))
+
+
+def test_ddpm_chain_exact_fp32_mfma_mode():
+    """The exact-fp32 MFMA GEMM mode (v_mfma_f32_32x32x2_f32) against the same reference chain."""
+    g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
+    chain, _ = run(make_static(25, gemm_mode="fp32"), g, 4)
+    err = np.abs(chain - g["chain"]).max()
+    print(f"ddpm plain fp32-MFMA mode: max {err:.2e}")
+    assert err < 1e-4
 
 
 def test_graph_replay_is_bitwise_eager_and_repeatable():

@@ -13,12 +13,13 @@ pytestmark = pytest.mark.gpu
 CASES = [("2d_h48", 4, 48, False), ("3d_h48", 6, 48, True), ("3d_h64", 6, 64, True)]
 
 
+@pytest.mark.parametrize("gemm_mode", ["bf16x6", "fp32"])
 @pytest.mark.parametrize("tag,S,H,o3", CASES)
-def test_score_against_reference_fixture(tag, S, H, o3):
+def test_score_against_reference_fixture(tag, S, H, o3, gemm_mode):
     """forward_no_energy, eps and every per-module output / output-gradient tap of the reference
     (UnetInference.py:157-224), through the reference-style forward(x, time, context, obstacle_pts=...)."""
     g = np.load(f"{GOLDEN}/unet{tag}.npz")
-    m = build_unet(S, H, o3, max_rows=8, debug=True)
+    m = build_unet(S, H, o3, max_rows=8, debug=True, gemm_mode=gemm_mode)
     N = g["x"].shape[0]
     x = dev(g["x"]); t = torch.from_numpy(g["t"]).cuda()
     pts = dev(g["cloud"])[None].repeat(N, 1, 1, 1)

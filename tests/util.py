@@ -28,10 +28,11 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def build_unet(S, H, o3, max_rows=64, debug=False):
+def build_unet(S, H, o3, max_rows=64, debug=False, gemm_mode="default"):
     from ramp_amd.models import TemporalUnetInference
     from ramp_amd.unet import load_numpy_state_dict
-    m = TemporalUnetInference(n_support_points=H, state_dim=S, obstacle_3d=o3, max_rows=max_rows, debug_taps=debug)
+    m = TemporalUnetInference(n_support_points=H, state_dim=S, obstacle_3d=o3, max_rows=max_rows, debug_taps=debug,
+                              gemm_mode=gemm_mode)
     load_numpy_state_dict(m, weights(S, H, o3))
     return m.eval().to("cuda")
 
