@@ -44,23 +44,34 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="trajectories in the bounded CPU-baseline sample")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+                    help="BASELINE.json config (1-based): 2 = headline Maze2D B=4096 H=48 T=25 (default); "
+                         "3 = Maze3D B=4096 H=48 T=25 4k-pt cloud; 5 = Maze3D B=8192/GPU H=64 T=50 8k-pt cloud")
     return ap.parse_args()
+
+
+WORKLOADS = {   # S, H, T, 3-D?, cloud (n_obstacles, n_points), use_apf
+    2: dict(S=4, H=48, T=25, o3=False, cloud=(16, 64), apf=True),
+    3: dict(S=6, H=48, T=25, o3=True, cloud=(20, 200), apf=False),
+    5: dict(S=6, H=64, T=50, o3=True, cloud=(40, 200), apf=False),
+}
+WL = WORKLOADS[2]
 
 
 def build_model(B, device, gemm_mode="default"):
     import torch
     from ramp_amd import synth
-    from ramp_amd.models import StaticGaussianDiffusionModel, TemporalUnetInference
+    from ramp_amd.models import GaussianDiffusionModel3d, StaticGaussianDiffusionModel, TemporalUnetInference
     from ramp_amd.spec import make_unet_spec
     from ramp_amd.unet import load_numpy_state_dict
-    sp = make_unet_spec(4, 48)
+    sp = make_unet_spec(WL["S"], WL["H"], obstacle_3d=WL["o3"])
     sd = synth.make_unet_state_dict(sp, seed=0)
-    unet = TemporalUnetInference(n_support_points=48, state_dim=4, unet_input_dim=32, dim_mults=(1, 2, 4, 8),
-                                 max_rows=2 * B, gemm_mode=gemm_mode)
+    unet = TemporalUnetInference(n_support_points=WL["H"], state_dim=WL["S"], unet_input_dim=32, dim_mults=(1, 2, 4, 8),
+                                 obstacle_3d=WL["o3"], max_rows=2 * B, gemm_mode=gemm_mode)
     load_numpy_state_dict(unet, sd)
-    dm = StaticGaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=25,
-                                      predict_epsilon=True, compose=False, use_apf=True, sampler="ddpm",
-                                      use_graph=True)
+    cls = GaussianDiffusionModel3d if WL["o3"] else StaticGaussianDiffusionModel
+    dm = cls(model=unet, variance_schedule="exponential", n_diffusion_steps=WL["T"], predict_epsilon=True,
+             compose=False, use_apf=WL["apf"], sampler="ddpm", use_graph=True)
     dm = dm.eval().to(device)
     return dm, sd
 
@@ -69,7 +80,7 @@ def run_job(dm, B, cloud, hard_conds, world, x_all=None):
     """One step = one run_inference of B trajectories + the final all-gather."""
     import torch
     from ramp_amd import dist as rdist
-    x = dm.run_inference(None, hard_conds, n_samples=B, horizon=48, return_chain=False, traj_normalized=None,
+    x = dm.run_inference(None, hard_conds, n_samples=B, horizon=WL["H"], return_chain=False, traj_normalized=None,
                          obstacle_pts=cloud, sample_fn=None, guide=None, n_guide_steps=1, t_start_guide=7,
                          noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=0)
     if world > 1:
@@ -123,6 +134,10 @@ def main():
     from ramp_amd import dist as rdist
     from ramp_amd import synth
 
+    global WL
+    WL = WORKLOADS[args.config]
+    if args.config == 5 and args.batch == 4096:
+        args.batch = 8192
     rank, world, local = rdist.env_rank()
     if world > 1:
         torch.cuda.set_device(local)
@@ -136,9 +151,9 @@ def main():
     torch.manual_seed(1234 + rank)
 
     dm, sd = build_model(B, device)
-    cloud_np = synth.make_cloud(16, 64, 2, seed=42)                 # 16 x 64 = 1024 points
+    cloud_np = synth.make_cloud(WL["cloud"][0], WL["cloud"][1], 3 if WL["o3"] else 2, seed=42)   # config 2: 16 x 64 = 1024 pts
     cloud = torch.from_numpy(cloud_np).to(device)
-    hard_conds = {k: torch.from_numpy(v).to(device) for k, v in synth.default_hard_conds(4, 48).items()}
+    hard_conds = {k: torch.from_numpy(v).to(device) for k, v in synth.default_hard_conds(WL["S"], WL["H"]).items()}
 
     def barrier():
         torch.cuda.synchronize()
@@ -158,22 +173,25 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert out.shape == (B * world, 48, 4) and bool(torch.isfinite(out).all())
+    assert out.shape == (B * world, WL["H"], WL["S"]) and bool(torch.isfinite(out).all())
 
     value = world * B * args.steps / dt
     ms_per_step = dt / args.steps * 1e3
-    e2e_tflops_per_gpu = B * 2 * 25 * FLOP_PER_ROW_EVAL / (dt / args.steps) / 1e12
+    flop_row = {2: 1.324e9, 3: 1.323e9, 5: 1.773e9}[args.config]          # SURVEY.md §8(d), reduced count
+    e2e_tflops_per_gpu = B * 2 * WL["T"] * flop_row / (dt / args.steps) / 1e12
 
     result = {
-        "metric": "sampled trajectories/sec (H=48, T=25)", "value": value, "unit": "trajectories/s",
+        "metric": f"sampled trajectories/sec (H={WL['H']}, T={WL['T']})", "value": value, "unit": "trajectories/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "gemm_mode": "bf16x6: every fp32 operand split into 3 bf16 planes, 6 bf16 MFMA products accumulated in fp32 "
                      "(fp32-level accuracy, parity tests run in this mode); the exact fp32-MFMA mode is timed below",
-        "config": {"workload": "BASELINE configs[1]: Maze2D static DDPM, B=4096 trajectories/GPU x 2 CFG rows, "
-                               "H=48, S=4, T=25, 1024-pt cloud, APF forward_t>20, hipGraph replay",
-                   "trajectories_per_gpu": B, "horizon": 48, "state_dim": 4, "n_diffusion_steps": 25,
-                   "cloud_points": 1024, "sharding": f"sample-batch x{world}, final all-gather only"},
+        "config": {"workload": {2: "BASELINE configs[1]: Maze2D static DDPM, B=4096 trajectories/GPU x 2 CFG rows, "
+                                   "H=48, S=4, T=25, 1024-pt cloud, APF forward_t>20, hipGraph replay",
+                                3: "BASELINE configs[2]: Maze3D DDPM (w=5.75), B=4096/GPU x 2 CFG rows, H=48, S=6, T=25, 4000-pt cloud",
+                                5: "BASELINE configs[4]: Maze3D DDPM, B=8192/GPU x 2 CFG rows, H=64, S=6, T=50, 8000-pt cloud"}[args.config],
+                   "trajectories_per_gpu": B, "horizon": WL["H"], "state_dim": WL["S"], "n_diffusion_steps": WL["T"],
+                   "cloud_points": WL["cloud"][0] * WL["cloud"][1], "sharding": f"sample-batch x{world}, final all-gather only"},
         "e2e_algorithmic_tflops_per_gpu": e2e_tflops_per_gpu,
         "e2e_frac_of_fp32_mfma_peak": e2e_tflops_per_gpu / PEAK_FP32_MFMA_TFLOPS,
         "workspace_gb": dm.model.workspace_bytes() / 2 ** 30,
@@ -198,7 +216,7 @@ def main():
         }
     elif rank == 0:
         result["roofline"] = None
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline and args.config == 2:
         # the same job with exact fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs, one step, for reference
         del dm
         torch.cuda.empty_cache()
@@ -210,7 +228,7 @@ def main():
         result["fp32_mfma_mode"] = {"value": B / dt2, "unit": "trajectories/s", "ms_per_step": dt2 * 1e3,
                                     "e2e_frac_of_fp32_mfma_peak": B * 2 * 25 * FLOP_PER_ROW_EVAL / dt2 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         del dm2
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
         result["cpu_baseline"] = cpu_baseline(sd, cloud_np, args.cpu_sample)
     elif rank == 0:
         result["cpu_baseline"] = None

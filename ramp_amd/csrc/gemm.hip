@@ -11,8 +11,8 @@
 //    staged global -> registers -> LDS with one 16-byte pad per row, so every lane feeds four
 //    MFMAs from a single conflict-free ds_read_b128 per operand (the k order inside a 32-chunk is
 //    permuted identically for A and B).  Double-buffered LDS, one barrier per K-tile.
-//  * PERSISTENT blocks: each block walks a contiguous run of logical tiles (XCD-aware: the runs of
-//    one XCD are adjacent, so the N-tiles of one M-tile hit the same L2).  The global loads of the
+//  * PERSISTENT blocks: each XCD owns a contiguous run of logical tiles (N fastest) and its resident blocks
+//    walk it interleaved, so the N-tiles of one M-tile are in flight together and hit the same L2.  The global loads of the
 //    next tile's first K-slab are issued before the current tile's epilogue and parked in
 //    registers, so the short-K shapes of this network (K = 256) do not pay a cold prologue per tile.
 //  * Epilogue through LDS: accumulators are transposed in LDS and leave as coalesced float4 rows;
@@ -147,8 +147,10 @@ void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   const int bid = blockIdx.x, nb = gridDim.x;          // nb is a multiple of 8
   const int xcd = bid & 7, slot = bid >> 3, bpx = nb >> 3;
   const long xlo = (long)xcd * n_tiles / 8, xhi = (long)(xcd + 1) * n_tiles / 8;
-  const int t_begin = (int)(xlo + (xhi - xlo) * slot / bpx);
-  const int t_end = (int)(xlo + (xhi - xlo) * (slot + 1) / bpx);
+  // Interleaved assignment inside the XCD's run: at any moment the resident blocks of one XCD work on
+  // bpx CONSECUTIVE logical tiles (= a few M-tiles x all their N-tiles), so the A tiles they share and the
+  // weight panel stay in that XCD's 4 MiB L2 (a contiguous run per block re-fetched A once per N-tile).
+  const int t_begin = (int)xlo + slot, t_end = (int)xhi, t_step = bpx;
   if (t_begin >= t_end) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -232,7 +234,7 @@ void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   auto advance_loader = [&]() {          // after the last tile the loader idles on it (loads are harmless)
     if (++ld_it == total) {
       ld_it = 0;
-      if (ld_tile + 1 < t_end) { ++ld_tile; setup_rows(ld_tile); }
+      if (ld_tile + t_step < t_end) { ld_tile += t_step; setup_rows(ld_tile); }
     }
   };
 
@@ -246,7 +248,7 @@ void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   advance_loader();
   __syncthreads();
   int st = 0;
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -285,7 +287,7 @@ void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 
     epilogue<WM, WN, MI, NI, EPI, GEN>(a, acc, smem, tile, tiles_n, tid, wm, wn, r, h);
     __syncthreads();
-    if (tile + 1 < t_end) { store_tile(st); advance_loader(); __syncthreads(); }
+    if (tile + t_step < t_end) { store_tile(st); advance_loader(); __syncthreads(); }
   }
 }
 
@@ -367,8 +369,10 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   const int bid = blockIdx.x, nb = gridDim.x;
   const int xcd = bid & 7, slot = bid >> 3, bpx = nb >> 3;
   const long xlo = (long)xcd * n_tiles / 8, xhi = (long)(xcd + 1) * n_tiles / 8;
-  const int t_begin = (int)(xlo + (xhi - xlo) * slot / bpx);
-  const int t_end = (int)(xlo + (xhi - xlo) * (slot + 1) / bpx);
+  // Interleaved assignment inside the XCD's run: at any moment the resident blocks of one XCD work on
+  // bpx CONSECUTIVE logical tiles (= a few M-tiles x all their N-tiles), so the A tiles they share and the
+  // weight panel stay in that XCD's 4 MiB L2 (a contiguous run per block re-fetched A once per N-tile).
+  const int t_begin = (int)xlo + slot, t_end = (int)xhi, t_step = bpx;
   if (t_begin >= t_end) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -458,7 +462,7 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   auto advance_loader = [&]() {
     if (++ld_it == total) {
       ld_it = 0;
-      if (ld_tile + 1 < t_end) { ++ld_tile; setup_rows(ld_tile); }
+      if (ld_tile + t_step < t_end) { ld_tile += t_step; setup_rows(ld_tile); }
     }
   };
 
@@ -470,7 +474,7 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 
   setup_rows(ld_tile);
   load_tile();
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
