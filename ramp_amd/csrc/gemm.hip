@@ -259,6 +259,7 @@ void gemm_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 
     for (int it = 0; it < total; ++it) {
       load_tile();                       // next slab (of this or the next tile) into registers
+      __builtin_amdgcn_sched_barrier(0); // keep the global loads ahead of the MFMA block
       const float* As = As0 + st * STAGE;
       const float* Bs = Bs0 + st * STAGE;
       f32x4 av[4][MI], bv[4][NI];
@@ -489,6 +490,7 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
       __syncthreads();
       advance_loader();
       load_tile();                       // next slab -> registers, in flight during the MFMAs below
+      __builtin_amdgcn_sched_barrier(0); // keep the global loads AHEAD of the MFMA block (hipcc sinks them to its end)
       bf16x8 av[2][3][MI], bv[2][3][NI];          // all fragments of the slab first: one exposed LDS latency
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
