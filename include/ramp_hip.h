@@ -126,6 +126,14 @@ int ramp_sample(ramp_ctx* ctx, const ramp_sample_params* p, const float* noise, 
 /* ---- kernel-level entry points (same kernels the loops use; exported for parity tests) ---- */
 /* avoidance(trajectories, ObstacleField(cloud, thr), window, strength) in place (APFhelper.py:37-104) */
 int ramp_apf(float* traj, int32_t B, int32_t H, int32_t S, const ramp_apf_params* p, void* stream);
+/* per-trajectory APF of the dynamic planner: avoidance(trajectory, obstacle_field, is_dynamic, ...)
+ * (APFhelper_dynamic.py:107-142) for B trajectories at once.  points: device (P,2) FLOAT64 (the reference's numpy
+ * clouds).  window >= 0: static pass (pushes waypoints [ci-w, min(H-1, ci+w)) around the waypoint ci nearest to the
+ * cloud, force length strength*exp(-d/thr_force), hit iff d < thr_query); window < 0: pursuer pass over waypoints
+ * [0, affected) with the 0.9/0.1 avoid/goal blend (goal: device (S) or NULL).  enable: device (B) int32 or NULL. */
+int ramp_apf_dynamic(float* traj, int32_t B, int32_t H, int32_t S, const double* points, int32_t n_points,
+                     double thr_query, double thr_force, double strength, int32_t window, int32_t affected,
+                     const float* goal, const int32_t* enable, void* stream);
 /* apply_hard_conditioning (sample_functions.py:5-10); idx host, val device (n,B,S) */
 int ramp_hard_cond(float* x, int32_t B, int32_t H, int32_t S, int32_t n, const int32_t* idx_host,
                    const float* val, void* stream);
@@ -137,6 +145,10 @@ int ramp_traj_costs(const float* traj, int32_t B, int32_t H, int32_t S, const fl
 int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32_t n_rp, double w0, double w1,
                   float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip,
                   float* x0_out, float* mean_out, float* ecomb_out, void* stream);
+/* the DDIM update of ddim_p_sample given x0 (diffusion_model_static.py:321-333 / _dynamic.py:436-447), eta = 0:
+ * x_out = sqrt_a_prev * x0 + dir_coef * (x - sqrt_a_t * x0) / sqrt_1m_a_t */
+int ramp_ddim_finish(const float* x, const float* x0, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
+                     float dir_coef, float* x_out, int32_t B, int32_t H, int32_t S, void* stream);
 /* generic fp32 MFMA GEMM with taps: C[M,N] = sum_tap shift(A)[M,K] W[tap][N][K]^T + bias + resid */
 int ramp_op_gemm(const float* A, const float* W, const float* bias, const float* resid, float* C,
                  int32_t M, int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step,

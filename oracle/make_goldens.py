@@ -41,7 +41,8 @@ from ramp_amd.spec import make_unet_spec, unet_param_shapes, SCHEDULE_BUFFERS  #
 
 with contextlib.redirect_stdout(io.StringIO()):
     from mpd.models import (TemporalUnetInference, UNET_DIM_MULTS, StaticGaussianDiffusionModel,  # noqa: E402
-                            GaussianDiffusionModel3d)
+                            GaussianDiffusionModel3d, DynamicGaussianDiffusionModel)
+    from mpd.models.diffusion_models import APFhelper_dynamic as ref_apf_dyn  # noqa: E402
     from mpd.models.diffusion_models.sample_functions import ddpm_sample_fn  # noqa: E402
     from mpd.models.diffusion_models.APFhelper import ObstacleField, avoidance  # noqa: E402
     from mpd.models.diffusion_models import cost as ref_cost  # noqa: E402
@@ -318,7 +319,61 @@ def gen_cost():
     save("cost_cases.npz", **arrs)
 
 
+def gen_dynamic(m2, sp2):
+    """Dynamic (pursuit-evasion) wrapper: CFG with the blocked row layout (w = 2.5; reference quirk Q1: the net
+    masks odd GLOBAL rows) for even and odd batch sizes, and the per-trajectory dynamic APF (static + pursuer)."""
+    arrs = {}
+    cloud = synth.make_cloud(6, 64, 2, seed=42)
+    dm = quiet(DynamicGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=100,
+               predict_epsilon=True)
+    dm.eval()
+    for B in (4, 3):
+        x = torch.from_numpy(synth.make_noise((B, 48, 4), seed=30 + B))
+        t = torch.full((B,), 40, dtype=torch.long)
+        pts = torch.from_numpy(cloud)[None].repeat(B, 1, 1, 1)
+        m2.reset_cache()
+        mean, _, _, x0, ec = dm.p_mean_variance(x, None, None, t, traj_normalized=torch.zeros(B, 48, 4), obstacle_pts=pts)
+        arrs[f"pmv{B}/x"] = x.numpy(); arrs[f"pmv{B}/ecomb"] = ec.detach().numpy()
+        arrs[f"pmv{B}/x0"] = x0.detach().numpy(); arrs[f"pmv{B}/mean"] = mean.detach().numpy()
+    arrs["cloud"] = cloud
+    # dynamic APF: seeded numpy RNG so the generated point sets can be captured
+    np.random.seed(7)
+    centers = np.array([[-0.3, 0.2], [0.35, -0.25], [0.1, 0.55], [-0.5, -0.5]])
+    sizes = np.full((4, 2), 0.26)
+    pursuer = np.array([0.05, 0.0])
+    field = ref_apf_dyn.ObstacleField(centers, sizes, lambda t, sp, rg=False, bi=None: (pursuer, 0.1), 64,
+                                      distance_threshold=0.2, distance_threshold_pred=0.5)
+    field.update_dynamic(0, None)
+    arrs["apf/static_points"] = field.static_obstacle_points
+    arrs["apf/dynamic_points"] = np.asarray(field.dynamic_kdtree.data)
+    g = np.random.Generator(np.random.PCG64(17))
+    lin = np.linspace(-0.8, 0.8, 48, dtype=np.float32)
+    trajs = np.zeros((4, 48, 4), np.float32)
+    for b in range(4):
+        trajs[b, :, 0] = lin + 0.03 * g.standard_normal(48).astype(np.float32)
+        trajs[b, :, 1] = (0.9 - 0.45 * b) * lin + 0.03 * g.standard_normal(48).astype(np.float32)
+    trajs[3] += 5.0                                            # far from everything: nothing may change
+    goal = torch.tensor([0.8, 0.8, 0.0, 0.0])
+    arrs["apf/traj"] = trajs; arrs["apf/goal"] = goal.numpy()
+    out_s = np.stack([ref_apf_dyn.avoidance(torch.from_numpy(trajs[b].copy()), field, is_dynamic=False,
+                                            avoidance_window=8, avoidance_strength=0.15,
+                                            avoidance_strength_pred=0.15).numpy() for b in range(4)])
+    out_d = np.stack([ref_apf_dyn.avoidance(torch.from_numpy(trajs[b].copy()), field, is_dynamic=True,
+                                            avoidance_window=5, avoidance_strength=0.15, avoidance_strength_pred=0.15,
+                                            affected_states=48, goal_state=goal).numpy() for b in range(4)])
+    arrs["apf/out_static"] = out_s; arrs["apf/out_dynamic"] = out_d
+    arrs["apf/params"] = np.array([0.2, 0.5, 0.15, 0.15, 8, 5], np.float64)   # thr_static, thr_pred, strengths, windows
+    print(f"    dynamic apf: static changed {(out_s != trajs).sum()}, dynamic changed {(out_d != trajs).sum()}")
+    # sm() velocity smoothing
+    s1 = torch.from_numpy(synth.make_noise((5, 4), seed=41)); s2 = torch.from_numpy(synth.make_noise((5, 4), seed=42))
+    arrs["sm/s1"] = s1.numpy(); arrs["sm/s2"] = s2.numpy(); arrs["sm/out"] = dm.sm(s1, s2).numpy()
+    save("dynamic_cases.npz", **arrs)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "dynamic":
+        m2, sp2, _ = build_unet(4, 48, False)
+        gen_dynamic(m2, sp2); return
     if len(sys.argv) > 1 and sys.argv[1] == "cost":
         gen_cost(); return
     if len(sys.argv) > 1 and sys.argv[1] == "apf":
@@ -337,6 +392,7 @@ def main():
     print("cost"); gen_cost()
     print("chains 2-D"); gen_chains(m2, sp2)
     print("chain 3-D"); gen_chain3d(m3, sp3)
+    print("dynamic"); gen_dynamic(m2, sp2)
     print("done")
 
 

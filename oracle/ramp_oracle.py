@@ -606,6 +606,62 @@ def apf_avoidance(traj: np.ndarray, cloud: np.ndarray, thr: float, strength: flo
     return out
 
 
+def apf_dynamic_avoidance(traj: np.ndarray, points: np.ndarray, thr_query: float, thr_force: float, strength: float,
+                          window: Optional[int], affected: Optional[int] = None,
+                          goal: Optional[np.ndarray] = None) -> np.ndarray:
+    """Per-trajectory APF of the dynamic planner (APFhelper_dynamic.py:107-142), one trajectory (H,S) float32.
+
+    points (P,2) float64.  ``window`` = static pass: only waypoints [ci - w, min(H-1, ci + w)) around the waypoint ci
+    closest to the cloud are pushed; ``window`` None = pursuer pass over waypoints [0, affected) with the
+    0.9 / 0.1 avoid / goal direction blend.  Distances, directions and forces are float64 (the reference subtracts a
+    float64 numpy point from the float32 waypoint), the update rounds to float32; the force length uses the
+    STATIC threshold in both passes (``obstacle_field.distance_threshold``, APFhelper_dynamic.py:140)."""
+    H = traj.shape[0]
+    n_q = H if window is not None else min(affected if affected is not None else H, H)
+    q = traj[:n_q, :2].astype(np.float64)
+    d2 = ((q[:, None, :] - points[None, :, :]) ** 2).sum(-1)
+    idx = d2.argmin(axis=1)
+    dist = np.sqrt(d2[np.arange(n_q), idx])
+    hit = dist < thr_query
+    dist_q = np.where(hit, dist, np.inf)
+    ci = int(np.argmin(dist_q))
+    if window is not None:
+        lo, hi = max(0, ci - window), min(H - 1, ci + window)
+    else:
+        lo, hi = 0, n_q
+    out = traj.copy()
+    for i in range(lo, hi):
+        if not hit[i]:
+            continue
+        ad = traj[i, :2].astype(np.float64) - points[idx[i]]
+        ad = ad / (np.sqrt((ad * ad).sum()) + 1e-8)
+        if goal is not None:
+            gd = (goal[:2] - traj[i, :2]).astype(np.float32)
+            gd = gd / (np.sqrt((gd * gd).sum(dtype=np.float32)) + np.float32(1e-8))
+            cd = 0.9 * ad + 0.1 * gd.astype(np.float64)
+            cd = cd / (np.sqrt((cd * cd).sum()) + 1e-8)
+        else:
+            cd = ad
+        force = strength * np.exp(-dist[i] / thr_force)
+        out[i, :2] = (traj[i, :2].astype(np.float64) + force * cd).astype(traj.dtype)
+    return out
+
+
+def sm_smooth(s1: np.ndarray, s2: np.ndarray, dt=0.1, num_steps=3, max_vel=0.8) -> np.ndarray:
+    """Velocity-limited straight-line smoothing between two states (diffusion_model_dynamic.py:192-214)."""
+    f = s1.dtype.type
+    delta = s2[:, :2] - s1[:, :2]
+    dist = np.sqrt((delta * delta).sum(1, keepdims=True))
+    direc = np.where(dist > 1e-6, delta / np.where(dist > 1e-6, dist, 1), 0).astype(s1.dtype)
+    desired = delta / f(num_steps * dt)
+    mag = np.sqrt((desired * desired).sum(1, keepdims=True))
+    base = np.where(mag > max_vel, direc * f(max_vel), desired).astype(s1.dtype)
+    t = (np.arange(1, num_steps + 1, dtype=s1.dtype) * f(dt)).reshape(1, num_steps, 1)
+    pos = s1[:, None, :2] + t * base[:, None, :]
+    vel = np.broadcast_to(base[:, None, :], pos.shape)
+    return np.concatenate([pos, vel], axis=-1).astype(s1.dtype)
+
+
 def collision_mask(traj: np.ndarray, cloud: np.ndarray, thr: float) -> np.ndarray:
     """cost.py:25-54: mask_b = any_{h,p} ||xy_bh - p|| < thr."""
     xy = traj[..., :2]
@@ -678,6 +734,18 @@ class SamplerOracle:
         out = self.unet.score(x2, tt, lat).reshape(B, 2, *x.shape[1:])
         w = self.dt(self.w)
         return ((1 + w) * out[:, 0] - w * out[:, 1]).astype(self.dt)
+
+    def eps_cfg_dynamic_compat(self, x: np.ndarray, t: int, latent: np.ndarray) -> np.ndarray:
+        """The dynamic wrapper's CFG exactly as the reference evaluates it: rows are laid
+        out blocked [x_0..x_{B-1}, x_0..x_{B-1}] (diffusion_model_dynamic.py:129-147) while the net zeroes the
+        latent of every odd GLOBAL row (UnetInference.py:192-195); e_b = (1+w) out[b] - w out[B+b]."""
+        B = x.shape[0]
+        x2 = np.concatenate([x, x], axis=0)
+        lat = np.tile(latent[None, :], (2 * B, 1)).astype(self.dt)
+        lat[1::2] = 0
+        out = self.unet.score(x2, np.full((2 * B,), t, np.int64), lat)
+        w = self.dt(self.w)
+        return ((1 + w) * out[:B] - w * out[B:]).astype(self.dt)
 
     def x0_mean(self, x, e, t):
         s = self.sched

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "ramp_sample": (C.c_int, [C.c_void_p, C.POINTER(RampSampleParams), C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p]),
     "ramp_apf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RampApfParams), C.c_void_p]),
+    "ramp_apf_dynamic": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
+                                   C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ramp_hard_cond": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p,
                                  C.c_void_p]),
     "ramp_traj_costs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
@@ -61,6 +63,8 @@ PROTOTYPES = {
     "ramp_cfg_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
+    "ramp_ddim_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ramp_op_gemm": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]),
     "ramp_op_groupnorm": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p]),
     "ramp_op_groupnorm_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p]),

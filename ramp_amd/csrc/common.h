@@ -154,6 +154,17 @@ struct ApfArgs {
   double thr = 0, strength = 0;
 };
 int launch_apf(const ApfArgs& a, hipStream_t s);
+struct ApfDynArgs {
+  float* traj = nullptr;          // (B,H,S) in place (xy only)
+  const double* points = nullptr; // (P,2) float64
+  const float* goal = nullptr;    // (S) goal state for the pursuer pass, or null
+  const int* enable = nullptr;    // (B) per-trajectory switch, or null = all
+  int B = 0, H = 0, S = 0, P = 0;
+  int window = -1;                // >= 0: static pass around the closest waypoint; < 0: waypoints [0, affected)
+  int affected = 0;
+  double thr_query = 0, thr_force = 0, strength = 0;
+};
+int launch_apf_dynamic(const ApfDynArgs& a, hipStream_t s);
 // mask[b] = any_{h,p} ||xy - p|| < thr ; plen[b], smooth[b]
 int launch_traj_costs(const float* traj, const float* cloud, int B, int H, int S, int P, float thr,
                       int* mask, float* plen, float* smooth, hipStream_t s);

@@ -1012,6 +1012,16 @@ int ramp_apf(float* traj, int32_t B, int32_t H, int32_t S, const ramp_apf_params
   return rc;
 }
 
+int ramp_apf_dynamic(float* traj, int32_t B, int32_t H, int32_t S, const double* points, int32_t n_points,
+                     double thr_query, double thr_force, double strength, int32_t window, int32_t affected,
+                     const float* goal, const int32_t* enable, void* stream) {
+  RAMP_REQUIRE(traj && points, "null argument");
+  ApfDynArgs a; a.traj = traj; a.points = points; a.goal = goal; a.enable = enable; a.B = B; a.H = H; a.S = S;
+  a.P = n_points; a.window = window; a.affected = affected; a.thr_query = thr_query; a.thr_force = thr_force;
+  a.strength = strength;
+  return launch_apf_dynamic(a, as_stream(stream));
+}
+
 int ramp_hard_cond(float* x, int32_t B, int32_t H, int32_t S, int32_t n, const int32_t* idx_host, const float* val,
                    void* stream) {
   RAMP_REQUIRE(x && (n == 0 || (idx_host && val)), "null argument");
@@ -1042,6 +1052,14 @@ int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32
   m.w0p1 = (float)(1.0 + w0); m.sqrt_recip = sqrt_recip; m.sqrt_recipm1 = sqrt_recipm1; m.coef1 = coef1; m.coef2 = coef2;
   m.clip = clip; m.x0 = x0_out; m.mean = mean_out; m.ecomb = ecomb_out;
   return launch_cfg_mean(m, as_stream(stream));
+}
+
+int ramp_ddim_finish(const float* x, const float* x0, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
+                     float dir_coef, float* x_out, int32_t B, int32_t H, int32_t S, void* stream) {
+  RAMP_REQUIRE(x && x0 && x_out, "null argument");
+  HardConds hc;
+  return launch_ddim_finish(x, x0, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, dir_coef, hc, x_out, nullptr, B, H, S,
+                            as_stream(stream));
 }
 
 int ramp_op_gemm(const float* A, const float* W, const float* bias, const float* resid, float* C, int32_t M, int32_t N,

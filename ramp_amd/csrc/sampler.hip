@@ -218,6 +218,83 @@ int launch_apf(const ApfArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Dynamic-planner APF (APFhelper_dynamic.py:107-142), one block per trajectory, points in float64 like the
+// reference's numpy clouds.  window >= 0: static pass, pushes only waypoints [ci - w, min(H-1, ci + w)) around the
+// waypoint ci nearest to the cloud; window < 0: pursuer pass over waypoints [0, affected) with the 0.9 / 0.1
+// avoid / goal blend.  Each waypoint update is independent (no accumulation across waypoints).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void apf_dyn_kernel(ApfDynArgs a) {
+  __shared__ double2 cl[APF_TILE];
+  __shared__ double best_d2[APF_MAXH];
+  __shared__ int best_i[APF_MAXH];
+  __shared__ int s_lo, s_hi;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.enable && !a.enable[b]) return;
+  float* tr = a.traj + (long)b * a.H * a.S;
+  const int nq = a.window >= 0 ? a.H : min(a.affected, a.H);
+  for (int h = tid; h < a.H; h += 256) { best_d2[h] = 1.0e300; best_i[h] = -1; }
+  for (int p0 = 0; p0 < a.P; p0 += APF_TILE) {
+    const int np = min(APF_TILE, a.P - p0);
+    __syncthreads();
+    for (int e = tid; e < np; e += 256) cl[e] = make_double2(a.points[(p0 + e) * 2], a.points[(p0 + e) * 2 + 1]);
+    __syncthreads();
+    for (int h = wave; h < nq; h += 4) {
+      const double qx = (double)tr[h * a.S], qy = (double)tr[h * a.S + 1];
+      double bd = 1.0e300; int bi = -1;
+      for (int e = lane; e < np; e += 64) {
+        const double dx = qx - cl[e].x, dy = qy - cl[e].y;
+        const double d2 = dx * dx + dy * dy;
+        if (d2 < bd) { bd = d2; bi = p0 + e; }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const double od = __shfl_xor(bd, m);
+        const int oi = __shfl_xor(bi, m);
+        if (od < bd || (od == bd && oi >= 0 && (bi < 0 || oi < bi))) { bd = od; bi = oi; }
+      }
+      if (lane == 0 && bi >= 0 && bd < best_d2[h]) { best_d2[h] = bd; best_i[h] = bi; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double bm = 1.0e300; int ci = 0;                     // np.argmin over distances with inf for misses
+    for (int h = 0; h < nq; ++h) {
+      const double d = sqrt(best_d2[h]);
+      if (best_i[h] >= 0 && d < a.thr_query && d < bm) { bm = d; ci = h; }
+    }
+    if (a.window >= 0) { s_lo = max(0, ci - a.window); s_hi = min(a.H - 1, ci + a.window); }
+    else { s_lo = 0; s_hi = nq; }
+  }
+  __syncthreads();
+  for (int h = s_lo + tid; h < s_hi; h += 256) {
+    const double d = sqrt(best_d2[h]);
+    if (!(best_i[h] >= 0 && d < a.thr_query)) continue;
+    const float tx = tr[h * a.S], ty = tr[h * a.S + 1];
+    double ax = (double)tx - a.points[best_i[h] * 2], ay = (double)ty - a.points[best_i[h] * 2 + 1];
+    const double an = sqrt(ax * ax + ay * ay) + 1e-8;
+    ax /= an; ay /= an;
+    double cx = ax, cy = ay;
+    if (a.goal) {
+      float gx = sub(a.goal[0], tx), gy = sub(a.goal[1], ty);
+      const float gn = add(sqrtf(add(mul(gx, gx), mul(gy, gy))), 1e-8f);
+      gx = __fdiv_rn(gx, gn); gy = __fdiv_rn(gy, gn);
+      cx = 0.9 * ax + 0.1 * (double)gx; cy = 0.9 * ay + 0.1 * (double)gy;
+      const double cn = sqrt(cx * cx + cy * cy) + 1e-8;
+      cx /= cn; cy /= cn;
+    }
+    const double force = a.strength * exp(-d / a.thr_force);
+    tr[h * a.S] = (float)((double)tx + force * cx);
+    tr[h * a.S + 1] = (float)((double)ty + force * cy);
+  }
+}
+int launch_apf_dynamic(const ApfDynArgs& a, hipStream_t s) {
+  RAMP_REQUIRE(a.B > 0 && a.H > 0 && a.H <= APF_MAXH && a.S >= 2 && a.P > 0 && a.traj && a.points, "bad dynamic-APF dims");
+  hipLaunchKernelGGL(apf_dyn_kernel, dim3(a.B), dim3(256), 0, s, a);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // trajectory costs: collision mask against the cloud, path length, smoothness (cost.py:3-54)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void traj_costs_kernel(const float* __restrict__ traj, const float* __restrict__ cloud,

@@ -125,7 +125,11 @@ class _GaussianDiffusionBase(nn.Module):
     def _n_rp(self) -> int:
         return 3 if self.compose else 2
 
-    def _prepare_scene(self, obstacle_pts: torch.Tensor):
+    def _row_pattern(self, B):
+        """network-row -> scene-variant pattern (variant 1 = unconditional); rows are [b*n_rp + v]."""
+        return [0, 1]
+
+    def _prepare_scene(self, obstacle_pts: torch.Tensor, B=None):
         """Encode the distinct scene(s) once and hand the variants to the context."""
         m = self.model
         dev = self._device()
@@ -137,7 +141,7 @@ class _GaussianDiffusionBase(nn.Module):
             pattern = [0, 1, 2]
         else:
             lat = torch.cat([m.encode_scene(obstacle_pts), zero])
-            pattern = [0, 1]
+            pattern = self._row_pattern(B)
         m.set_scene(lat, pattern)
         m.cached_batch_size = None          # the compat forward() cache is keyed differently
 
@@ -167,7 +171,7 @@ class _GaussianDiffusionBase(nn.Module):
         H, S = m.n_support_points, self.state_dim
         n_steps = len(steps)
         m.prepare_time_table(self.n_diffusion_steps)
-        self._prepare_scene(obstacle_pts)
+        self._prepare_scene(obstacle_pts, B)
         buf = {k: getattr(self, k).detach().cpu() for k in
                ('alphas_cumprod', 'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod',
                 'posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped')}
@@ -341,9 +345,9 @@ class _GaussianDiffusionBase(nn.Module):
         ti = int(t.reshape(-1)[0])
         self.model.prepare_time_table(self.n_diffusion_steps)
         pts = obstacle_pts
-        if not self.compose and pts.dim() == 4 and pts.shape[0] == 1:
-            pts = pts[0]
-        self._prepare_scene(pts.to(dev))
+        if not self.compose and pts.dim() == 4:
+            pts = pts[0]                    # the loops replicate one cloud per row; one copy is encoded
+        self._prepare_scene(pts.to(dev), B)
         xx = x.detach().to(dev, torch.float32).contiguous()
         n_rp = self._n_rp()
         eps = torch.empty((B * n_rp,) + tuple(x.shape[1:]), device=dev)
@@ -386,3 +390,113 @@ class GaussianDiffusionModel3d(_GaussianDiffusionBase):
     _default_compose = (5.0, 5.0)      # diffusion_model_3d.py:170-171
     _default_ddim = False
     _supports_apf = False
+
+
+class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
+    """Pursuit-evasion wrapper (diffusion_model_dynamic.py:24-680): the pieces on the sampler hot path — CFG
+    (w = 2.5) + x0 + clamp + posterior (``p_mean_variance``), one DDIM step with the per-trajectory static /
+    pursuer APF (``ddim_p_sample``), velocity smoothing ``sm`` and ``q_sample`` re-noising.  The receding-horizon
+    replanning state machine around them (``ddim_p_sample_loop``, :495-624) is SURVEY.md §8(f) "next" row 1.
+
+    ``cfg_mode='reference_compat'`` reproduces the reference's row pairing exactly: it
+    lays rows out blocked [x_0..x_{B-1}, x_0..x_{B-1}] while the net zeroes the latent of every odd GLOBAL row, so
+    for even B even samples get pure eps_cond and odd samples pure eps_uncond, and for odd B odd samples get the
+    inverted combination.  ``cfg_mode='intended'`` is true classifier-free guidance."""
+    _default_cfg_weight = 2.5          # diffusion_model_dynamic.py:157
+    _default_ddim = True               # diffusion_model_dynamic.py:46
+    _supports_apf = False
+
+    def __init__(self, model=None, variance_schedule='exponential', n_diffusion_steps=100, clip_denoised=True,
+                 predict_epsilon=False, loss_type='l2', context_model=None, mask_type=None, traj_len=None,
+                 cfg_mode: str = 'reference_compat', **kwargs):
+        super().__init__(model=model, variance_schedule=variance_schedule, n_diffusion_steps=n_diffusion_steps,
+                         clip_denoised=clip_denoised, predict_epsilon=predict_epsilon, loss_type=loss_type,
+                         context_model=context_model, **kwargs)
+        self.mask_type = mask_type
+        self.traj_len = traj_len
+        self.ddim_num_inference_steps_high = 10
+        self.ddim_num_inference_steps_low = 5
+        assert cfg_mode in ('reference_compat', 'intended')
+        self.cfg_mode = cfg_mode
+
+    # dynamic APF constants hard-coded in the reference (diffusion_model_dynamic.py:380-389)
+    apf_dynamic = dict(obs_radius=0.1, points_per_obstacle=64, threshold_static=0.2, threshold_pred=0.5,
+                       strength_static=0.15, strength_pred=0.15, window_static=8, window_pred=5)
+
+    def _row_pattern(self, B):
+        if self.cfg_mode == 'intended' or B is None:
+            return [0, 1]
+        # rows here are [b*2 + v]; v = 0 plays global row b, v = 1 plays global row B + b of the reference
+        return [0, 0, 1, 1] if B % 2 == 0 else [0, 1, 1, 0]
+
+    @torch.no_grad()
+    def ddim_p_sample(self, x, hard_conds, context, t, obstacle_pts, traj_normalized=None, forward_t=None, eta=0.0,
+                      use_apf=False, use_clipped_model_output=False, obstacle_field=None, pursuer_pos=None):
+        """One DDIM step of the high-level plan (diffusion_model_dynamic.py:338-447).  With ``use_apf`` the
+        caller supplies ``obstacle_field`` (ramp_amd.apf_dynamic.ObstacleField, dynamic cloud already updated) and
+        the pursuer position; every trajectory gets the static pass, those whose current waypoint is within
+        ``threshold_pred`` of the pursuer also the pursuer pass, then the goal waypoint is restored."""
+        assert use_clipped_model_output and eta == 0.0
+        from .apf_dynamic import avoidance
+        dev = self._device()
+        B, H, S = x.shape
+        ti = int(t.reshape(-1)[0])
+        prev = ti - self.n_diffusion_steps // self.ddim_num_inference_steps_high
+        ac = self.alphas_cumprod.detach().cpu()
+        a_t = ac[ti]
+        a_prev = ac[prev] if prev >= 0 else self.final_alpha_cumprod[0]
+        was = self.ddim
+        self.ddim = True
+        _, _, _, x0, _ = self.p_mean_variance(x, hard_conds, context, t, traj_normalized=traj_normalized,
+                                              obstacle_pts=obstacle_pts)
+        self.ddim = was
+        xx = x.detach().to(dev, torch.float32).contiguous()
+        if use_apf:
+            if obstacle_field is None or pursuer_pos is None:
+                raise ValueError("use_apf=True needs obstacle_field and pursuer_pos (the reference pulls them from "
+                                 "context['dataset'].env, which is outside the sampler hot path)")
+            c = self.apf_dynamic
+            x_start = xx[:, forward_t].clone()
+            x_goal = xx[:, -1].clone()
+            avoidance(x0, obstacle_field, is_dynamic=False, avoidance_window=c['window_static'],
+                      avoidance_strength=c['strength_static'], avoidance_strength_pred=c['strength_pred'])
+            near = (torch.norm(x_start[:, :2] - pursuer_pos.to(dev, torch.float32)[None, :2], dim=1)
+                    < c['threshold_pred']).to(torch.int32)
+            avoidance(x0, obstacle_field, is_dynamic=True, avoidance_window=c['window_pred'],
+                      avoidance_strength=c['strength_static'], avoidance_strength_pred=c['strength_pred'],
+                      affected_states=H, goal_state=x_goal[0], enable=near)
+            x0[:, -1] = x_goal
+        out = torch.empty_like(xx)
+        idx = (C.c_int32 * 1)(0)
+        with torch.cuda.device(dev):
+            p = _lib.RampSampleParams()      # reuse the DDIM finish through the kernel-level path: no hard conds here
+            _lib.check(_lib.load().ramp_ddim_finish(_lib.ptr(xx), _lib.ptr(x0), float(a_t ** 0.5),
+                                                    float((1 - a_t) ** 0.5), float(a_prev ** 0.5),
+                                                    float((1 - a_prev) ** 0.5), _lib.ptr(out), B, H, S,
+                                                    _lib.current_stream()), "ramp_ddim_finish")
+        return out
+
+    def sm(self, s1, s2, dt=0.1, num_steps=3, max_vel=.8):
+        """Velocity-limited straight-line states between s1 and s2 (diffusion_model_dynamic.py:192-214)."""
+        delta_pos = s2[:, :2] - s1[:, :2]
+        dist = torch.norm(delta_pos, dim=1, keepdim=True)
+        direc = torch.where(dist > 1e-6, delta_pos / dist, torch.zeros_like(delta_pos))
+        desired_v = delta_pos / (num_steps * dt)
+        base_v = torch.where(torch.norm(desired_v, dim=1, keepdim=True) > max_vel, direc * max_vel, desired_v)
+        tt = torch.arange(1, num_steps + 1, device=s1.device).float().view(1, num_steps, 1) * dt
+        pos = s1[:, None, :2] + tt * base_v[:, None, :]
+        return torch.cat([pos, base_v.unsqueeze(1).expand(-1, num_steps, -1)], dim=-1)
+
+    def q_sample(self, x_start, t, noise=None):
+        """diffusion_model_dynamic.py:671-680."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return (extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
+                + extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
+
+    def ddim_p_sample_loop(self, *a, **k):
+        raise NotImplementedError("the receding-horizon replanning loop (diffusion_model_dynamic.py:495-624) is "
+                                  "SURVEY.md §8(f) next-row 1; its inner step is ddim_p_sample()")
+
+    def run_inference(self, *a, **k):
+        raise NotImplementedError("see ddim_p_sample_loop")

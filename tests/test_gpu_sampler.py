@@ -190,3 +190,41 @@ def test_properties_at_scale():
     assert np.abs(a[:22, :4] - plain[:22]).max() < 1e-4                    # batch neighbours do not matter
     hc = synth.default_hard_conds(4, 48)
     assert np.array_equal(a[-1][:, 0], np.broadcast_to(hc[0], (B, 4))) and np.array_equal(a[-1][:, 47], np.broadcast_to(hc[47], (B, 4)))
+
+
+def test_dynamic_wrapper_against_reference_fixture():
+    """DynamicGaussianDiffusionModel pieces vs the reference: p_mean_variance with the reference's (quirky, Q1) row
+    pairing for even and odd B, the per-trajectory static / pursuer APF, sm()."""
+    from ramp_amd.apf_dynamic import ObstacleField, avoidance
+    from ramp_amd.models import DynamicGaussianDiffusionModel
+    g = np.load(f"{GOLDEN}/dynamic_cases.npz")
+    u = build_unet(4, 48, False, max_rows=16)
+    dm = DynamicGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True).eval().to("cuda")
+    for B in (4, 3):
+        x = dev(g[f"pmv{B}/x"]); t = torch.full((B,), 40, dtype=torch.long, device="cuda")
+        pts = dev(g["cloud"])[None].repeat(B, 1, 1, 1)
+        mean, _, _, x0, ec = dm.p_mean_variance(x, None, None, t, traj_normalized=None, obstacle_pts=pts)
+        assert rel(ec.cpu().numpy(), g[f"pmv{B}/ecomb"]) < 5e-5
+        assert np.abs(x0.cpu().numpy() - g[f"pmv{B}/x0"]).max() < 1e-4
+        assert np.abs(mean.cpu().numpy() - g[f"pmv{B}/mean"]).max() < 1e-4
+    dm2 = DynamicGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True, cfg_mode="intended").eval().to("cuda")
+    x = dev(g["pmv4/x"]); t = torch.full((4,), 40, dtype=torch.long, device="cuda")
+    ec2 = dm2.p_mean_variance(x, None, None, t, obstacle_pts=dev(g["cloud"]))[4]
+    assert rel(ec2.cpu().numpy(), g["pmv4/ecomb"]) > 1e-2          # true CFG differs from the reference's pairing
+    thr_s, thr_p, st_s, st_p, w_s, w_p = g["apf/params"]
+    field = ObstacleField(static_points=g["apf/static_points"], distance_threshold=thr_s, distance_threshold_pred=thr_p)
+    field.set_dynamic_points(g["apf/dynamic_points"])
+    tr = dev(g["apf/traj"])
+    out_s = avoidance(tr.clone(), field, is_dynamic=False, avoidance_window=int(w_s), avoidance_strength=st_s,
+                      avoidance_strength_pred=st_p).cpu().numpy()
+    out_d = avoidance(tr.clone(), field, is_dynamic=True, avoidance_window=int(w_p), avoidance_strength=st_s,
+                      avoidance_strength_pred=st_p, affected_states=48, goal_state=dev(g["apf/goal"])).cpu().numpy()
+    assert np.abs(out_s - g["apf/out_static"]).max() < 5e-7 and np.abs(out_d - g["apf/out_dynamic"]).max() < 5e-7
+    one = avoidance(tr[1].clone(), field, is_dynamic=False, avoidance_window=int(w_s), avoidance_strength=st_s).cpu().numpy()
+    assert np.array_equal(one, out_s[1])                            # single-trajectory form, like the reference's loop
+    assert np.abs(dm.sm(dev(g["sm/s1"]), dev(g["sm/s2"])).cpu().numpy() - g["sm/out"]).max() < 1e-6
+    # one full inner step: static APF for all, pursuer pass only for trajectories near the pursuer; finite, goal kept
+    xs = dm.ddim_p_sample(tr.clone(), None, None, torch.full((4,), 40, dtype=torch.long, device="cuda"),
+                          dev(g["cloud"]), forward_t=3, use_apf=True, use_clipped_model_output=True,
+                          obstacle_field=field, pursuer_pos=torch.tensor([0.05, 0.0]))
+    assert xs.shape == tr.shape and bool(torch.isfinite(xs).all())

@@ -156,3 +156,28 @@ def test_chain3d_ddpm():
     ch = sm.ddpm(g["noise"], synth.default_hard_conds(6, 48), g["latent"])
     assert ch.shape == g["chain"].shape
     assert np.abs(ch - g["chain"]).max() < 2e-4
+
+
+def test_dynamic_cases():
+    """Dynamic (pursuit-evasion) wrapper pieces: CFG with the reference's blocked row layout (quirk Q1) for even
+    and odd batch sizes, the per-trajectory static / pursuer APF, and the velocity smoothing."""
+    g = np.load(f"{G}/dynamic_cases.npz")
+    sched = dict(np.load(f"{G}/schedule_T100.npz"))
+    u = O.UNetOracle(weights(4, 48, False), 4, 48)
+    sm = O.SamplerOracle(u, 100, 2.5, sched=sched)
+    lat = u.encode_scene(g["cloud"])
+    for B in (4, 3):
+        e = sm.eps_cfg_dynamic_compat(g[f"pmv{B}/x"], 40, lat)
+        assert rel(e, g[f"pmv{B}/ecomb"]) < 2e-5
+        x0, mean = sm.x0_mean(g[f"pmv{B}/x"], g[f"pmv{B}/ecomb"], 40)
+        assert np.abs(x0 - g[f"pmv{B}/x0"]).max() < 1e-6 and np.abs(mean - g[f"pmv{B}/mean"]).max() < 1e-6
+    thr_s, thr_p, st_s, st_p, w_s, w_p = g["apf/params"]
+    tr = g["apf/traj"]
+    for b in range(tr.shape[0]):
+        o1 = O.apf_dynamic_avoidance(tr[b], g["apf/static_points"], thr_s, thr_s, st_s, int(w_s))
+        o2 = O.apf_dynamic_avoidance(tr[b], g["apf/dynamic_points"], thr_p, thr_s, st_p, None, affected=48, goal=g["apf/goal"])
+        assert np.abs(o1 - g["apf/out_static"][b]).max() < 2e-7
+        assert np.abs(o2 - g["apf/out_dynamic"][b]).max() < 2e-7
+    assert (g["apf/out_static"] != tr).sum() > 20 and (g["apf/out_dynamic"] != tr).sum() > 20
+    assert np.array_equal(g["apf/out_static"][3], tr[3]) and np.array_equal(g["apf/out_dynamic"][3], tr[3])
+    assert np.abs(O.sm_smooth(g["sm/s1"], g["sm/s2"]) - g["sm/out"]).max() < 1e-6
