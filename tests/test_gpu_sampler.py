@@ -228,3 +228,32 @@ def test_dynamic_wrapper_against_reference_fixture():
                           dev(g["cloud"]), forward_t=3, use_apf=True, use_clipped_model_output=True,
                           obstacle_field=field, pursuer_pos=torch.tensor([0.05, 0.0]))
     assert xs.shape == tr.shape and bool(torch.isfinite(xs).all())
+
+
+def test_warmup_consumes_one_randn_and_compose_loop_runs():
+    """Driver flow of inference_static.py: warmup() (one throw-away score evaluation that consumes one randn,
+    diffusion_model_static.py:405-433) then run_inference; and the compose=True DDIM-8 + APF loop end to end."""
+    from ramp_amd.models import StaticGaussianDiffusionModel
+    g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
+    dm = make_static(25)
+    hc = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(4, 48).items()}
+    extra = synth.make_noise((1, 4, 48, 4), seed=77)
+    with NoiseInjector([extra[0]] + list(g["noise"])) as inj:
+        dm.warmup(horizon=48, traj_normalized=None, obstacle_pts=dev(g["cloud"]), batch_size=4, device="cuda")
+        assert inj.used == 1
+        chain = dm.run_inference(None, hc, n_samples=4, horizon=48, return_chain=True, obstacle_pts=dev(g["cloud"]),
+                                 noise_std_extra_schedule_fn=lambda x: 0.5).cpu().numpy()
+        assert inj.used == 27
+    assert np.abs(chain - g["chain"]).max() < 1e-4
+    last = dm.run_inference(None, hc, n_samples=4, horizon=48, return_chain=False, obstacle_pts=dev(g["cloud"]),
+                            noise_std_extra_schedule_fn=lambda x: 0.5)
+    assert last.shape == (4, 48, 4)
+    # compose: two scenes + unconditional, DDIM with 8 steps and the APF hook on the 10-obstacle union cloud
+    u = build_unet(4, 48, False, max_rows=24)
+    dc = StaticGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True, compose=True,
+                                      use_apf=True).eval().to("cuda")
+    assert dc.ddim and dc.ddim_num_inference_steps == 8
+    clouds = dev(np.stack([synth.make_cloud(6, 64, 2, seed=1), synth.make_cloud(6, 64, 2, seed=2)]))
+    out = dc.run_inference(None, hc, n_samples=5, horizon=48, return_chain=True, obstacle_pts=clouds)
+    assert out.shape == (9, 5, 48, 4) and bool(torch.isfinite(out).all())
+    assert torch.equal(out[-1][:, 0], hc[0].cuda().expand(5, -1)) and torch.equal(out[-1][:, 47], hc[47].cuda().expand(5, -1))
