@@ -47,8 +47,8 @@ int ramp_destroy(ramp_ctx* ctx);
 
 /* load_state_dict (inference_static.py:107-111): one call per U-Net tensor, `name` is the
  * reference key without the leading "model." (e.g. "downs.0.0.blocks.0.block.0.weight").
- * `data` is HOST memory, fp32, `shape[ndim]` as in the checkpoint.  scene_encoder.* keys are
- * accepted and ignored here (the scene encoder runs once per scene above this ABI). */
+ * `data` is HOST memory, fp32, `shape[ndim]` as in the checkpoint.  scene_encoder.* float tensors (weights and
+ * BatchNorm running statistics) are loaded the same way for ramp_encode_scene. */
 int ramp_load_weight(ramp_ctx* ctx, const char* name, const float* data, const int64_t* shape, int32_t ndim);
 /* after the last ramp_load_weight: verifies every required tensor arrived, packs GEMM layouts. */
 int ramp_finalize_weights(ramp_ctx* ctx);
@@ -64,6 +64,12 @@ int ramp_prepare_time_table(ramp_ctx* ctx, int32_t T, void* stream);
  * array of length n_rows_pattern, applied cyclically: [0,1] = CFG, [0,1,2] = compose). */
 int ramp_set_scene(ramp_ctx* ctx, const float* latents, int32_t n_variants,
                    const int32_t* row_variant_host, int32_t n_rows_pattern, void* stream);
+
+/* scene_encoder(obstacle_pts) for ONE scene: ObstacleEncoderSet.forward (obstacle_encoder.py:125-152, point_dim 2,
+ * latent 320) or ObstacleEncoder.forward in eval mode (obstacle_encoder3d.py:77-94, point_dim 3, latent 256).
+ * cloud: device (n_obstacles, n_points, point_dim); latent_out: device (context_dim), 16-byte aligned. */
+int ramp_encode_scene(ramp_ctx* ctx, const float* cloud, int32_t n_obstacles, int32_t n_points, int32_t point_dim,
+                      float* latent_out, void* stream);
 
 /* TemporalUnetInference.forward / forward_no_energy (UnetInference.py:157-224).
  * x (B,H,S); each trajectory is evaluated n_rp times (rows b*n_rp + v).  f_out (B*n_rp,H,S)

@@ -146,6 +146,8 @@ struct ramp_ctx {
   float* s_cloud = nullptr; size_t s_cloud_cap = 0;
   // graph cache
   hipGraphExec_t graph_exec = nullptr; std::string graph_key;
+  // scene-encoder scratch
+  float* scene_ws = nullptr; size_t scene_ws_cap = 0;
   // bf16x6 weight planes: fp32 weight base pointer -> (planes, element count)
   int gemm_mode = 0;                 // 0 = exact fp32 MFMA, 1 = bf16x6 split on the bf16 matrix cores
   std::map<const float*, std::pair<unsigned short*, size_t>> x6;
@@ -583,6 +585,136 @@ int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s) {
   return 0;
 }
 
+// ---- scene encoders (once per scene) ------------------------------------------------------------
+GemmArgs slin(const float* A, int K, const float* W, const float* bias, float* C, int M, int N, const float* resid = nullptr) {
+  GemmArgs a = lin(A, K, W, bias, C, N, M, N, K);
+  if (resid) { a.resid = resid; a.ldr = N; }
+  return a;
+}
+int sw(ramp_ctx* c, const std::string& key, float** out) {
+  auto it = c->raw.find("scene_encoder." + key);
+  RAMP_REQUIRE(it != c->raw.end(), "missing scene-encoder weight '" + key + "'");
+  *out = it->second.first;
+  return 0;
+}
+int scene_scratch(ramp_ctx* c, size_t n) {
+  if (n > c->scene_ws_cap) { CK(dev_alloc(c, &c->scene_ws, n)); c->scene_ws_cap = n; }
+  return 0;
+}
+
+// ObstacleEncoderSet.forward for one scene (obstacle_encoder.py:125-152); cloud (No, Np, 2) -> latent (320)
+int encode_scene_2d(ramp_ctx* c, const float* cloud, int No, int Np, float* out, hipStream_t s) {
+  const int T = No * Np;
+  CK(scene_scratch(c, (size_t)T * (192 + 64 * 4 + 192 + 256) + 4096));
+  float* p = c->scene_ws;
+  float* F = p; p += (size_t)T * 192;
+  float* COMB = p; p += (size_t)T * 64;
+  float* X = p; p += (size_t)T * 64;
+  float* X2 = p; p += (size_t)T * 64;
+  float* LNb = p; p += (size_t)T * 64;
+  float* QKV = p; p += (size_t)T * 192;
+  float* Hb = p; p += (size_t)T * 256;
+  float* centers = p; p += 2 * ((No + 3) & ~3);
+  float* maxd = p; p += (No + 3) & ~3;
+  float* P0 = p; p += 64; float* P1 = p; p += 256;
+  float *w, *b, *g, *be, *div;
+  CK(sw(c, "pos_encoder.div_term", &div));
+  CK(sw(c, "point_embedding.0.weight", &w)); CK(sw(c, "point_embedding.0.bias", &b));
+  CK(sw(c, "point_embedding.1.weight", &g)); CK(sw(c, "point_embedding.1.bias", &be));
+  CK(scene_enc2d_prep(cloud, No, Np, centers, maxd, s));
+  CK(scene_enc2d_feat(cloud, centers, maxd, div, w, b, g, be, F, Np, T, s));
+  CK(sw(c, "combined_encoder.0.weight", &w)); CK(sw(c, "combined_encoder.0.bias", &b));
+  CK(launch_gemm(slin(F, 192, w, b, X2, T, 64), s));
+  CK(sw(c, "combined_encoder.1.weight", &g)); CK(sw(c, "combined_encoder.1.bias", &be));
+  CK(scene_ln64(X2, g, be, COMB, T, 1, s));
+  const int dims[3] = {64, 96, 160};
+  int off = 0;
+  for (int i = 0; i < 3; ++i) {
+    const float* xin = COMB;
+    for (int j = 0; j < 3; ++j) {
+      const std::string t = "set_transformers." + std::to_string(i) + "." + std::to_string(j);
+      CK(sw(c, t + ".norm1.weight", &g)); CK(sw(c, t + ".norm1.bias", &be));
+      CK(scene_ln64(xin, g, be, LNb, T, 0, s));
+      CK(sw(c, t + ".attn.qkv.weight", &w));
+      CK(launch_gemm(slin(LNb, 64, w, nullptr, QKV, T, 192), s));
+      CK(scene_attention(QKV, LNb, T, 4, 16, 0.25f, s));
+      CK(sw(c, t + ".attn.proj.weight", &w)); CK(sw(c, t + ".attn.proj.bias", &b));
+      CK(launch_gemm(slin(LNb, 64, w, b, X2, T, 64, xin), s));
+      CK(sw(c, t + ".norm2.weight", &g)); CK(sw(c, t + ".norm2.bias", &be));
+      CK(scene_ln64(X2, g, be, LNb, T, 0, s));
+      CK(sw(c, t + ".mlp.0.weight", &w)); CK(sw(c, t + ".mlp.0.bias", &b));
+      CK(launch_gemm(slin(LNb, 64, w, b, Hb, T, 256), s));
+      CK(scene_affine_act(Hb, nullptr, nullptr, nullptr, Hb, (long)T * 256, 256, 1, s));
+      CK(sw(c, t + ".mlp.3.weight", &w)); CK(sw(c, t + ".mlp.3.bias", &b));
+      CK(launch_gemm(slin(Hb, 256, w, b, X, T, 64, X2), s));
+      xin = X;
+    }
+    const int d = dims[i];
+    const std::string q = "poolings." + std::to_string(i);
+    CK(scene_colreduce(X, P0, 1, T, 64, 0, s));
+    CK(sw(c, q + ".0.weight", &w)); CK(sw(c, q + ".0.bias", &b));
+    CK(launch_gemm(slin(P0, 64, w, b, P1, 1, d), s));
+    CK(scene_affine_act(P1, nullptr, nullptr, nullptr, P1, d, d, 1, s));
+    CK(sw(c, q + ".2.weight", &w)); CK(sw(c, q + ".2.bias", &b));
+    CK(launch_gemm(slin(P1, d, w, b, out + off, 1, d), s));
+    off += d;
+  }
+  return 0;
+}
+
+// ObstacleEncoder.forward, eval mode, one scene (obstacle_encoder3d.py:77-94); cloud (No, Np, 3) -> latent (256)
+int encode_scene_3d(ramp_ctx* c, const float* cloud, int No, int Np, float* out, hipStream_t s) {
+  const int T = No * Np, E = 256;
+  CK(scene_scratch(c, (size_t)T * (64 + 256) + (size_t)No * (256 * 4 + 768 + 512) + 4096));
+  float* p = c->scene_ws;
+  float* H1 = p; p += (size_t)T * 64;
+  float* H2 = p; p += (size_t)T * E;
+  float* X = p; p += (size_t)No * E; float* X2 = p; p += (size_t)No * E;
+  float* LNb = p; p += (size_t)No * E; float* O = p; p += (size_t)No * E;
+  float* QKV = p; p += (size_t)No * 768; float* Hb = p; p += (size_t)No * 512;
+  float* sc = p; p += 256; float* sh = p; p += 256; float* S0 = p; p += 256; float* S1 = p; p += 256;
+  float *w, *b, *g, *be, *rm, *rv;
+  CK(sw(c, "point_processor.conv1.weight", &w)); CK(sw(c, "point_processor.conv1.bias", &b));
+  CK(scene_linear_small(cloud, w, b, H1, T, 64, 3, s));
+  CK(sw(c, "point_processor.bn1.weight", &g)); CK(sw(c, "point_processor.bn1.bias", &be));
+  CK(sw(c, "point_processor.bn1.running_mean", &rm)); CK(sw(c, "point_processor.bn1.running_var", &rv));
+  CK(scene_bn_fold(g, be, rm, rv, sc, sh, 64, s));
+  CK(scene_affine_act(H1, sc, sh, nullptr, H1, (long)T * 64, 64, 2, s));
+  CK(sw(c, "point_processor.conv2.weight", &w)); CK(sw(c, "point_processor.conv2.bias", &b));
+  CK(launch_gemm(slin(H1, 64, w, b, H2, T, E), s));
+  CK(sw(c, "point_processor.bn2.weight", &g)); CK(sw(c, "point_processor.bn2.bias", &be));
+  CK(sw(c, "point_processor.bn2.running_mean", &rm)); CK(sw(c, "point_processor.bn2.running_var", &rv));
+  CK(scene_bn_fold(g, be, rm, rv, sc, sh, E, s));
+  CK(scene_affine_act(H2, sc, sh, nullptr, H2, (long)T * E, E, 2, s));
+  CK(scene_colreduce(H2, X, No, Np, E, 1, s));                     // max over the points of each obstacle
+  for (int i = 0; i < 2; ++i) {
+    const std::string t = "set_transformer_blocks." + std::to_string(i);
+    CK(sw(c, t + ".norm1.weight", &g)); CK(sw(c, t + ".norm1.bias", &be));
+    CK(launch_ln_fwd(X, g, be, LNb, No, s));
+    CK(sw(c, t + ".mha.in_proj_weight", &w)); CK(sw(c, t + ".mha.in_proj_bias", &b));
+    CK(launch_gemm(slin(LNb, E, w, b, QKV, No, 768), s));
+    CK(scene_attention(QKV, O, No, 4, 64, 0.125f, s));
+    CK(sw(c, t + ".mha.out_proj.weight", &w)); CK(sw(c, t + ".mha.out_proj.bias", &b));
+    CK(launch_gemm(slin(O, E, w, b, X2, No, E, X), s));
+    CK(sw(c, t + ".norm2.weight", &g)); CK(sw(c, t + ".norm2.bias", &be));
+    CK(launch_ln_fwd(X2, g, be, LNb, No, s));
+    CK(sw(c, t + ".ffn.0.weight", &w)); CK(sw(c, t + ".ffn.0.bias", &b));
+    CK(launch_gemm(slin(LNb, E, w, b, Hb, No, 512), s));
+    CK(scene_affine_act(Hb, nullptr, nullptr, nullptr, Hb, (long)No * 512, 512, 2, s));
+    CK(sw(c, t + ".ffn.3.weight", &w)); CK(sw(c, t + ".ffn.3.bias", &b));
+    CK(launch_gemm(slin(Hb, 512, w, b, X, No, E, X2), s));
+  }
+  CK(sw(c, "output_proj.weight", &w)); CK(sw(c, "output_proj.bias", &b));
+  CK(launch_gemm(slin(X, E, w, b, O, No, E), s));
+  CK(scene_colreduce(O, S0, 1, No, E, 1, s));
+  CK(sw(c, "global_pooling.0.weight", &w)); CK(sw(c, "global_pooling.0.bias", &b));
+  CK(launch_gemm(slin(S0, E, w, b, S1, 1, E), s));
+  CK(scene_affine_act(S1, nullptr, nullptr, nullptr, S1, E, E, 2, s));
+  CK(sw(c, "global_pooling.2.weight", &w)); CK(sw(c, "global_pooling.2.bias", &b));
+  CK(launch_gemm(slin(S1, E, w, b, out, 1, E), s));
+  return 0;
+}
+
 hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
 int ensure_sampler_buffers(ramp_ctx* c, int B, int n_rp, int n_steps, bool chain) {
@@ -662,7 +794,6 @@ int ramp_load_weight(ramp_ctx* c, const char* name, const float* data, const int
   RAMP_REQUIRE(c && name && data && (shape || ndim == 0), "null argument");
   RAMP_REQUIRE(!c->finalized, "weights already finalized");
   std::string key(name);
-  if (key.rfind("scene_encoder.", 0) == 0) return 0;
   size_t n = 1; std::vector<int64_t> shp;
   for (int i = 0; i < ndim; ++i) { RAMP_REQUIRE(shape[i] > 0, "bad shape"); n *= (size_t)shape[i]; shp.push_back(shape[i]); }
   float* d; CK(dev_alloc(c, &d, n));
@@ -876,6 +1007,18 @@ int ramp_set_scene(ramp_ctx* c, const float* latents, int32_t n_variants, const 
   RAMP_HIP_CHECK(hipFree(d));
   c->graph_key.clear();     // scene changed: cross_bias pointer may have moved
   return rc;
+}
+
+int ramp_encode_scene(ramp_ctx* c, const float* cloud, int32_t n_obstacles, int32_t n_points, int32_t point_dim,
+                      float* latent_out, void* stream) {
+  RAMP_REQUIRE(c && c->finalized && cloud && latent_out && n_obstacles > 0 && n_points > 0, "bad arguments");
+  RAMP_REQUIRE((reinterpret_cast<uintptr_t>(latent_out) & 15) == 0, "latent_out must be 16-byte aligned");
+  if (point_dim == 2) {
+    RAMP_REQUIRE(c->cfg.context_dim == 320, "2-D scene encoder produces a 320-d latent");
+    return encode_scene_2d(c, cloud, n_obstacles, n_points, latent_out, as_stream(stream));
+  }
+  RAMP_REQUIRE(point_dim == 3 && c->cfg.context_dim == 256, "3-D scene encoder takes (No,Np,3) and produces 256-d");
+  return encode_scene_3d(c, cloud, n_obstacles, n_points, latent_out, as_stream(stream));
 }
 
 int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, float* f_out, float* eps_out,

@@ -1,4 +1,7 @@
-"""Scene encoders (run ONCE per scene, above the C ABI, in PyTorch-ROCm).
+"""Scene-encoder parameter containers (the arithmetic runs in HIP: ramp_encode_scene / csrc/scene.hip).
+
+These torch modules exist so that ``state_dict`` / ``load_state_dict`` / ``.to(device)`` behave like the
+reference's; their ``forward`` is a torch restatement used only by the CPU tests as a cross-check.
 
 Same parameter names / shapes as the reference so checkpoints load unchanged:
   2-D  ObstacleEncoderSet   mpd/models/diffusion_models/obstacle_encoder.py:94-152

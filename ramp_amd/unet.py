@@ -126,6 +126,13 @@ class TemporalUnetInference(nn.Module):
                 shape = (C.c_int64 * w.dim())(*w.shape)
                 _lib.check(lib.ramp_load_weight(h, k.encode(), C.cast(w.data_ptr(), _lib.c_f32p), shape, w.dim()),
                            f"ramp_load_weight({k})")
+            for k, v in self.scene_encoder.state_dict().items():          # float tensors incl. BN running stats
+                if not torch.is_floating_point(v):
+                    continue
+                w = v.detach().to("cpu", torch.float32).contiguous()
+                shape = (C.c_int64 * max(w.dim(), 1))(*(w.shape if w.dim() else (1,)))
+                _lib.check(lib.ramp_load_weight(h, ("scene_encoder." + k).encode(), C.cast(w.data_ptr(), _lib.c_f32p),
+                                                shape, max(w.dim(), 1)), f"ramp_load_weight(scene_encoder.{k})")
             _lib.check(lib.ramp_finalize_weights(h), "ramp_finalize_weights")
         self._ctx = h
         return h
@@ -140,10 +147,18 @@ class TemporalUnetInference(nn.Module):
     # ------------------------------------------------------------------ scene
     @torch.no_grad()
     def encode_scene(self, cloud: torch.Tensor) -> torch.Tensor:
-        """cloud (No,Np,D) or (n_scenes,No,Np,D) -> latents (n_scenes, context_dim)."""
+        """cloud (No,Np,D) or (n_scenes,No,Np,D) -> latents (n_scenes, context_dim), on the HIP kernels
+        (ramp_encode_scene).  ``self.scene_encoder`` (torch) only holds the parameters / state_dict."""
         if cloud.dim() == 3:
             cloud = cloud.unsqueeze(0)
-        return self.scene_encoder(cloud.to(self._device(), torch.float32))
+        cloud = cloud.to(self._device(), torch.float32).contiguous()
+        out = torch.empty((cloud.shape[0], self.context_dim), device=self._device(), dtype=torch.float32)
+        with torch.cuda.device(self._device()):
+            for i in range(cloud.shape[0]):
+                _lib.check(_lib.load().ramp_encode_scene(self.ctx(), _lib.ptr(cloud[i]), cloud.shape[1], cloud.shape[2],
+                                                         cloud.shape[3], out[i].data_ptr(), _lib.current_stream()),
+                           "ramp_encode_scene")
+        return out
 
     def set_scene(self, latents: torch.Tensor, row_pattern: List[int]):
         """latents (n_variants, ctx) with all-zero rows for unconditional variants; row r of the network

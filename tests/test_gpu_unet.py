@@ -82,3 +82,18 @@ def test_missing_weights_and_bad_args_fail_loudly():
     with pytest.raises(_lib.RampHipError):     # timestep outside the table
         lat = torch.zeros(2, 320, device="cuda"); m.set_scene(lat, [0, 1])
         _lib.check(_lib.load().ramp_score(m.ctx(), _lib.ptr(x), 1, 2, 7, None, _lib.ptr(e), None))
+
+
+def test_scene_encoders_hip_against_reference_fixture():
+    """ramp_encode_scene (HIP) vs the reference's scene latents: 2-D 6x64 and 16x64 clouds, 3-D 5x50 and 20x200."""
+    g = np.load(f"{GOLDEN}/scene_latents.npz")
+    m2 = build_unet(4, 48, False, max_rows=4)
+    m3 = build_unet(6, 48, True, max_rows=4)
+    for k in ("2d_6x64", "2d_16x64"):
+        lat = m2.encode_scene(dev(g["cloud" + k]))[0].cpu().numpy()
+        assert lat.shape == (320,) and rel(lat, g["lat" + k]) < 5e-6, k
+    for k in ("3d_5x50", "3d_20x200"):
+        lat = m3.encode_scene(dev(g["cloud" + k]))[0].cpu().numpy()
+        assert lat.shape == (256,) and rel(lat, g["lat" + k]) < 5e-6, k
+    two = m2.encode_scene(dev(np.stack([g["cloud2d_6x64"], g["cloud2d_6x64"][::-1].copy()])))
+    assert two.shape == (2, 320) and rel(two[0].cpu().numpy(), g["lat2d_6x64"]) < 5e-6
