@@ -370,10 +370,101 @@ def gen_dynamic(m2, sp2):
     save("dynamic_cases.npz", **arrs)
 
 
+FAKE_BOX_CENTRES = [[-0.3, 0.2], [0.35, -0.25], [0.1, 0.55], [-0.5, -0.5], [0.7, -0.7], [-0.7, 0.7]]
+
+
+class _StopReplan(Exception):
+    pass
+
+
+def make_fake_pursuit_env(stop_at=None, log=None):
+    """Stand-in for context['dataset'].env as the dynamic planner touches it: obj_fixed_list[0].fields[0] has
+    .centers / .sizes (boxes), obj_extra_list[0].fields[0] has .centers (1,2) / .radii (1,) and
+    update_centers(t, current_state): a deterministic pursuer stepping 0.05 toward the mean evader position.
+    tests/util.py holds the identical definition for the HIP side."""
+    from types import SimpleNamespace as NS
+
+    class Sphere:
+        def __init__(self):
+            self.centers = torch.tensor([[0.6, 0.55]], dtype=torch.float32)
+            self.radii = torch.tensor([0.1], dtype=torch.float32)
+
+        def update_centers(self, t, current_state):
+            if log is not None:
+                log.append((int(t), current_state.detach().cpu().numpy().copy()))
+            if stop_at is not None and t >= stop_at:
+                raise _StopReplan()
+            tgt = current_state.detach().cpu().float().mean(dim=0)[:2]
+            d = tgt - self.centers[0]
+            n = float(torch.linalg.norm(d))
+            step = d * (0.05 / n) if n > 0.05 else d
+            self.centers = (self.centers[0] + step).unsqueeze(0)
+
+    boxes = NS(centers=torch.tensor(FAKE_BOX_CENTRES), sizes=torch.full((6, 2), 0.16))
+    sphere = Sphere()
+    env = NS(obj_fixed_list=[NS(fields=[boxes])], obj_extra_list=[NS(fields=[sphere])])
+    return NS(env=env), sphere
+
+
+def gen_replan(m2, sp2):
+    """Receding-horizon planner (diffusion_model_dynamic.py:495-624) with a fake env, seeded numpy RNG, recorded
+    torch noise; the reference's cost selection is instrumented from outside to log each batch it ranks."""
+    import mpd.models.diffusion_models.diffusion_model_dynamic as ref_dyn
+    B, H, S, K = 6, 48, 4, 4
+    boxes_c = np.array(FAKE_BOX_CENTRES)
+    np.random.seed(11)
+    cloud = np.stack([ref_apf_dyn.generate_box_points(c, (0.16, 0.16), 64) for c in boxes_c]).astype(np.float32)
+    dm = quiet(DynamicGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=100,
+               predict_epsilon=True)
+    dm.eval()
+    noises = [torch.from_numpy(synth.make_noise((B, H, S), seed=500 + i)) for i in range(K + 2)]
+    log_env, log_cost = [], []
+    dataset, sphere = make_fake_pursuit_env(stop_at=K, log=log_env)
+    orig = ref_dyn.compute_trajectory_costs
+
+    def logged(trajs, pts, **kw):
+        out = orig(trajs, pts, **kw)
+        log_cost.append((trajs.detach().numpy().copy(), np.asarray(pts).reshape(-1, 2).copy(),
+                         -1 if out[4] is None else int(out[4]), out[3].numpy().copy(),
+                         None if out[0] is None else out[0].detach().numpy().copy()))
+        return out
+
+    ref_dyn.compute_trajectory_costs = logged
+    hard = {0: torch.tensor([-0.8, -0.8, 0.0, 0.0]).repeat(B, 1), H - 1: torch.tensor([0.8, 0.8, 0.0, 0.0]).repeat(B, 1)}
+    m2.reset_cache()
+    np.random.seed(23)
+    try:
+        with NoiseInjector(noises) as inj:
+            quiet(dm.ddim_p_sample_loop, (B, H, S), hard, context={'dataset': dataset}, return_chain=True,
+                  traj_normalized=torch.zeros(B, H, S), obstacle_pts=torch.from_numpy(cloud))
+            used = inj.used
+    except _StopReplan:
+        used = inj.used
+    finally:
+        ref_dyn.compute_trajectory_costs = orig
+    arrs = {"cloud": cloud, "noise": np.stack([n.numpy() for n in noises[:used]]), "n_iter": np.array(K),
+            "hard0": hard[0][0].numpy(), "hardN": hard[H - 1][0].numpy()}
+    for j, (tr, pts, idx, free, best) in enumerate(log_cost):
+        arrs[f"cost{j}/trajs"] = tr; arrs[f"cost{j}/npts"] = np.array(pts.shape[0]); arrs[f"cost{j}/idx"] = np.array(idx)
+        arrs[f"cost{j}/free"] = free
+        if best is not None:
+            arrs[f"cost{j}/best"] = best
+    for j, (t, st) in enumerate(log_env):
+        arrs[f"env{j}/t"] = np.array(t); arrs[f"env{j}/state"] = st
+    arrs["n_cost"] = np.array(len(log_cost)); arrs["n_env"] = np.array(len(log_env))
+    arrs["pursuer_final"] = sphere.centers.numpy()
+    print(f"    replan: {len(log_cost)} selections (idx {[c[2] for c in log_cost]}, free {[int(c[3].sum()) for c in log_cost]}), "
+          f"{len(log_env)} pursuer updates, {used} noise draws")
+    save("replan_chain.npz", **arrs)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "dynamic":
         m2, sp2, _ = build_unet(4, 48, False)
         gen_dynamic(m2, sp2); return
+    if len(sys.argv) > 1 and sys.argv[1] == "replan":
+        m2, sp2, _ = build_unet(4, 48, False)
+        gen_replan(m2, sp2); return
     if len(sys.argv) > 1 and sys.argv[1] == "cost":
         gen_cost(); return
     if len(sys.argv) > 1 and sys.argv[1] == "apf":
@@ -393,6 +484,7 @@ def main():
     print("chains 2-D"); gen_chains(m2, sp2)
     print("chain 3-D"); gen_chain3d(m3, sp3)
     print("dynamic"); gen_dynamic(m2, sp2)
+    print("replan"); gen_replan(m2, sp2)
     print("done")
 
 

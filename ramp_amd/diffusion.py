@@ -140,9 +140,15 @@ class _GaussianDiffusionBase(nn.Module):
             lat = torch.cat([m.encode_scene(obstacle_pts), zero])
             pattern = [0, 1, 2]
         else:
-            lat = torch.cat([m.encode_scene(obstacle_pts), zero])
             pattern = self._row_pattern(B)
+            # the step-at-a-time callers (p_mean_variance, the replanning loop) pass the same cloud every step
+            m.ctx()                          # (re)creates the context and clears the key after a weight reload
+            key = (obstacle_pts.data_ptr(), obstacle_pts._version, tuple(obstacle_pts.shape), tuple(pattern))
+            if getattr(m, '_scene_key', None) == key:
+                return
+            lat = torch.cat([m.encode_scene(obstacle_pts), zero])
         m.set_scene(lat, pattern)
+        m._scene_key = None if self.compose else key
         m.cached_batch_size = None          # the compat forward() cache is keyed differently
 
     @staticmethod
@@ -395,8 +401,10 @@ class GaussianDiffusionModel3d(_GaussianDiffusionBase):
 class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
     """Pursuit-evasion wrapper (diffusion_model_dynamic.py:24-680): the pieces on the sampler hot path — CFG
     (w = 2.5) + x0 + clamp + posterior (``p_mean_variance``), one DDIM step with the per-trajectory static /
-    pursuer APF (``ddim_p_sample``), velocity smoothing ``sm`` and ``q_sample`` re-noising.  The receding-horizon
-    replanning state machine around them (``ddim_p_sample_loop``, :495-624) is SURVEY.md §8(f) "next" row 1.
+    pursuer APF (``ddim_p_sample``), velocity smoothing ``sm`` and ``q_sample`` re-noising, and the receding-horizon
+    replanning state machine around them (``ddim_p_sample_loop`` / ``ddim_replan_scratch`` / ``run_inference``,
+    :461-667; SURVEY.md §8(f) "next" row 1), which reaches the environment through the same attribute path as the
+    reference (``context['dataset'].env.obj_fixed_list / obj_extra_list``).
 
     ``cfg_mode='reference_compat'`` reproduces the reference's row pairing exactly: it
     lays rows out blocked [x_0..x_{B-1}, x_0..x_{B-1}] while the net zeroes the latent of every odd GLOBAL row, so
@@ -494,9 +502,175 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
         return (extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
                 + extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
 
-    def ddim_p_sample_loop(self, *a, **k):
-        raise NotImplementedError("the receding-horizon replanning loop (diffusion_model_dynamic.py:495-624) is "
-                                  "SURVEY.md §8(f) next-row 1; its inner step is ddim_p_sample()")
+    # ------------------------------------------------------------------ receding-horizon planner
+    def _obstacle_field(self, context):
+        """Lazily build the APF clouds exactly where the reference does (diffusion_model_dynamic.py:391-411): static
+        boxes from context['static_obstacle_centers'/'sizes'], pursuer from the env's moving sphere field."""
+        from .apf_dynamic import ObstacleField
+        if 'obstacle_field' not in context:
+            sphere = context['dataset'].env.obj_extra_list[0].fields[0]
+            c = self.apf_dynamic
 
-    def run_inference(self, *a, **k):
-        raise NotImplementedError("see ddim_p_sample_loop")
+            def dynamic_obstacle_fn(t, start_pos, replan_guide=True, best_idx=None):
+                if replan_guide and best_idx is not None:
+                    start_pos = start_pos[best_idx].unsqueeze(0)
+                sphere.update_centers(t, start_pos)
+                return sphere.centers[0].cpu().numpy(), c['obs_radius']
+
+            context['obstacle_field'] = ObstacleField(context['static_obstacle_centers'], context['static_obstacle_sizes'],
+                                                      dynamic_obstacle_fn, c['points_per_obstacle'],
+                                                      distance_threshold=c['threshold_static'],
+                                                      distance_threshold_pred=c['threshold_pred'], device=self._device())
+        return context['obstacle_field']
+
+    def _step(self, x, hard_conds, context, i, obstacle_pts, traj_normalized, forward_t, use_apf):
+        """ddim_p_sample as the loops call it: with use_apf the pursuer cloud is advanced to ``forward_t`` first."""
+        B = x.shape[0]
+        t = torch.full((B,), int(i), device=self._device(), dtype=torch.long)
+        field, pursuer = None, None
+        if use_apf:
+            field = self._obstacle_field(context)
+            field.update_dynamic(forward_t, x[:, forward_t, :2].clone(), replan_guide=True)
+            pursuer = torch.as_tensor(np.asarray(field.dynamic_center), dtype=torch.float32)
+        return self.ddim_p_sample(x, hard_conds, context, t, obstacle_pts, traj_normalized=traj_normalized,
+                                  forward_t=forward_t, eta=0.0, use_apf=use_apf, use_clipped_model_output=True,
+                                  obstacle_field=field, pursuer_pos=pursuer)
+
+    @torch.no_grad()
+    def ddim_replan_scratch(self, shape, hard_conds, context=None, traj_normalized=None, forward_t=None,
+                            obstacle_pts=None, use_apf=False, executed_history=None):
+        """diffusion_model_dynamic.py:461-493."""
+        x = torch.randn(shape, device=self._device())
+        x = apply_hard_conditioning(x, hard_conds)
+        for h, st in enumerate(executed_history):
+            x[:, h] = st
+        for i in self.ddim_set_timesteps(self.ddim_num_inference_steps_high):
+            if i == 0:
+                use_apf = True
+            x = self._step(x, hard_conds, context, i, obstacle_pts, traj_normalized, forward_t, use_apf)
+            x = apply_hard_conditioning(x, hard_conds)
+            for h, st in enumerate(executed_history):
+                x[:, h] = st
+        return x
+
+    @torch.no_grad()
+    def ddim_p_sample_loop(self, shape, hard_conds, context=None, return_chain=False, traj_normalized=None,
+                           obstacle_pts=None, t_start_guide=float('inf'), guide=None, n_guide_steps=1,
+                           max_iteration=60, **sample_kwargs):
+        """Pursuit-evasion receding-horizon planner (diffusion_model_dynamic.py:495-624): a 10-step DDIM high-level
+        plan, best-trajectory selection, then up to ``max_iteration`` replans of 5 DDIM steps each from a re-noised
+        copy of the current plan with the executed history and the goal inpainted, velocity smoothing, the
+        per-trajectory static / pursuer APF on the last step, and collision / cost selection.  Host control flow as
+        in the reference; every tensor operation on the trajectories runs on the HIP kernels."""
+        from .apf_dynamic import generate_sphere_points
+        from .cost import compute_trajectory_costs
+        device = self._device()
+        B = shape[0]
+        x = torch.randn(shape, device=device)
+        x = apply_hard_conditioning(x, hard_conds)
+        env = context['dataset'].env
+        fixed = env.obj_fixed_list[0].fields[0]
+        context['static_obstacle_centers'] = fixed.centers.cpu().numpy()[:4]
+        context['static_obstacle_sizes'] = fixed.sizes.cpu().numpy()[:4]
+        sphere = env.obj_extra_list[0].fields[0]
+        cloud = obstacle_pts.to(device).contiguous()          # (n_obstacles, n_points, 2); the reference replicates it per row
+        cost_cloud = cloud.reshape(-1, 2)
+        chain_obs = []
+        chain_start = [hard_conds[0][0].unsqueeze(0)]
+        safe_threshold, distance_threshold_pred = 0.2, 0.4
+        thr_high, thr_low = 0.02, 0.05
+        replan_scratch_shape = (min(30, B), shape[1], shape[2])   # the reference hard-codes (30, 48, 4)
+        chain = [] if return_chain else None
+        stepp = 0
+        # STAGE I: high-level plan
+        for i in self.ddim_set_timesteps(self.ddim_num_inference_steps_high):
+            x = self._step(x, hard_conds, context, i, cloud, traj_normalized, None, False)
+            x = apply_hard_conditioning(x, hard_conds)
+        best_traj, _, _, _, _ = compute_trajectory_costs(x, cost_cloud, collision_threshold=thr_high)
+        if best_traj is None:
+            raise RuntimeError("no collision-free high-level plan (the reference dereferences None here)")
+        high_plan = best_traj.clone()
+        x = best_traj.clone()
+        executed_history = [x[0].clone().unsqueeze(0)]
+        # STAGE II: receding-horizon replanning
+        ts = self.ddim_set_timesteps(self.ddim_num_inference_steps_high)
+        low = ts[-self.ddim_num_inference_steps_low:]
+        for k in range(max_iteration):
+            x_clean = x.clone()
+            x = x.unsqueeze(0).repeat(B, 1, 1).contiguous()
+            noise_t = torch.tensor([int(low[0])], device=device)
+            x = self.q_sample(x, noise_t).contiguous()
+            x[:, 0, 2:] = 0
+            for h, st in enumerate(executed_history):
+                x[:, h] = st
+            x[:, -1] = x_clean[-1]
+            for i in low:
+                use_apf = False
+                if i == 0:
+                    use_apf = True
+                    window = 3
+                    x[:, stepp + 1:stepp + 1 + window] = self.sm(x[:, stepp], x[:, stepp + window], num_steps=window)
+                x = self._step(x, hard_conds, context, i, cloud, traj_normalized, k, use_apf)
+                x = apply_hard_conditioning(x, hard_conds)
+                for h, st in enumerate(executed_history):
+                    x[:, h] = st
+                x[:, -1] = x_clean[-1]
+                x[:, 0, 2:] = 0.0
+            window = 2
+            x[:, stepp + 1:stepp + 1 + window] = self.sm(x[:, stepp], x[:, stepp + window], num_steps=window)
+            near = np.linalg.norm(x[0, stepp, :2].cpu().numpy() - sphere.centers[0].cpu().numpy()) < distance_threshold_pred
+            if near:
+                pts = generate_sphere_points(sphere.centers[0].cpu().numpy(), sphere.radii[0].cpu().numpy(), 64)
+                allpts = torch.cat([cost_cloud, torch.from_numpy(pts).to(device, cloud.dtype)])
+                x, _, _, _, _ = compute_trajectory_costs(x, allpts, collision_threshold=thr_low)
+            else:
+                x, _, _, _, _ = compute_trajectory_costs(x, cost_cloud, collision_threshold=thr_low)
+            while x is None:
+                new_hc = {kk: v[:replan_scratch_shape[0]].clone() for kk, v in hard_conds.items()}
+                x = self.ddim_replan_scratch(replan_scratch_shape, new_hc, context, traj_normalized, forward_t=k,
+                                             obstacle_pts=cloud, use_apf=False, executed_history=executed_history)
+                window = 2
+                x[:, stepp + 1:stepp + 1 + window] = self.sm(x[:, stepp], x[:, stepp + window], num_steps=window)
+                x, _, _, _, _ = compute_trajectory_costs(x, cost_cloud, collision_threshold=thr_low)
+            x = x.clone()
+            x[0, 2:] = 0.0
+            executed_history.append(x[stepp + 1].clone().unsqueeze(0))
+            updated_start_state = x[stepp].clone()
+            stepp += 1
+            if return_chain:
+                if stepp == 1:
+                    chain.append(high_plan.unsqueeze(0).clone())
+                chain.append(x.unsqueeze(0).clone())
+            chain_obs.append(sphere.centers.clone())
+            chain_start.append(updated_start_state.unsqueeze(0).clone())
+            if torch.norm(x[stepp - 1, :2] - x[-1, :2]) < safe_threshold:
+                break
+        if return_chain:
+            chain = torch.stack(chain, dim=1)
+        return x, chain, chain_obs, chain_start
+
+    @torch.no_grad()
+    def conditional_sample(self, hard_conds, horizon=None, batch_size=1, ddim=False, traj_normalized=None,
+                           obstacle_pts=None, **sample_kwargs):
+        horizon = horizon or self.model.n_support_points
+        shape = (batch_size, horizon, self.state_dim)
+        for k in ('sample_fn', 'n_diffusion_steps_without_noise', 'noise_std_extra_schedule_fn'):
+            sample_kwargs.pop(k, None)
+        return self.ddim_p_sample_loop(shape, hard_conds, traj_normalized=traj_normalized, obstacle_pts=obstacle_pts,
+                                       **sample_kwargs)
+
+    @torch.no_grad()
+    def run_inference(self, context=None, hard_conds=None, n_samples=1, return_chain=False, traj_normalized=None,
+                      obstacle_pts=None, **diffusion_kwargs):
+        """diffusion_model_dynamic.py:649-667: (chain (iters, 1, H, S), chain_obs, chain_start) if return_chain."""
+        hard_conds = copy(hard_conds)
+        context = copy(context)
+        for k, v in hard_conds.items():
+            hard_conds[k] = v.to(self._device()).unsqueeze(0).expand(n_samples, -1).contiguous() if v.dim() == 1 else v
+        samples, chain, chain_obs, chain_start = self.conditional_sample(
+            hard_conds, context=context, batch_size=n_samples, return_chain=True, traj_normalized=traj_normalized,
+            obstacle_pts=obstacle_pts, **diffusion_kwargs)
+        chain = chain.permute(1, 0, 2, 3)
+        if return_chain:
+            return chain, chain_obs, chain_start
+        return chain[-1]

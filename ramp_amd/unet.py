@@ -164,6 +164,7 @@ class TemporalUnetInference(nn.Module):
         """latents (n_variants, ctx) with all-zero rows for unconditional variants; row r of the network
         uses variant row_pattern[r % len(row_pattern)]."""
         lat = latents.to(self._device(), torch.float32).contiguous()
+        self._scene_key = None
         pat = (C.c_int32 * len(row_pattern))(*row_pattern)
         with torch.cuda.device(self._device()):
             _lib.check(_lib.load().ramp_set_scene(self.ctx(), _lib.ptr(lat), lat.shape[0], pat, len(row_pattern),

@@ -257,3 +257,72 @@ def test_warmup_consumes_one_randn_and_compose_loop_runs():
     out = dc.run_inference(None, hc, n_samples=5, horizon=48, return_chain=True, obstacle_pts=clouds)
     assert out.shape == (9, 5, 48, 4) and bool(torch.isfinite(out).all())
     assert torch.equal(out[-1][:, 0], hc[0].cuda().expand(5, -1)) and torch.equal(out[-1][:, 47], hc[47].cuda().expand(5, -1))
+
+
+def test_dynamic_replanning_loop_against_reference_run():
+    """The receding-horizon planner (diffusion_model_dynamic.py:495-624) against a run of the reference planner with
+    the same fake env, numpy seed and torch noise: every batch handed to the cost selection, every selected index,
+    every evader state handed to the pursuer dynamics."""
+    import ramp_amd.cost as cost_mod
+    from ramp_amd.models import DynamicGaussianDiffusionModel
+    from util import NoiseInjector, StopReplan, make_fake_pursuit_env
+    g = np.load(f"{GOLDEN}/replan_chain.npz")
+    K = int(g["n_iter"]); B, H, S = g["noise"].shape[1:]
+    u = build_unet(4, 48, False, max_rows=16)
+    dm = DynamicGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True).eval().to("cuda")
+    log_env, log_cost = [], []
+    dataset, sphere = make_fake_pursuit_env(stop_at=K, log=log_env)
+    orig = cost_mod.compute_trajectory_costs
+
+    def logged(trajs, pts, **kw):
+        out = orig(trajs, pts, **kw)
+        log_cost.append((trajs.cpu().numpy().copy(), pts.reshape(-1, 2).shape[0], -1 if out[4] is None else int(out[4]),
+                         out[3].cpu().numpy().copy()))
+        return out
+
+    cost_mod.compute_trajectory_costs = logged
+    hard = {0: dev(g["hard0"]).repeat(B, 1), H - 1: dev(g["hardN"]).repeat(B, 1)}
+    np.random.seed(23)
+    try:
+        with NoiseInjector(list(g["noise"])):
+            with pytest.raises(StopReplan):
+                dm.ddim_p_sample_loop((B, H, S), hard, context={'dataset': dataset}, return_chain=True,
+                                      obstacle_pts=dev(g["cloud"]))
+    finally:
+        cost_mod.compute_trajectory_costs = orig
+    assert len(log_cost) == int(g["n_cost"]) and len(log_env) == int(g["n_env"])
+    errs = []
+    for j, (tr, npts, idx, free) in enumerate(log_cost):
+        errs.append(float(np.abs(tr - g[f"cost{j}/trajs"]).max()))
+        assert npts == int(g[f"cost{j}/npts"])
+        assert idx == int(g[f"cost{j}/idx"]) and np.array_equal(free, g[f"cost{j}/free"]), (j, idx, free)
+    for j, (t, st) in enumerate(log_env):
+        assert t == int(g[f"env{j}/t"])
+        errs.append(float(np.abs(st - g[f"env{j}/state"]).max()))
+    print("replan errs", errs)
+    assert errs[0] < 1e-4                      # stage I: ten plain DDIM steps
+    assert max(errs) < 2e-4                    # later iterations pass through APF pushes and re-selection (measured 4.3e-5)
+    assert np.abs(sphere.centers.numpy() - g["pursuer_final"]).max() < 1e-4
+
+
+def test_dynamic_run_inference_terminates_and_respects_constraints():
+    """run_inference end to end with the fake env: start near the goal so the loop ends on its own; the returned
+    chain / chain_obs / chain_start have the reference's shapes and the executed history is inpainted."""
+    from ramp_amd.models import DynamicGaussianDiffusionModel
+    from util import make_fake_pursuit_env, FAKE_BOX_CENTRES
+    from ramp_amd.apf_dynamic import generate_box_points
+    u = build_unet(4, 48, False, max_rows=16)
+    dm = DynamicGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True).eval().to("cuda")
+    np.random.seed(3)
+    cloud = np.stack([generate_box_points(c, (0.16, 0.16), 64) for c in FAKE_BOX_CENTRES]).astype(np.float32)
+    dataset, sphere = make_fake_pursuit_env()
+    torch.manual_seed(0)
+    hard = {0: torch.tensor([0.05, -0.05, 0.0, 0.0]), 47: torch.tensor([0.15, 0.05, 0.0, 0.0])}
+    chain, chain_obs, chain_start = dm.run_inference(context={'dataset': dataset}, hard_conds=hard, n_samples=6,
+                                                     return_chain=True, obstacle_pts=dev(cloud), max_iteration=3)
+    n_it = len(chain_obs)
+    assert 1 <= n_it <= 3
+    assert chain.shape == (n_it + 1, 1, 48, 4) and len(chain_start) == n_it + 1
+    last = chain[-1, 0].cpu().numpy()
+    assert np.allclose(last[0, :2], [0.05, -0.05]) and np.allclose(last[-1], [0.15, 0.05, 0, 0])
+    assert np.isfinite(chain.cpu().numpy()).all()

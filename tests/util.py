@@ -65,3 +65,38 @@ class NoiseInjector:
 
     def __exit__(self, *exc):
         torch.randn, torch.randn_like = self._randn, self._randn_like
+
+
+FAKE_BOX_CENTRES = [[-0.3, 0.2], [0.35, -0.25], [0.1, 0.55], [-0.5, -0.5], [0.7, -0.7], [-0.7, 0.7]]
+
+
+class StopReplan(Exception):
+    pass
+
+
+def make_fake_pursuit_env(stop_at=None, log=None):
+    """The same stand-in for context['dataset'].env that oracle/make_goldens.py drove the reference planner with:
+    boxes with .centers / .sizes, a one-sphere pursuer with .centers (1,2) / .radii (1,) and a deterministic
+    update_centers(t, current_state) stepping 0.05 toward the mean evader position."""
+    from types import SimpleNamespace as NS
+
+    class Sphere:
+        def __init__(self):
+            self.centers = torch.tensor([[0.6, 0.55]], dtype=torch.float32)
+            self.radii = torch.tensor([0.1], dtype=torch.float32)
+
+        def update_centers(self, t, current_state):
+            if log is not None:
+                log.append((int(t), current_state.detach().cpu().numpy().copy()))
+            if stop_at is not None and t >= stop_at:
+                raise StopReplan()
+            tgt = current_state.detach().cpu().float().mean(dim=0)[:2]
+            d = tgt - self.centers[0]
+            n = float(torch.linalg.norm(d))
+            step = d * (0.05 / n) if n > 0.05 else d
+            self.centers = (self.centers[0] + step).unsqueeze(0)
+
+    boxes = NS(centers=torch.tensor(FAKE_BOX_CENTRES), sizes=torch.full((6, 2), 0.16))
+    sphere = Sphere()
+    env = NS(obj_fixed_list=[NS(fields=[boxes])], obj_extra_list=[NS(fields=[sphere])])
+    return NS(env=env), sphere
