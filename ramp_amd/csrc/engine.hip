@@ -150,7 +150,9 @@ struct ramp_ctx {
   float* scene_ws = nullptr; size_t scene_ws_cap = 0;
   // bf16x6 weight planes: fp32 weight base pointer -> (planes, element count)
   int gemm_mode = 0;                 // 0 = exact fp32 MFMA, 1 = bf16x6 split on the bf16 matrix cores
-  std::map<const float*, std::pair<unsigned short*, size_t>> x6;
+  struct X6W { unsigned short* planes; size_t n; int K; unsigned short* packed; };
+  std::map<const float*, X6W> x6;
+  int x6_pipe = 1;                   // 1 = fragment-packed weights + pipelined kernel (RAMP_X6_PIPE=0: LDS-staged weights)
   // debug
   std::map<std::string, std::pair<float*, size_t>> dbg;
   int64_t launches = 0;
@@ -321,9 +323,16 @@ struct Run {
       auto it = c->x6.upper_bound(b.W);
       if (it != c->x6.begin()) {
         --it;
-        if (b.W >= it->first && b.W < it->first + it->second.second) {
-          b.Wx = it->second.first + (b.W - it->first);
-          b.wx_plane = (long)it->second.second;
+        const auto& e = it->second;
+        if (b.W >= it->first && b.W < it->first + e.n) {
+          const size_t off = b.W - it->first;
+          if (c->x6_pipe && e.packed && e.K == b.K && off % (32ul * b.K) == 0 && b.N % 32 == 0) {
+            b.Wx = e.packed + 3 * off; b.wx_packed = 1;
+          } else {
+            if (c->x6_pipe && getenv("RAMP_X6_WARN"))
+              fprintf(stderr, "[ramp] x6 weight not fragment-packed: M %d N %d K %d taps %d (blob K %d, off %zu)\n", b.M, b.N, b.K, b.taps, e.K, off);
+            b.Wx = e.planes + off; b.wx_plane = (long)e.n;
+          }
         }
       }
     }
@@ -903,30 +912,37 @@ int ramp_finalize_weights(ramp_ctx* c) {
     c->gemm_mode = c->cfg.gemm_mode == 1 ? 0 : c->cfg.gemm_mode == 2 ? 1 : (env && std::string(env) == "bf16x6") ? 1 : (env && std::string(env) == "fp32") ? 0 : RAMP_DEFAULT_GEMM_MODE;
   }
   if (c->gemm_mode == 1) {
-    auto reg = [&](const float* w, size_t n) -> int {
+    const char* pe = getenv("RAMP_X6_PIPE");
+    c->x6_pipe = !(pe && pe[0] == '0');
+    auto reg = [&](const float* w, size_t n, int K) -> int {
       if (!w || c->x6.count(w)) return 0;
-      float* p; CK(dev_alloc(c, &p, (3 * n + 1) / 2 + 4));
+      float *p, *q = nullptr;
+      CK(dev_alloc(c, &p, (3 * n + 1) / 2 + 4));
       CK(launch_split3(w, reinterpret_cast<unsigned short*>(p), (long)n, 0));
-      c->x6[w] = {reinterpret_cast<unsigned short*>(p), n};
+      if (n % K == 0 && (n / K) % 32 == 0 && K % 16 == 0) {
+        CK(dev_alloc(c, &q, (3 * n + 1) / 2 + 4));
+        CK(launch_pack_x6(w, reinterpret_cast<unsigned short*>(q), (long)(n / K), K, 0));
+      }
+      c->x6[w] = {reinterpret_cast<unsigned short*>(p), n, K, reinterpret_cast<unsigned short*>(q)};
       return 0;
     };
     for (auto& r : c->rtbs) {
-      if (!r.first) { CK(reg(r.c1.fwd, 5ul * r.cin * r.cout)); CK(reg(r.c1.bwd, 5ul * r.cin * r.cout)); }
-      CK(reg(r.c2.fwd, 5ul * r.cout * r.cout)); CK(reg(r.c2.bwd, 5ul * r.cout * r.cout));
-      if (r.has_res && !r.first) { CK(reg(r.res_f, (size_t)r.cin * r.cout)); CK(reg(r.res_b, (size_t)r.cin * r.cout)); }
+      if (!r.first) { CK(reg(r.c1.fwd, 5ul * r.cin * r.cout, r.cin)); CK(reg(r.c1.bwd, 5ul * r.cin * r.cout, r.cout)); }
+      CK(reg(r.c2.fwd, 5ul * r.cout * r.cout, r.cout)); CK(reg(r.c2.bwd, 5ul * r.cout * r.cout, r.cout));
+      if (r.has_res && !r.first) { CK(reg(r.res_f, (size_t)r.cin * r.cout, r.cin)); CK(reg(r.res_b, (size_t)r.cin * r.cout, r.cout)); }
     }
     for (auto& st : c->sts) {
-      CK(reg(st.wpi_f, 256ul * st.C)); CK(reg(st.wpi_b, 256ul * st.C));
-      CK(reg(st.wpo_f, 256ul * st.C)); CK(reg(st.wpo_b, 256ul * st.C));
+      CK(reg(st.wpi_f, 256ul * st.C, st.C)); CK(reg(st.wpi_b, 256ul * st.C, 256));
+      CK(reg(st.wpo_f, 256ul * st.C, 256)); CK(reg(st.wpo_b, 256ul * st.C, st.C));
       for (auto& k : st.blk) {
-        CK(reg(k.wqkv_f, 768ul * 256)); CK(reg(k.wqkv_b, 768ul * 256));
-        CK(reg(k.wo_f, 256ul * 256)); CK(reg(k.wo_b, 256ul * 256));
-        CK(reg(k.w1_pk, 2048ul * 256)); CK(reg(k.w1_b, 2048ul * 256));
-        CK(reg(k.w2_f, 1024ul * 256)); CK(reg(k.w2_b, 1024ul * 256));
+        CK(reg(k.wqkv_f, 768ul * 256, 256)); CK(reg(k.wqkv_b, 768ul * 256, 768));
+        CK(reg(k.wo_f, 256ul * 256, 256)); CK(reg(k.wo_b, 256ul * 256, 256));
+        CK(reg(k.w1_pk, 2048ul * 256, 256)); CK(reg(k.w1_b, 2048ul * 256, 2048));
+        CK(reg(k.w2_f, 1024ul * 256, 1024)); CK(reg(k.w2_b, 1024ul * 256, 256));
       }
     }
-    for (auto& d : c->downs) { CK(reg(d.w_f, 3ul * d.C * d.C)); CK(reg(d.w_b, 3ul * d.C * d.C)); }
-    for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C)); CK(reg(u.w_b, 4ul * u.C * u.C)); }
+    for (auto& d : c->downs) { CK(reg(d.w_f, 3ul * d.C * d.C, d.C)); CK(reg(d.w_b, 3ul * d.C * d.C, d.C)); }
+    for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C, u.C)); CK(reg(u.w_b, 4ul * u.C * u.C, u.C)); }
   }
   RAMP_HIP_CHECK(hipDeviceSynchronize());
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
@@ -1220,8 +1236,14 @@ int ramp_op_gemm(const float* A, const float* W, const float* bias, const float*
       RAMP_HIP_CHECK(hipMalloc(&p, 3 * n * sizeof(unsigned short)));
       it = cache.emplace(W, p).first;
     }
-    if (int rc = launch_split3(W, it->second, n, as_stream(stream))) return rc;
-    a.Wx = it->second; a.wx_plane = n;
+    const char* pe = getenv("RAMP_X6_PIPE");
+    if (!(pe && pe[0] == '0') && N % 32 == 0 && K % 16 == 0) {
+      if (int rc = launch_pack_x6(W, it->second, (long)taps * N, K, as_stream(stream))) return rc;
+      a.Wx = it->second; a.wx_packed = 1;
+    } else {
+      if (int rc = launch_split3(W, it->second, n, as_stream(stream))) return rc;
+      a.Wx = it->second; a.wx_plane = n;
+    }
   }
   return launch_gemm(a, as_stream(stream));
 }

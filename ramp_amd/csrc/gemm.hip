@@ -40,24 +40,32 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // Accumulators -> LDS -> coalesced float4 rows, with the fused epilogue math.  The caller guarantees that no
 // wave still reads operand tiles from `smem` (a barrier precedes the call); ends with the C tile fully consumed
 // by this thread's own reads only (the caller issues the next barrier before reusing `smem`).
-template <int WM, int WN, int MI, int NI, int EPI, bool GEN>
+// HALVES = WM: the C image holds one wave-row (MI * 32 tile rows) at a time (the pipelined x6 kernel lends it
+// only one operand buffer); the caller then needs no barrier before the call but one after it.
+template <int WM, int WN, int MI, int NI, int EPI, bool GEN, int HALVES = 1>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[MI][NI], float* smem, int tile, int tiles_n,
                                          int tid, int wm, int wn, int r, int h) {
-  constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
+  static_assert(HALVES == 1 || HALVES == WM, "C image: whole tile or one wave-row at a time");
+  constexpr int BMT = WM * MI * 32, BM = BMT / HALVES, BN = WN * NI * 32, NT = WM * WN * 64;
   constexpr int CLD = BN + 4;
   // ---------------- epilogue: accumulators -> LDS -> coalesced float4 rows ----------------
   const int tile_m = tile / tiles_n;
-  const int m0 = tile_m * BM, n0 = (tile - tile_m * tiles_n) * BN;
+  const int n0 = (tile - tile_m * tiles_n) * BN;
   float* Cs = smem;
+#pragma unroll 1
+  for (int g = 0; g < HALVES; ++g) {
+  const int m0 = tile_m * BMT + g * BM;
+  if (HALVES == 1 || wm == g) {
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int row = wm * MI * 32 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int row = (HALVES == 1 ? wm * MI * 32 : 0) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         Cs[row * CLD + wn * NI * 32 + ni * 32 + r] = acc[mi][ni][reg];
       }
+  }
   __syncthreads();
   if (EPI == EPI_LINEAR || EPI == EPI_GEGLU_BWD) {
     constexpr int C4N = BN / 4, RP = NT / C4N, PASSES = BM / RP;
@@ -125,6 +133,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[MI][NI
         *reinterpret_cast<f32x4*>(a.aux_out + (long)m * a.ld_aux + j) = hv;
       }
     }
+  }
+  if (HALVES > 1) __syncthreads();      // the image is reused by the next half / by the caller's operand stores
   }
 }
 
@@ -520,6 +530,274 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// bf16x6, software-pipelined: the weight fragments never touch LDS.
+//
+// The weight planes are pre-packed in MFMA-fragment order ([row/32][k/16][plane][lane][8 bf16], launch_pack_x6),
+// so one wave fetches the B operand of a 32x32x16 step with a single fully coalesced 16-byte-per-lane global load
+// straight into the registers the MFMA reads (the two waves that share the columns hit the same L1/L2 lines).
+// Only the activations go through LDS (they are split into their three planes once, by the staging thread):
+// two 24 KB buffers, ONE barrier per 32-wide K slab in the middle of the slab:
+//   step 0 of slab s : MFMAs(s, k16 0)  ||  W(s, k16 1) -> regs, A frags (s, k16 1) <- LDS, split + store slab s+1 -> other buffer
+//   barrier
+//   step 1 of slab s : MFMAs(s, k16 1)  ||  W(s+1, k16 0) -> regs, A frags (s+1, k16 0) <- LDS, global A loads of slab s+2
+// so every global / LDS access of a wave is issued one k16 step (24 MFMAs) before its consumer.
+template <int EPI, bool GEN>
+__global__ __launch_bounds__(256)
+void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
+  constexpr int WM = 2, WN = 2, MI = 2, NI = 2;
+  constexpr int BM = 128, BN = 128;
+  constexpr int AI = 4;                               // fp32 float4 loads per thread (A)
+  constexpr int PLANE = BM * XLD;                     // bf16 elements per LDS plane
+  constexpr int BUF = 3 * PLANE;                      // one A buffer: 3 planes
+  // LDS: [margin | buffer 0 | buffer 1 | margin]; a half-tile C image (64 x 132 floats) = one buffer + one margin
+  constexpr int C_IMG = 64 * (BN + 4) * 4;            // bytes
+  constexpr int MARGIN = C_IMG - BUF * 2;             // bytes
+  static_assert(MARGIN > 0 && MARGIN % 16 == 0, "C image must cover a buffer");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* Ax = reinterpret_cast<unsigned short*>(smem) + MARGIN / 2;   // [2][3][BM][XLD]
+
+  const int bid = blockIdx.x, nb = gridDim.x;
+  const int xcd = bid & 7, slot = bid >> 3, bpx = nb >> 3;
+  const long xlo = (long)xcd * n_tiles / 8, xhi = (long)(xcd + 1) * n_tiles / 8;
+  const int t_begin = (int)xlo + slot, t_end = (int)xhi, t_step = bpx;
+  if (t_begin >= t_end) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int c4 = tid & 7, r0 = tid >> 3;              // A staging: float4 column / first row (rows r0 + 32 i)
+
+  const int nk = a.K / BK;
+  const int total = GEN ? a.taps * nk : nk;
+  const int nk16 = a.K / 16;
+  const long tap_blocks = (long)(a.N / 32) * nk16;    // fragment blocks per tap
+
+  // ---- A loader (runs one slab ahead of the LDS stores, across tile boundaries) -------------------
+  int ld_tile = t_begin, ld_it = 0;
+  const float* ap[AI];
+  int a_l[GEN ? AI : 1]; long a_m[GEN ? AI : 1];
+  const int Lin = GEN ? a.L * a.a_stride : 0;
+  auto setup_rows = [&](int tile) {
+    const int tile_m = tile / tiles_n;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int m = tile_m * BM + r0 + 32 * i;
+      if (!GEN) {
+        m = m < a.M ? m : a.M - 1;
+        ap[i] = a.A + (long)m * a.lda + c4 * 4;
+      } else {
+        const bool mv = m < a.M;
+        m = mv ? m : 0;
+        const int seg = m / a.L, l = m - seg * a.L;
+        a_l[i] = mv ? l * a.a_stride : -(1 << 28);
+        a_m[i] = (long)seg * Lin + l * a.a_stride;
+      }
+    }
+  };
+  f32x4 ra[AI];
+  auto load_tile = [&]() {
+    if (!GEN) {
+      const int k0 = ld_it * BK;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+    } else {
+      const int tap = ld_it / nk;
+      const int k0 = (ld_it - tap * nk) * BK;
+      const int sh = a.shift0 + tap * a.shift_step;
+      const bool src1 = k0 < a.K1;                     // branch-free: the loader sits inside the MFMA stream
+      const float* Ab = src1 ? a.A : a.A2;
+      const int ld = src1 ? a.lda : a.lda2, kc = src1 ? k0 : k0 - a.K1;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int l = a_l[i] + sh;
+        const bool ok = l >= 0 && l < Lin;
+        const long row = ok ? a_m[i] + sh : a_m[i];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Ab + row * ld + kc + c4 * 4);
+        ra[i] = ok ? v : f32x4{0, 0, 0, 0};
+      }
+    }
+  };
+  auto store_tile = [&](unsigned short* dst) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      u32x2 p1, p2, p3;
+      split3(ra[i], p1, p2, p3);
+      const int rowa = r0 + 32 * i;
+      const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
+      *reinterpret_cast<u32x2*>(dst + off) = p1;
+      *reinterpret_cast<u32x2*>(dst + PLANE + off) = p2;
+      *reinterpret_cast<u32x2*>(dst + 2 * PLANE + off) = p3;
+    }
+  };
+  auto advance_loader = [&]() {
+    if (++ld_it == total) {
+      ld_it = 0;
+      if (ld_tile + t_step < t_end) { ld_tile += t_step; setup_rows(ld_tile); }
+    }
+  };
+
+  // ---- W fragments: straight from the packed planes ----------------------------------------------
+  const unsigned short* wl = a.Wx + lane * 8;
+  auto w_blocks = [&](int tile, long (&blk)[NI]) {      // first fragment block of this wave's two 32-column groups
+    const int tile_m = tile / tiles_n;
+    const int n0 = (tile - tile_m * tiles_n) * BN + wn * 64;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      int n = n0 + ni * 32;
+      n = n <= a.N - 32 ? n : a.N - 32;                  // columns past N only feed outputs that are never stored
+      blk[ni] = (long)(n >> 5) * nk16;
+    }
+  };
+  auto load_w = [&](bf16x8 (&dst)[3][NI], const long (&blk)[NI], int it, int s2) {
+    long kb;
+    if (!GEN) kb = 2 * it + s2;
+    else { const int tap = it / nk; kb = tap * tap_blocks + 2 * (it - tap * nk) + s2; }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const unsigned short* q = wl + (blk[ni] + kb) * 1536;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[p][ni] = *reinterpret_cast<const bf16x8*>(q + p * 512);
+    }
+  };
+
+  const int r = lane & 31, h = lane >> 5;
+  const int arow = (wm * 64 + r) * XLD;
+  const int sw = (r >> 2) & 3;
+  auto read_a = [&](bf16x8 (&dst)[3][MI], const unsigned short* src, int s2) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        dst[p][mi] = *reinterpret_cast<const bf16x8*>(src + p * PLANE + arow + mi * 32 * XLD + (((2 * s2 + h) ^ sw) << 3));
+  };
+
+  bf16x8 av[2][3][MI], bw[2][3][NI];
+  long wblk[NI], wnext[NI];
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+
+  // prologue: slab 0 of the first tile -> buffer 0, slab 1 parked in registers, first fragments in flight
+  setup_rows(ld_tile);
+  load_tile();
+  w_blocks(t_begin, wblk);
+  load_w(bw[0], wblk, 0, 0);
+  store_tile(Ax);
+  advance_loader();
+  load_tile();
+  __syncthreads();
+  read_a(av[0], Ax, 0);
+
+  int parity = 0;
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    if (tile + t_step < t_end) w_blocks(tile + t_step, wnext);
+    else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wnext[ni] = wblk[ni];
+    }
+    for (int it = 0; it < total; ++it) {
+      // ---- slab boundary (scheduling-region boundary): uniform bookkeeping only
+      advance_loader();                                  // the A loader now points at slab it + 2
+      const bool last = it + 1 == total;
+      const int it_next = last ? 0 : it + 1;
+      long wsel[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wsel[ni] = last ? wnext[ni] : wblk[ni];
+      unsigned short* cur = Ax + parity * BUF;
+      unsigned short* oth = Ax + (parity ^ 1) * BUF;
+
+      // Hand-interleaved issue order, pinned with sched_barrier(0): every MFMA is followed by a small piece of the
+      // staging work of the NEXT step (one fragment load pair, or one plane of one float4 of the split), so a
+      // single wave keeps the matrix pipe fed while its own loads / VALU / LDS stores issue in the gaps.
+      // ---- step 0: MFMAs (slab, k16 0)  ||  W (slab, k16 1), A frags (slab, k16 1), split + store of the next slab
+      {
+        const long kb = GEN ? (long)(it / nk) * tap_blocks + 2 * (it % nk) + 1 : 2 * it + 1;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+          acc[(j >> 1) & 1][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][PA[j >> 2]][(j >> 1) & 1], bw[0][PB[j >> 2]][j & 1],
+                                                                             acc[(j >> 1) & 1][j & 1], 0, 0, 0);
+          if (j < 6) {
+            const int p = j >> 1, x = j & 1;
+            bw[1][p][x] = *reinterpret_cast<const bf16x8*>(wl + (wblk[x] + kb) * 1536 + p * 512);
+            av[1][p][x] = *reinterpret_cast<const bf16x8*>(cur + p * PLANE + arow + x * 32 * XLD + (((2 + h) ^ sw) << 3));
+          } else if (j < 18) {
+            const int i = (j - 6) / 3, st = (j - 6) % 3;
+            const int rowa = r0 + 32 * i;
+            const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
+            const unsigned q0 = pk_bf16(ra[i][0], ra[i][1]), q1 = pk_bf16(ra[i][2], ra[i][3]);
+            *reinterpret_cast<u32x2*>(oth + st * PLANE + off) = u32x2{q0, q1};
+            if (st < 2) {
+              ra[i][0] -= __builtin_bit_cast(float, q0 << 16);
+              ra[i][1] -= __builtin_bit_cast(float, q0 & 0xffff0000u);
+              ra[i][2] -= __builtin_bit_cast(float, q1 << 16);
+              ra[i][3] -= __builtin_bit_cast(float, q1 & 0xffff0000u);
+            }
+          } else if (j == 18) {
+            load_tile();                               // global A loads two slabs ahead, as early as ra is free
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      // ---- step 1: MFMAs (slab, k16 1)  ||  W / A frags of (next slab, k16 0), global A loads two slabs ahead
+      {
+        const long kb = GEN ? (long)(it_next / nk) * tap_blocks + 2 * (it_next % nk) : 2 * it_next;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+          acc[(j >> 1) & 1][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][PA[j >> 2]][(j >> 1) & 1], bw[1][PB[j >> 2]][j & 1],
+                                                                             acc[(j >> 1) & 1][j & 1], 0, 0, 0);
+          if (j < 6) {
+            const int p = j >> 1, x = j & 1;
+            bw[0][p][x] = *reinterpret_cast<const bf16x8*>(wl + (wsel[x] + kb) * 1536 + p * 512);
+            av[0][p][x] = *reinterpret_cast<const bf16x8*>(oth + p * PLANE + arow + x * 32 * XLD + ((h ^ sw) << 3));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      parity ^= 1;
+    }
+    // the finished slab's buffer (plus its 9 KB margin) carries the C image, one wave-row at a time; the other
+    // buffer already holds slab 0 of the next tile
+    epilogue<WM, WN, MI, NI, EPI, GEN, WM>(a, acc, smem + (parity ^ 1) * (C_IMG / 4), tile, tiles_n, tid, wm, wn, r, h);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wblk[ni] = wnext[ni];
+  }
+}
+
+// fp32 [rows][K] -> fragment-packed bf16 planes [rows/32][K/16][3][64 lanes][8]
+__global__ void pack_x6_kernel(const float* __restrict__ W, unsigned short* __restrict__ out, long rows, int K) {
+  const int k8n = K / 8;
+  const long total = rows * k8n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / k8n;
+    const int k8 = (int)(i - row * k8n);
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8 + 4);
+    u32x2 a1, a2, a3, b1, b2, b3;
+    split3(lo, a1, a2, a3);
+    split3(hi, b1, b2, b3);
+    const long blk = (row >> 5) * (K / 16) + (k8 >> 1);
+    unsigned short* q = out + blk * 1536 + (((k8 & 1) * 32 + (int)(row & 31)) << 3);
+    *reinterpret_cast<u32x4*>(q) = u32x4{a1[0], a1[1], b1[0], b1[1]};
+    *reinterpret_cast<u32x4*>(q + 512) = u32x4{a2[0], a2[1], b2[0], b2[1]};
+    *reinterpret_cast<u32x4*>(q + 1024) = u32x4{a3[0], a3[1], b3[0], b3[1]};
+  }
+}
+int launch_pack_x6(const float* W, unsigned short* out, long rows, int K, hipStream_t s) {
+  RAMP_REQUIRE(rows > 0 && rows % 32 == 0 && K > 0 && K % 16 == 0, "pack_x6 needs rows % 32 == 0 and K % 16 == 0");
+  const long total = rows * (K / 8);
+  hipLaunchKernelGGL(pack_x6_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, W, out, rows, K);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+
 constexpr size_t X6_LDS = std::max<size_t>(6 * (size_t)128 * XLD * 2, (size_t)128 * 132 * 4);
 
 template <int EPI, bool GEN>
@@ -529,13 +807,16 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
   const int slots = 512;
   const int rounds = (n_tiles + slots - 1) / slots;
   const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
-  hipLaunchKernelGGL((gemm_x6_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
+  if (a.wx_packed) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
+  else hipLaunchKernelGGL((gemm_x6_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }
 template <int EPI, bool GEN>
 static int set_attr_x6() {
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<EPI, GEN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI, GEN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
   return 0;
 }
@@ -597,7 +878,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const bool gen = a.taps > 1 || a.a_stride != 1 || a.c_rstride != 1 || a.c_roff != 0 || a.A2 || a.C2 || a.resid2 ||
                    a.shift0 != 0;
   const bool x6 = a.Wx != nullptr && a.N >= 128;
-  RAMP_REQUIRE(!x6 || (al16(a.Wx) && a.K % 8 == 0 && a.wx_plane > 0), "bad bf16x6 weight planes");
+  RAMP_REQUIRE(!x6 || (al16(a.Wx) && a.K % 8 == 0 && (a.wx_packed ? a.N % 32 == 0 : a.wx_plane > 0)), "bad bf16x6 weight planes");
   if (a.epi == EPI_GEGLU_FWD) {
     RAMP_REQUIRE(!gen && a.N % 256 == 0 && a.aux_out && !a.resid && !a.rowbias,
                  "GEGLU-forward epilogue needs a plain linear with N % 256 == 0 and aux_out");

@@ -1,0 +1,60 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE CSVs of score_pmc.py into per-kernel-class HBM traffic.
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane coalesced reads
+(MI355X_MICROARCH.md, HBM section), so reads are doubled: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+Only the LAST score pass is counted (dispatches after the midpoint marker = second half of the dispatch list).
+"""
+import csv
+import glob
+import json
+import sys
+
+
+def klass(name):
+    if "gemm_x6_kernel" in name or "gemm_kernel" in name:
+        return "gemm_f32_mfma"
+    if "attn2" in name:
+        return "attention"
+    if "gn_" in name or "ln_" in name:
+        return "norm_rows"
+    if "ramp::" in name:
+        return "other_ramp"
+    return None
+
+
+def load(d, counter):
+    rows = []
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] == counter and klass(r["Kernel_Name"]):
+                    rows.append((int(r["Dispatch_Id"]), klass(r["Kernel_Name"]), float(r["Counter_Value"]),
+                                 int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows.sort()
+    return rows[len(rows) // 2:]          # second of the two identical passes
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    res = {}
+    for d, counter, scale in ((fetch, "FETCH_SIZE", 2.0), (write, "WRITE_SIZE", 1.0)):
+        for _, k, v, _ in load(d, counter):
+            e = res.setdefault(k, {"launches": {}, "read_bytes": 0.0, "write_bytes": 0.0})
+            e["launches"][counter] = e["launches"].get(counter, 0) + 1
+            e["read_bytes" if counter == "FETCH_SIZE" else "write_bytes"] += v * 1024.0 * scale
+    for k, e in res.items():
+        n = max(e["launches"].values())
+        assert len(set(e["launches"].values())) == 1, e["launches"]
+        e["launches"] = n
+        e["hbm_bytes"] = e["read_bytes"] + e["write_bytes"]
+        e["hbm_bytes_per_launch"] = e["hbm_bytes"] / n
+    res["_note"] = ("one score evaluation (forward + dX backward) of the headline workload, B=4096 trajectories = 8192 "
+                    "network rows; read bytes = 2 x FETCH_SIZE KiB (gfx950 correction), write bytes = WRITE_SIZE KiB; "
+                    "counters collected in separate --pmc passes")
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps({k: (v if isinstance(v, str) else {kk: round(vv) for kk, vv in v.items()}) for k, v in res.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
