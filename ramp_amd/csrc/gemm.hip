@@ -55,6 +55,39 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[MI][NI
 #pragma unroll 1
   for (int g = 0; g < HALVES; ++g) {
   const int m0 = tile_m * BMT + g * BM;
+  // The global operands of the fused math (residual rows / GEGLU stash) do not depend on the C image: the first
+  // chunk is requested BEFORE the accumulators go through LDS, so its HBM latency hides behind the transpose.
+  constexpr int C4N = BN / 4, RP = NT / C4N, PASSES = BM / RP;
+  constexpr int CHMAX = EPI == EPI_GEGLU_BWD ? 4 : 8;
+  constexpr int CH = PASSES < CHMAX ? PASSES : CHMAX;
+  static_assert(PASSES % CH == 0, "epilogue chunking");
+  const int cc = tid % C4N, rr = tid / C4N;
+  const int n = n0 + cc * 4;
+  const bool nok = n < a.N;
+  const int nc = nok ? n : 0;
+  f32x4 pre0[CH], pre1[EPI == EPI_GEGLU_BWD ? CH : 1];
+  auto prefetch = [&](int c0) {
+    if (EPI == EPI_LINEAR) {
+      if (a.resid) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          const int m = m0 + (c0 + q) * RP + rr;
+          const int mc = m < a.M ? m : 0;
+          const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
+          pre0[q] = *reinterpret_cast<const f32x4*>(a.resid + orow * a.ldr + nc);
+        }
+      }
+    } else if (EPI == EPI_GEGLU_BWD) {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int m = m0 + (c0 + q) * RP + rr;
+        const int mc = m < a.M ? m : 0;
+        pre0[q] = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + nc);
+        pre1[q] = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + a.N + nc);
+      }
+    }
+  };
+  prefetch(0);
   if (HALVES == 1 || wm == g) {
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -68,37 +101,34 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[MI][NI
   }
   __syncthreads();
   if (EPI == EPI_LINEAR || EPI == EPI_GEGLU_BWD) {
-    constexpr int C4N = BN / 4, RP = NT / C4N, PASSES = BM / RP;
-    const int cc = tid % C4N, rr = tid / C4N;
-    const int n = n0 + cc * 4;
-    const bool nok = n < a.N;
-    const int nc = nok ? n : 0;
     f32x4 b4 = {0, 0, 0, 0};
     if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + nc);
-#pragma unroll 4
-    for (int p = 0; p < PASSES; ++p) {
-      const int row = p * RP + rr;
-      const int m = m0 + row;
-      const bool ok = nok && m < a.M;
-      const int mc = m < a.M ? m : 0;
-      const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
-      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + b4;
-      if (EPI == EPI_LINEAR) {
-        if (a.rowbias) v += *reinterpret_cast<const f32x4*>(a.rowbias + (long)a.rowvar[a.row0 + mc / a.L] * a.rb_stride + nc);
-        if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + orow * a.ldr + nc);
-        if (GEN && a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + orow * a.ldr2 + nc);
-        if (ok) {
-          if (!GEN || n < a.N1) *reinterpret_cast<f32x4*>(a.C + orow * a.ldc + n) = v;
-          else *reinterpret_cast<f32x4*>(a.C2 + orow * a.ldc2 + (n - a.N1)) = v;
-        }
-      } else {
-        // v = d(hg)[m][n]; the forward stashed s = [gelu(g) | a * gelu'(g)] (n_tok, 2N): d(ag) = [v * s1 | v * s2]
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + nc);
-        const f32x4 s2 = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + a.N + nc);
-        const f32x4 da = v * s1, dg = v * s2;
-        if (ok) {
-          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + n) = da;
-          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + a.N + n) = dg;
+#pragma unroll 1
+    for (int c0 = 0; c0 < PASSES; c0 += CH) {
+      if (c0) prefetch(c0);
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int row = (c0 + q) * RP + rr;
+        const int m = m0 + row;
+        const bool ok = nok && m < a.M;
+        const int mc = m < a.M ? m : 0;
+        const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + b4;
+        if (EPI == EPI_LINEAR) {
+          if (a.rowbias) v += *reinterpret_cast<const f32x4*>(a.rowbias + (long)a.rowvar[a.row0 + mc / a.L] * a.rb_stride + nc);
+          if (a.resid) v += pre0[q];
+          if (GEN && a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + orow * a.ldr2 + nc);
+          if (ok) {
+            if (!GEN || n < a.N1) *reinterpret_cast<f32x4*>(a.C + orow * a.ldc + n) = v;
+            else *reinterpret_cast<f32x4*>(a.C2 + orow * a.ldc2 + (n - a.N1)) = v;
+          }
+        } else {
+          // v = d(hg)[m][n]; the forward stashed s = [gelu(g) | a * gelu'(g)] (n_tok, 2N): d(ag) = [v * s1 | v * s2]
+          const f32x4 da = v * pre0[q], dg = v * pre1[q];
+          if (ok) {
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + n) = da;
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + a.N + n) = dg;
+          }
         }
       }
     }
