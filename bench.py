@@ -107,6 +107,16 @@ def profile_gemm(dm, B, cloud, hard_conds):
     return {n: {"ms": ms[i], "flops": fl[i], "launches": int(cnt[i])} for i, n in enumerate(names)}
 
 
+def pmc_traffic(klass):
+    """Per-launch HBM traffic of a kernel class from the committed PMC summary (counters need their own passes)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return float(json.load(fh)[klass]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(sd, cloud_np, n_traj):
     """The oracle (numpy restatement of the reference algorithm) on the host cores, bounded sample."""
     from oracle import ramp_oracle as O
@@ -204,8 +214,11 @@ def main():
         total_ms = sum(v["ms"] for v in prof.values())
         result["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-            "kernel": "ramp::gemm_x6_kernel<*> + gemm_kernel<*> (linears + k5/k1/stride-2 convs, fwd and dX)",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic("gemm_f32_mfma"),
+            "traffic_note": "HBM-side bytes per GEMM launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc "
+                            "passes over one score evaluation of this workload (profiles/r01_pmc_traffic.json, "
+                            "ramp_amd/tools/score_pmc.py + pmc_summary.py); not collected inside this run",
+            "kernel": "ramp::gemm_x6p_kernel<*> + gemm_kernel<*> (linears + k5/k1/stride-2 convs, fwd and dX)",
             "peak_note": "peak = fp32 matrix peak (the arithmetic contract is fp32); the bf16x6 kernel executes 6 bf16 "
                          "MFMA products per fp32 product, i.e. 6x the algorithmic FLOPs against the 2500 TFLOP/s bf16 peak",
             "executed_bf16_tflops": 6 * achieved, "frac_of_bf16_peak": 6 * achieved / 2500.0,

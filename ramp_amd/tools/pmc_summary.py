@@ -2,7 +2,7 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane coalesced reads
 (MI355X_MICROARCH.md, HBM section), so reads are doubled: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
-Only the LAST score pass is counted (dispatches after the midpoint marker = second half of the dispatch list).
+Only the LAST score pass is counted (the dispatches between the last two cfg_mean launches).
 """
 import csv
 import glob
@@ -11,7 +11,7 @@ import sys
 
 
 def klass(name):
-    if "gemm_x6_kernel" in name or "gemm_kernel" in name:
+    if "gemm_x6" in name or "gemm_kernel" in name:
         return "gemm_f32_mfma"
     if "attn2" in name:
         return "attention"
@@ -23,15 +23,18 @@ def klass(name):
 
 
 def load(d, counter):
+    """Dispatches of the LAST score pass: those between the last two cfg_mean launches (one ends each pass)."""
     rows = []
     for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         with open(f, newline="") as fh:
             for r in csv.DictReader(fh):
-                if r["Counter_Name"] == counter and klass(r["Kernel_Name"]):
-                    rows.append((int(r["Dispatch_Id"]), klass(r["Kernel_Name"]), float(r["Counter_Value"]),
-                                 int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+                if r["Counter_Name"] == counter and "ramp::" in r["Kernel_Name"]:
+                    rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
     rows.sort()
-    return rows[len(rows) // 2:]          # second of the two identical passes
+    ends = [i for i, r in enumerate(rows) if "cfg_mean" in r[1]]
+    assert len(ends) >= 2, "need two score passes"
+    last = rows[ends[-2] + 1:ends[-1] + 1]
+    return [(i, klass(n), v, 0) for i, n, v in last if klass(n)]
 
 
 def main():
