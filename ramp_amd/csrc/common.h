@@ -42,6 +42,7 @@ struct GemmArgs {
   const float* A2 = nullptr; int lda2 = 0; int K1 = 0;    // K1 == K when A2 unused
   const float* W = nullptr;                                 // [taps][N][K], K contiguous
   const unsigned short* Wx = nullptr; long wx_plane = 0;    // optional bf16x6 planes [3][taps][N][K] (plane stride in elements)
+  const float* Amul = nullptr; int lda_mul = 0; int a_period = 0;   // optional: A_eff[m][k] = A[m][k % a_period] * Amul[m][k]
   int wx_packed = 0;                                        // 1: Wx is fragment-packed [taps*N/32][K/16][3][64][8] (launch_pack_x6)
   const float* bias = nullptr;                              // [N]
   const float* rowbias = nullptr; const int* rowvar = nullptr; int row0 = 0; int rb_stride = 0;  // [n_var][rb_stride]

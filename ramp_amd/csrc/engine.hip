@@ -473,10 +473,19 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx) {
   for (int b = 1; b >= 0; --b) {
     STBlock& k = m.blk[b];
     const float* zin = (b == 0) ? m.a_z0 : m.blk[0].a_z2;
-    GemmArgs w = lin(dz, D, k.w2_b, nullptr, c->t_dag, 2048, M, 1024, D);     // d(hg) -> d(ag) in the epilogue
-    w.epi = EPI_GEGLU_BWD; w.aux_in = k.a_ag; w.ld_aux = 2048;
-    CK(r.gemm(w));
-    CK(r.gemm(lin(c->t_dag, 2048, k.w1_b, nullptr, c->t_dln, D, M, D, 2048)));          // d(ln3)
+    if (c->gemm_mode == 1 && c->x6_pipe) {
+      // d(hg) only (1024 wide); d(ag) = [d(hg) s1 | d(hg) s2] is formed by the next GEMM's operand loader from the
+      // forward stash: the 2048-wide d(ag) never goes to HBM (saves a 2048-float write and a 2048-float read per token)
+      CK(r.gemm(lin(dz, D, k.w2_b, nullptr, c->t_hg, 1024, M, 1024, D)));
+      GemmArgs v = lin(c->t_hg, 1024, k.w1_b, nullptr, c->t_dln, D, M, D, 2048);         // d(ln3)
+      v.Amul = k.a_ag; v.lda_mul = 2048; v.a_period = 1024;
+      CK(r.gemm(v));
+    } else {
+      GemmArgs w = lin(dz, D, k.w2_b, nullptr, c->t_dag, 2048, M, 1024, D);   // d(hg) -> d(ag) in the epilogue
+      w.epi = EPI_GEGLU_BWD; w.aux_in = k.a_ag; w.ld_aux = 2048;
+      CK(r.gemm(w));
+      CK(r.gemm(lin(c->t_dag, 2048, k.w1_b, nullptr, c->t_dln, D, M, D, 2048)));        // d(ln3)
+    }
     LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, k.a_z1, k.ln3_g, dz, dz1, M, r.s));         // dz1
     CK(r.gemm(lin(dz1, D, k.wo_b, nullptr, c->t_o, D, M, D, D)));                       // d(o)
     LAUNCH(c, r.s, CAT_ATTN, 32.0 * R * m.L * m.L * 64, launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, R, m.L, r.s));

@@ -589,7 +589,9 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 //   barrier
 //   step 1 of slab s : MFMAs(s, k16 1)  ||  W(s+1, k16 0) -> regs, A frags (s+1, k16 0) <- LDS, global A loads of slab s+2
 // so every global / LDS access of a wave is issued one k16 step (24 MFMAs) before its consumer.
-template <int EPI, bool GEN>
+// AMUL: A_eff[m][k] = A[m][k % a_period] * Amul[m][k] (the GEGLU VJP d(ag) = [d(hg) s1 | d(hg) s2] formed while the
+// operand is staged, instead of a 2048-wide d(ag) round trip through HBM).
+template <int EPI, bool GEN, bool AMUL = false>
 __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   constexpr int WM = 2, WN = 2, MI = 2, NI = 2;
@@ -623,6 +625,7 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   // ---- A loader (runs one slab ahead of the LDS stores, across tile boundaries) -------------------
   int ld_tile = t_begin, ld_it = 0;
   const float* ap[AI];
+  const float* sp[AMUL ? AI : 1];
   int a_l[GEN ? AI : 1]; long a_m[GEN ? AI : 1];
   const int Lin = GEN ? a.L * a.a_stride : 0;
   auto setup_rows = [&](int tile) {
@@ -633,6 +636,7 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
       if (!GEN) {
         m = m < a.M ? m : a.M - 1;
         ap[i] = a.A + (long)m * a.lda + c4 * 4;
+        if (AMUL) sp[i] = a.Amul + (long)m * a.lda_mul + c4 * 4;
       } else {
         const bool mv = m < a.M;
         m = mv ? m : 0;
@@ -643,11 +647,19 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
     }
   };
   f32x4 ra[AI];
+  f32x4 rs[AMUL ? AI : 1];
   auto load_tile = [&]() {
     if (!GEN) {
       const int k0 = ld_it * BK;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+      for (int i = 0; i < AI; ++i) {
+        if (AMUL) {
+          ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0 % a.a_period);
+          rs[i] = *reinterpret_cast<const f32x4*>(sp[i] + k0);
+        } else {
+          ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+        }
+      }
     } else {
       const int tap = ld_it / nk;
       const int k0 = (ld_it - tap * nk) * BK;
@@ -669,7 +681,7 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       u32x2 p1, p2, p3;
-      split3(ra[i], p1, p2, p3);
+      split3(AMUL ? ra[i] * rs[i] : ra[i], p1, p2, p3);
       const int rowa = r0 + 32 * i;
       const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
       *reinterpret_cast<u32x2*>(dst + off) = p1;
@@ -775,6 +787,7 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
             av[1][p][x] = *reinterpret_cast<const bf16x8*>(cur + p * PLANE + arow + x * 32 * XLD + (((2 + h) ^ sw) << 3));
           } else if (j < 18) {
             const int i = (j - 6) / 3, st = (j - 6) % 3;
+            if (AMUL && st == 0) ra[i] *= rs[i];
             const int rowa = r0 + 32 * i;
             const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
             const unsigned q0 = pk_bf16(ra[i][0], ra[i][1]), q1 = pk_bf16(ra[i][2], ra[i][3]);
@@ -854,7 +867,10 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
   const int slots = 512;
   const int rounds = (n_tiles + slots - 1) / slots;
   const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
-  if (a.wx_packed) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
+  if (a.wx_packed && a.Amul) {
+    RAMP_REQUIRE(EPI == EPI_LINEAR && !GEN && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
+    hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
+  } else if (a.wx_packed) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
   else hipLaunchKernelGGL((gemm_x6_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
@@ -900,6 +916,8 @@ int init_gemm_attributes() {
   if (int e = set_attr<2, 2, 2, 2, EPI_GEGLU_BWD, false>()) return e;
   if (int e = set_attr<2, 2, 2, 1, EPI_LINEAR, true>()) return e;
   if (int e = set_attr<4, 1, 1, 1, EPI_LINEAR, true>()) return e;
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI_LINEAR, false, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
   if (int e = set_attr_x6<EPI_LINEAR, false>()) return e;
   if (int e = set_attr_x6<EPI_LINEAR, true>()) return e;
   if (int e = set_attr_x6<EPI_GEGLU_FWD, false>()) return e;
@@ -925,6 +943,8 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const bool gen = a.taps > 1 || a.a_stride != 1 || a.c_rstride != 1 || a.c_roff != 0 || a.A2 || a.C2 || a.resid2 ||
                    a.shift0 != 0;
   const bool x6 = a.Wx != nullptr && a.N >= 128;
+  RAMP_REQUIRE(a.Amul == nullptr || (x6 && a.wx_packed && !gen && a.epi == EPI_LINEAR && al16(a.Amul)),
+               "the A-multiplier operand needs the pipelined bf16x6 kernel");
   RAMP_REQUIRE(!x6 || (al16(a.Wx) && a.K % 8 == 0 && (a.wx_packed ? a.N % 32 == 0 : a.wx_plane > 0)), "bad bf16x6 weight planes");
   if (a.epi == EPI_GEGLU_FWD) {
     RAMP_REQUIRE(!gen && a.N % 256 == 0 && a.aux_out && !a.resid && !a.rowbias,

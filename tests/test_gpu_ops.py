@@ -24,11 +24,19 @@ def rng(seed):
 @pytest.mark.parametrize("M,N,K,taps,L", [
     (96, 256, 256, 1, 1), (1000, 768, 256, 1, 1), (333, 2048, 256, 1, 1), (257, 256, 1024, 1, 1),
     (48 * 5, 32, 32, 5, 48), (24 * 7, 64, 32, 5, 24), (6 * 11, 128, 512, 5, 6), (12 * 9, 64, 128, 5, 12),
-    (130, 32, 256, 1, 1), (64 * 3, 32, 32, 5, 64),
+    (130, 32, 256, 1, 1), (64 * 3, 32, 32, 5, 64), (777, 160, 64, 1, 1), (12 * 50, 512, 64, 3, 12), (129, 768, 2048, 1, 1),
+    (48 * 20, 256, 128, 5, 48), (1000, 128, 32, 1, 1),
 ])
 @pytest.mark.parametrize("backward", [False, True])
-def test_gemm_taps(M, N, K, taps, L, backward):
-    """C = sum_tap shift(A) W_tap^T + bias + resid, exact-fp32 MFMA: vs float64 numpy within fp32 rounding."""
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "bf16x6-lds"])
+def test_gemm_taps(M, N, K, taps, L, backward, mode, monkeypatch):
+    """C = sum_tap shift(A) W_tap^T + bias + resid vs float64 numpy within fp32 rounding, in the exact-fp32 MFMA mode,
+    the pipelined bf16x6 mode (fragment-packed weights) and its LDS-staged predecessor (N < 128 always runs fp32)."""
+    if mode == "fp32":
+        monkeypatch.delenv("RAMP_GEMM_MODE", raising=False)
+    else:
+        monkeypatch.setenv("RAMP_GEMM_MODE", "bf16x6")
+        monkeypatch.setenv("RAMP_X6_PIPE", "1" if mode == "bf16x6" else "0")
     g = rng(M + N + K)
     A = g.standard_normal((M, K), dtype=np.float32)
     W = (g.standard_normal((taps, N, K), dtype=np.float32) / np.sqrt(K * taps)).astype(np.float32)
