@@ -207,6 +207,22 @@ def main():
         "workspace_gb": dm.model.workspace_bytes() / 2 ** 30,
     }
 
+    if rank == 0 and not WL["o3"]:
+        # solution quality of the last timed batch, outside the timed region (on-device metrics);
+        # the weights are random, so this only shows that the metric path runs at the benchmark's batch size
+        from ramp_amd.metrics import Metrics
+        boxes = synth.make_boxes(WL["cloud"][0], 2, seed=42)
+        tq = time.perf_counter()
+        mt = Metrics()
+        loc = out[:B].contiguous()
+        ci = mt.compute_collision_intensity(loc, boxes.astype(np.float32), np.full((len(boxes), 2), 0.26, np.float32))
+        q = mt.trajectory_success_and_metrics(loc, ci, threshold=0.01)
+        torch.cuda.synchronize()
+        result["solution_quality"] = {k: q[k] for k in ("success", "collision_intensity", "path_length", "path_length_std",
+                                                         "waypoint_variance", "n_free_trajectories")}
+        result["solution_quality"]["metrics_ms"] = (time.perf_counter() - tq) * 1e3
+        result["solution_quality"]["note"] = "random-init weights: not a planning-quality claim"
+
     if rank == 0 and world == 1 and not args.no_roofline:
         prof = profile_gemm(dm, B, cloud, hard_conds)
         g = prof["gemm_f32_mfma"]

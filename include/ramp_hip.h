@@ -147,6 +147,14 @@ int ramp_hard_cond(float* x, int32_t B, int32_t H, int32_t S, int32_t n, const i
  * mask (B) int32, path_len (B), smooth (B) */
 int ramp_traj_costs(const float* traj, int32_t B, int32_t H, int32_t S, const float* cloud, int32_t n_points,
                     float threshold, int32_t* mask, float* path_len, float* smooth, void* stream);
+/* Metrics.compute_collision_intensity / compute_path_length / compute_smoothness (scripts/inference/core/metrics.py:21-81):
+ * per trajectory, the fraction of waypoints inside any axis-aligned box (centre +- size/2, inclusive), the xy path
+ * length and sum_h |v_{h+1} - v_h| over the state dims >= 2.  box_centers / box_sizes: device (n_boxes, 2). */
+int ramp_traj_metrics(const float* traj, int32_t B, int32_t H, int32_t S, const float* box_centers, const float* box_sizes,
+                      int32_t n_boxes, float* intensity, float* path_len, float* smooth, void* stream);
+/* Metrics.compute_variance_waypoints (metrics.py:8-19): sum over waypoints of the unbiased variance of all B*B entries
+ * of triu(cdist(p, p), 1).  scratch: device, 2 * H * ceil(B/256) doubles; out: device, 1 double. */
+int ramp_waypoint_variance(const float* traj, int32_t B, int32_t H, int32_t S, double* scratch, double* out, void* stream);
 /* one p_mean_variance evaluation given eps (diffusion_model_static.py:161-172) */
 int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32_t n_rp, double w0, double w1,
                   float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip,

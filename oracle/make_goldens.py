@@ -458,10 +458,42 @@ def gen_replan(m2, sp2):
     save("replan_chain.npz", **arrs)
 
 
+def gen_metrics():
+    """Metrics class of scripts/inference/core/metrics.py on border-hugging trajectories (some inside boxes)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_metrics", os.path.join(REF, "scripts/inference/core/metrics.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    M = mod.Metrics()
+    g = np.random.Generator(np.random.PCG64(77))
+    B, H = 24, 48
+    lin = np.linspace(-0.9, 0.9, H, dtype=np.float32)
+    tr = np.zeros((B, H, 4), np.float32)
+    for b in range(B):
+        tr[b, :, 0] = lin + 0.05 * g.standard_normal(H).astype(np.float32)
+        tr[b, :, 1] = (g.uniform(-1, 1)) * lin + 0.05 * g.standard_normal(H).astype(np.float32) + g.uniform(-0.3, 0.3)
+        tr[b, :, 2:] = 0.3 * g.standard_normal((H, 2)).astype(np.float32)
+    centers = np.array([[-0.3, 0.2], [0.35, -0.25], [0.1, 0.55], [-0.5, -0.5], [0.0, 0.0]], np.float32)
+    sizes = np.array([[0.2, 0.2], [0.16, 0.3], [0.1, 0.1], [0.25, 0.12], [0.08, 0.08]], np.float32)
+    t = torch.from_numpy(tr)
+    ci = M.compute_collision_intensity(t, torch.from_numpy(centers), torch.from_numpy(sizes))
+    res = M.trajectory_success_and_metrics(t, ci, threshold=0.01)
+    arrs = {"traj": tr, "centers": centers, "sizes": sizes, "intensity": ci.numpy(),
+            "path_length": M.compute_path_length(t).numpy(), "smoothness": M.compute_smoothness(t).numpy(),
+            "variance_all": float(M.compute_variance_waypoints(t)),
+            "success": res["success"], "collision_intensity_pct": res["collision_intensity"],
+            "n_free": res["n_free_trajectories"], "free_path_length": np.float64(res["path_length"] or np.nan),
+            "free_path_length_std": np.float64(res["path_length_std"] or np.nan),
+            "free_variance": np.float64(res["waypoint_variance"] if res["waypoint_variance"] is not None else np.nan)}
+    print(f"    metrics: intensity>0 for {(ci > 0).sum().item()} of {B}, n_free {res['n_free_trajectories']}, var {arrs['variance_all']:.6f}")
+    save("metrics_cases.npz", **arrs)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "dynamic":
         m2, sp2, _ = build_unet(4, 48, False)
         gen_dynamic(m2, sp2); return
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        gen_metrics(); return
     if len(sys.argv) > 1 and sys.argv[1] == "replan":
         m2, sp2, _ = build_unet(4, 48, False)
         gen_replan(m2, sp2); return
@@ -485,6 +517,7 @@ def main():
     print("chain 3-D"); gen_chain3d(m3, sp3)
     print("dynamic"); gen_dynamic(m2, sp2)
     print("replan"); gen_replan(m2, sp2)
+    print("metrics"); gen_metrics()
     print("done")
 
 

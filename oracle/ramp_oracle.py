@@ -693,6 +693,30 @@ def trajectory_costs(traj: np.ndarray, cloud: np.ndarray, thr: float, w_smooth=0
     return int(np.argmin(total)), total, free
 
 
+def collision_intensity(traj: np.ndarray, box_centers: np.ndarray, box_sizes: np.ndarray) -> np.ndarray:
+    """scripts/inference/core/metrics.py:49-81: fraction of waypoints inside any box (centre +- size/2, inclusive)."""
+    c = np.asarray(box_centers, traj.dtype).reshape(1, 1, -1, 2)
+    sz = np.asarray(box_sizes, traj.dtype)
+    if sz.ndim == 1:
+        sz = np.repeat(sz[:, None], 2, axis=1)
+    sz = sz.reshape(1, 1, -1, 2)
+    xy = traj[:, :, None, :2]
+    inside = ((xy >= c - sz / 2) & (xy <= c + sz / 2)).all(-1)
+    return inside.any(-1).astype(traj.dtype).mean(1)
+
+
+def waypoint_variance(traj: np.ndarray) -> float:
+    """metrics.py:8-19: sum over waypoints of the unbiased variance over ALL B*B entries of triu(cdist(p, p), 1)
+    (the zeros of the lower triangle and the diagonal are part of the population).  float64."""
+    xy = traj[:, :, :2].astype(np.float64)
+    B = xy.shape[0]
+    total = 0.0
+    for h in range(xy.shape[1]):
+        d = np.sqrt(((xy[:, None, h, :] - xy[None, :, h, :]) ** 2).sum(-1))
+        total += float(np.var(np.triu(d, 1).reshape(-1), ddof=1))
+    return total
+
+
 # ----------------------------------------------------------------------------------------
 # sampler
 # ----------------------------------------------------------------------------------------

@@ -59,6 +59,9 @@ PROTOTYPES = {
                                    C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ramp_hard_cond": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p,
                                  C.c_void_p]),
+    "ramp_traj_metrics": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ramp_waypoint_variance": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ramp_traj_costs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ramp_cfg_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,

@@ -171,6 +171,10 @@ int launch_apf_dynamic(const ApfDynArgs& a, hipStream_t s);
 // mask[b] = any_{h,p} ||xy - p|| < thr ; plen[b], smooth[b]
 int launch_traj_costs(const float* traj, const float* cloud, int B, int H, int S, int P, float thr,
                       int* mask, float* plen, float* smooth, hipStream_t s);
+int launch_traj_metrics(const float* traj, int B, int H, int S, const float* centers, const float* sizes, int n_boxes,
+                        float* intensity, float* path_len, float* smooth, hipStream_t s);
+// scratch: 2 * H * ceil(B / 256) doubles; out: 1 double
+int launch_waypoint_variance(const float* traj, int B, int H, int S, double* scratch, double* out, hipStream_t s);
 
 // ---- setup kernels --------------------------------------------------------------------------
 // time-bias table: tb[t][off_i + c] = Wc_i silu(temb(t)) + bc_i for every RTB i, t in [0,T)

@@ -1211,6 +1211,15 @@ int ramp_traj_costs(const float* traj, int32_t B, int32_t H, int32_t S, const fl
   RAMP_REQUIRE(traj && cloud && mask && path_len && smooth, "null argument");
   return launch_traj_costs(traj, cloud, B, H, S, n_points, threshold, mask, path_len, smooth, as_stream(stream));
 }
+int ramp_traj_metrics(const float* traj, int32_t B, int32_t H, int32_t S, const float* box_centers, const float* box_sizes,
+                      int32_t n_boxes, float* intensity, float* path_len, float* smooth, void* stream) {
+  RAMP_REQUIRE(traj && intensity && path_len && smooth && (n_boxes == 0 || (box_centers && box_sizes)), "null argument");
+  return launch_traj_metrics(traj, B, H, S, box_centers, box_sizes, n_boxes, intensity, path_len, smooth, as_stream(stream));
+}
+int ramp_waypoint_variance(const float* traj, int32_t B, int32_t H, int32_t S, double* scratch, double* out, void* stream) {
+  RAMP_REQUIRE(traj && scratch && out, "null argument");
+  return launch_waypoint_variance(traj, B, H, S, scratch, out, as_stream(stream));
+}
 
 int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32_t n_rp, double w0, double w1,
                   float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip, float* x0_out,

@@ -208,3 +208,27 @@ def test_hard_conditioning_and_cfg_mean():
     assert np.array_equal(oe.cpu().numpy(), e) and np.array_equal(o0.cpu().numpy(), x0)
     assert np.array_equal(om.cpu().numpy(), mean)
     assert (np.abs(x0) == 1).sum() > 10          # the clamp was exercised
+
+
+def test_metrics_against_reference_fixture_and_oracle():
+    """ramp_traj_metrics / ramp_waypoint_variance (through ramp_amd.metrics.Metrics) vs the reference's Metrics
+    outputs, and at a batch size where the pairwise pass spans several tiles vs the float64 oracle."""
+    from ramp_amd.metrics import Metrics
+    g = np.load(f"{GOLDEN}/metrics_cases.npz")
+    M = Metrics()
+    t = dev(g["traj"])
+    ci = M.compute_collision_intensity(t, g["centers"], g["sizes"])
+    assert np.array_equal(ci.cpu().numpy(), g["intensity"])
+    assert np.abs(M.compute_path_length(t).cpu().numpy() - g["path_length"]).max() < 2e-6
+    assert np.abs(M.compute_smoothness(t).cpu().numpy() - g["smoothness"]).max() < 2e-5
+    assert abs(float(M.compute_variance_waypoints(t)) - float(g["variance_all"])) < 1e-5 * float(g["variance_all"])
+    res = M.trajectory_success_and_metrics(t, ci, threshold=0.01)
+    assert res["success"] == int(g["success"]) and res["n_free_trajectories"] == int(g["n_free"])
+    assert abs(res["collision_intensity"] - float(g["collision_intensity_pct"])) < 1e-4
+    assert abs(res["path_length"] - float(g["free_path_length"])) < 1e-5
+    assert abs(res["path_length_std"] - float(g["free_path_length_std"])) < 1e-5
+    assert abs(res["waypoint_variance"] - float(g["free_variance"])) < 1e-5 * float(g["free_variance"])
+    big = rng(5).standard_normal((700, 48, 4)).astype(np.float32) * 0.4
+    assert abs(float(M.compute_variance_waypoints(dev(big))) - O.waypoint_variance(big)) < 2e-6 * O.waypoint_variance(big)
+    assert np.abs(M.compute_collision_intensity(dev(big), g["centers"], g["sizes"]).cpu().numpy()
+                  - O.collision_intensity(big, g["centers"], g["sizes"])).max() == 0

@@ -181,3 +181,17 @@ def test_dynamic_cases():
     assert (g["apf/out_static"] != tr).sum() > 20 and (g["apf/out_dynamic"] != tr).sum() > 20
     assert np.array_equal(g["apf/out_static"][3], tr[3]) and np.array_equal(g["apf/out_dynamic"][3], tr[3])
     assert np.abs(O.sm_smooth(g["sm/s1"], g["sm/s2"]) - g["sm/out"]).max() < 1e-6
+
+
+def test_metrics_against_reference_fixture():
+    """collision intensity / path length / smoothness / waypoint variance vs the reference's Metrics class."""
+    g = np.load(f"{G}/metrics_cases.npz")
+    tr = g["traj"]
+    assert np.array_equal(O.collision_intensity(tr, g["centers"], g["sizes"]), g["intensity"])
+    assert np.abs(O.path_length(tr) - g["path_length"]).max() < 2e-6
+    assert np.abs(O.smoothness(tr) - g["smoothness"]).max() < 2e-5
+    # the reference evaluates cdist + var in fp32: 1e-5 relative is its own rounding level
+    assert abs(O.waypoint_variance(tr) - float(g["variance_all"])) < 1e-5 * float(g["variance_all"])
+    free = tr[g["intensity"] <= 0.01]
+    assert len(free) == int(g["n_free"])
+    assert abs(O.waypoint_variance(free) - float(g["free_variance"])) < 1e-5 * float(g["free_variance"])
