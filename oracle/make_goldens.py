@@ -488,10 +488,35 @@ def gen_metrics():
     save("metrics_cases.npz", **arrs)
 
 
+def gen_compat():
+    """Pursuer dynamics (scripts/inference/core/utils.py:85-137) and LimitsNormalizer (normalization.py:144-167) outputs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_utils", os.path.join(REF, "scripts/inference/core/utils.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    fn, vel = mod.DynamicsGenerator.create_pursuit_dynamics(0.5)
+    g = np.random.Generator(np.random.PCG64(5))
+    ts = np.arange(12); prev = g.uniform(-1, 1, (12, 1, 2)); robot = g.uniform(-1, 1, (12, 1, 2))
+    prev[3] = robot[3]                                            # zero distance branch
+    prev[4] = [[0.999, -0.999]]                                   # clipping
+    out = np.stack([fn(int(t), prev[i], robot[i], vel) for i, t in enumerate(ts)])
+    # (mpd.datasets' package __init__ imports gitpython, absent here: load the one module file)
+    nspec = importlib.util.spec_from_file_location("ref_norm", os.path.join(REF, "mpd/datasets/normalization.py"))
+    nmod = importlib.util.module_from_spec(nspec); nspec.loader.exec_module(nmod)
+    x = torch.from_numpy(g.uniform(-2, 3, (7, 5, 4)).astype(np.float32))
+    n = nmod.LimitsNormalizer(x.reshape(-1, 4))                   # mins / maxs over the flattened data (normalization.py:90-93)
+    z = n.normalize(x); xb = n.unnormalize(z * 1.2)
+    hc = mod.StateGenerator.get_hard_cond_custom(torch.tensor([[0.1, -0.2], [0.5, 0.6], [0.7, 0.8]]), horizon=48)
+    save("compat_cases.npz", dyn_t=ts, dyn_prev=prev, dyn_robot=robot, dyn_vel=vel, dyn_out=out, norm_x=x.numpy(),
+         norm_mins=np.asarray(n.mins), norm_maxs=np.asarray(n.maxs), norm_z=z.numpy(), norm_back=xb.numpy(),
+         hc0=hc[0].numpy(), hc47=hc[47].numpy())
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "dynamic":
         m2, sp2, _ = build_unet(4, 48, False)
         gen_dynamic(m2, sp2); return
+    if len(sys.argv) > 1 and sys.argv[1] == "compat":
+        gen_compat(); return
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         gen_metrics(); return
     if len(sys.argv) > 1 and sys.argv[1] == "replan":
@@ -518,6 +543,7 @@ def main():
     print("dynamic"); gen_dynamic(m2, sp2)
     print("replan"); gen_replan(m2, sp2)
     print("metrics"); gen_metrics()
+    print("compat"); gen_compat()
     print("done")
 
 

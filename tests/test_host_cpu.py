@@ -118,3 +118,54 @@ def test_synthetic_inputs_are_deterministic():
     assert np.array_equal(n1, synth.make_noise((3, 2, 48, 4), seed=7))
     g = np.load(f"{GOLDEN}/scene_latents.npz")
     assert np.array_equal(g["cloud2d_16x64"], a)      # fixtures were generated from the same generator
+
+
+def test_compat_layer_against_reference_fixture(tmp_path):
+    """Pursuer dynamics, LimitsNormalizer and hard-condition helper vs the reference's outputs; checkpoint / context /
+    environment-directory round trips in the reference's on-disk layout."""
+    import torch
+    import yaml
+    from ramp_amd import compat
+    from ramp_amd.models import StaticGaussianDiffusionModel, TemporalUnetInference
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "compat_cases.npz"))
+    fn, vel = compat.DynamicsGenerator.create_pursuit_dynamics(0.5)
+    assert np.array_equal(vel, g["dyn_vel"])
+    for i, t in enumerate(g["dyn_t"]):
+        assert np.abs(fn(int(t), g["dyn_prev"][i], g["dyn_robot"][i], vel) - g["dyn_out"][i]).max() < 1e-15
+    n = compat.LimitsNormalizer(g["norm_mins"], g["norm_maxs"])
+    x = torch.from_numpy(g["norm_x"])
+    z = n.normalize(x)
+    assert np.array_equal(z.numpy(), g["norm_z"]) and np.array_equal(n.unnormalize(z * 1.2).numpy(), g["norm_back"])
+    hc = compat.StateGenerator.get_hard_cond_custom(torch.tensor([[0.1, -0.2], [0.5, 0.6], [0.7, 0.8]]), horizon=48)
+    assert np.array_equal(hc[0].numpy(), g["hc0"]) and np.array_equal(hc[47].numpy(), g["hc47"])
+    # pursuer field: same update path as MultiSphereFieldDynamics.update_centers
+    ds = compat.make_pursuit_env(np.zeros((6, 2)), np.full((6, 2), 0.2), [0.5, 0.5])
+    sphere = ds.env.obj_extra_list[0].fields[0]
+    sphere.update_centers(3, torch.tensor([[-0.5, -0.5], [9.0, 9.0]]))
+    want = fn(3, np.array([[0.5, 0.5]], np.float32), np.array([[-0.5, -0.5]]), vel.astype(np.float32))
+    assert np.abs(sphere.centers.numpy() - want).max() < 1e-6
+    # context + environment directory + checkpoint in the reference layout
+    p = compat.ContextManager.save_context(torch.tensor([0.1, 0.2]), torch.tensor([0.3, 0.4]), str(tmp_path), "d", 7)
+    assert p.endswith("contexts/context_007.pt")
+    s0, g0 = compat.ContextManager.load_context(str(tmp_path / "contexts"), 7)
+    assert torch.equal(s0, torch.tensor([0.1, 0.2])) and torch.equal(g0, torch.tensor([0.3, 0.4]))
+    torch.save(torch.ones(3, 8, 2), tmp_path / "obstacle_points.pt")
+    np.save(tmp_path / "box_centers.npy", np.zeros((3, 2), np.float32))
+    (tmp_path / "metadata.yaml").write_text(yaml.safe_dump({"box_sizes": [[0.2, 0.2]] * 3}))
+    env = compat.load_environment_dir(str(tmp_path))
+    assert env["obstacle_points"].shape == (3, 8, 2) and env["box_sizes"].shape == (3, 2)
+    sp = make_unet_spec(4, 48, obstacle_3d=False)
+    sd = synth.make_unet_state_dict(sp, seed=3)
+    dm = StaticGaussianDiffusionModel(model=TemporalUnetInference(n_support_points=48, state_dim=4), n_diffusion_steps=25,
+                                      predict_epsilon=True)
+    full = dm.state_dict()
+    for k, v in sd.items():
+        full["model." + k] = torch.from_numpy(np.asarray(v))
+    ck = tmp_path / "models" / "m1" / "checkpoints"
+    ck.mkdir(parents=True)
+    torch.save(full, ck / "ema_model_current_state_dict.pth")
+    dm2 = StaticGaussianDiffusionModel(model=TemporalUnetInference(n_support_points=48, state_dim=4), n_diffusion_steps=25,
+                                       predict_epsilon=True)
+    compat.load_checkpoint(dm2, str(tmp_path / "models"), "m1", use_ema=True)
+    got = dm2.state_dict()
+    assert all(torch.equal(got[k], full[k]) for k in full)
