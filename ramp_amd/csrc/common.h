@@ -43,7 +43,7 @@ struct GemmArgs {
   const float* W = nullptr;                                 // [taps][N][K], K contiguous
   const unsigned short* Wx = nullptr; long wx_plane = 0;    // optional bf16x6 planes [3][taps][N][K] (plane stride in elements)
   const float* Amul = nullptr; int lda_mul = 0; int a_period = 0;   // optional: A_eff[m][k] = A[m][k % a_period] * Amul[m][k]
-  int wx_packed = 0;                                        // 1: Wx is fragment-packed [taps*N/32][K/16][3][64][8] (launch_pack_x6)
+  int wx_packed = 0;                                        // 1: Wx is fragment-packed [taps*N/32][K/16][3][64][8] bf16 (launch_pack_x6); 2: [..][2][64][8] fp16 (launch_pack_h3)
   const float* bias = nullptr;                              // [N]
   const float* rowbias = nullptr; const int* rowvar = nullptr; int row0 = 0; int rb_stride = 0;  // [n_var][rb_stride]
   const float* resid = nullptr;  int ldr = 0;
@@ -70,6 +70,7 @@ enum { EPI_LINEAR = 0, EPI_GEGLU_FWD = 1, EPI_GEGLU_BWD = 2 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_split3(const float* in, unsigned short* out, long n, hipStream_t s);   // fp32 -> 3 bf16 planes
 int launch_pack_x6(const float* W, unsigned short* out, long rows, int K, hipStream_t s);   // fp32 [rows][K] -> MFMA-fragment-packed planes
+int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, hipStream_t s);   // same, two fp16 planes
 int init_gemm_attributes();        // raise the dynamic-LDS limit of every GEMM instantiation (once)
 int init_attention_attributes();   // same for the attention kernels
 

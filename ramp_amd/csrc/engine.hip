@@ -1245,6 +1245,18 @@ int ramp_op_gemm(const float* A, const float* W, const float* bias, const float*
   GemmArgs a; a.A = A; a.lda = K; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.C = C; a.ldc = N;
   a.M = M; a.N = N; a.K = K; a.taps = taps; a.shift0 = shift0; a.shift_step = shift_step; a.L = L;
   const char* env = getenv("RAMP_GEMM_MODE");
+  if (env && std::string(env) == "fp16x3" && N >= 128 && N % 32 == 0 && K % 16 == 0) {
+    static std::map<const float*, unsigned short*> cache3;
+    const long n = (long)taps * N * K;
+    auto it = cache3.find(W);
+    if (it == cache3.end()) {
+      unsigned short* p = nullptr;
+      RAMP_HIP_CHECK(hipMalloc(&p, 2 * n * sizeof(unsigned short)));
+      it = cache3.emplace(W, p).first;
+    }
+    if (int rc = launch_pack_h3(W, it->second, (long)taps * N, K, as_stream(stream))) return rc;
+    a.Wx = it->second; a.wx_packed = 2;
+  } else
   if (env && std::string(env) == "bf16x6" && N >= 128) {       // test / micro-benchmark path: split W on the fly
     static std::map<const float*, unsigned short*> cache;
     const long n = (long)taps * N * K;

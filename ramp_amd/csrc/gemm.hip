@@ -591,14 +591,42 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 // so every global / LDS access of a wave is issued one k16 step (24 MFMAs) before its consumer.
 // AMUL: A_eff[m][k] = A[m][k % a_period] * Amul[m][k] (the GEGLU VJP d(ag) = [d(hg) s1 | d(hg) s2] formed while the
 // operand is staged, instead of a 2048-wide d(ag) round trip through HBM).
-template <int EPI, bool GEN, bool AMUL = false>
+// NP = 3: bf16x6 (three 8-bit planes, six products).  NP = 2: fp16x3 (two 11-bit planes h1 + h2 = 22 significand bits,
+// products h1h1' + h1h2' + h2h1'; the dropped h2h2' and the plane residuals are <= 3 * 2^-22 |ab|): half the matrix
+// work, but fp16's 5 exponent bits need operands in [2^-14, 2^15] -- see launch_gemm for where it is allowed.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_planes(const u32x4 a, const u32x4 b, const f32x16 c) {
+  if (NP == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+// one plane of four floats: two packed 16-bit pairs, and (optionally) the floats with that plane removed
+template <int NP>
+__device__ __forceinline__ u32x2 peel4(f32x4& v, bool subtract) {
+  u32x2 q;
+  if (NP == 3) {
+    q[0] = pk_bf16(v[0], v[1]); q[1] = pk_bf16(v[2], v[3]);
+    if (subtract) {
+      v[0] -= __builtin_bit_cast(float, q[0] << 16); v[1] -= __builtin_bit_cast(float, q[0] & 0xffff0000u);
+      v[2] -= __builtin_bit_cast(float, q[1] << 16); v[3] -= __builtin_bit_cast(float, q[1] & 0xffff0000u);
+    }
+  } else {
+    const half2v h0 = __builtin_convertvector(f32x2{v[0], v[1]}, half2v), h1 = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
+    if (subtract) { v[0] -= (float)h0[0]; v[1] -= (float)h0[1]; v[2] -= (float)h1[0]; v[3] -= (float)h1[1]; }
+    q[0] = __builtin_bit_cast(unsigned, h0); q[1] = __builtin_bit_cast(unsigned, h1);
+  }
+  return q;
+}
+template <int EPI, bool GEN, bool AMUL = false, int NP = 3>
 __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
+  constexpr int NMF = (NP == 3 ? 6 : 3) * 4;           // MFMAs per k16 step
   constexpr int WM = 2, WN = 2, MI = 2, NI = 2;
   constexpr int BM = 128, BN = 128;
   constexpr int AI = 4;                               // fp32 float4 loads per thread (A)
   constexpr int PLANE = BM * XLD;                     // bf16 elements per LDS plane
-  constexpr int BUF = 3 * PLANE;                      // one A buffer: 3 planes
+  constexpr int BUF = NP * PLANE;                     // one A buffer: NP planes
   // LDS: [margin | buffer 0 | buffer 1 | margin]; a half-tile C image (64 x 132 floats) = one buffer + one margin
   constexpr int C_IMG = 64 * (BN + 4) * 4;            // bytes
   constexpr int MARGIN = C_IMG - BUF * 2;             // bytes
@@ -680,13 +708,13 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   auto store_tile = [&](unsigned short* dst) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      u32x2 p1, p2, p3;
-      split3(AMUL ? ra[i] * rs[i] : ra[i], p1, p2, p3);
+      f32x4 v = AMUL ? ra[i] * rs[i] : ra[i];
       const int rowa = r0 + 32 * i;
       const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
-      *reinterpret_cast<u32x2*>(dst + off) = p1;
-      *reinterpret_cast<u32x2*>(dst + PLANE + off) = p2;
-      *reinterpret_cast<u32x2*>(dst + 2 * PLANE + off) = p3;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        *reinterpret_cast<u32x2*>(dst + p * PLANE + off) = peel4<NP>(v, p + 1 < NP);
+      }
     }
   };
   auto advance_loader = [&]() {
@@ -708,32 +736,33 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
       blk[ni] = (long)(n >> 5) * nk16;
     }
   };
-  auto load_w = [&](bf16x8 (&dst)[3][NI], const long (&blk)[NI], int it, int s2) {
+  auto load_w = [&](u32x4 (&dst)[NP][NI], const long (&blk)[NI], int it, int s2) {
     long kb;
     if (!GEN) kb = 2 * it + s2;
     else { const int tap = it / nk; kb = tap * tap_blocks + 2 * (it - tap * nk) + s2; }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const unsigned short* q = wl + (blk[ni] + kb) * 1536;
+      const unsigned short* q = wl + (blk[ni] + kb) * (NP * 512);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) dst[p][ni] = *reinterpret_cast<const bf16x8*>(q + p * 512);
+      for (int p = 0; p < NP; ++p) dst[p][ni] = *reinterpret_cast<const u32x4*>(q + p * 512);
     }
   };
 
   const int r = lane & 31, h = lane >> 5;
   const int arow = (wm * 64 + r) * XLD;
   const int sw = (r >> 2) & 3;
-  auto read_a = [&](bf16x8 (&dst)[3][MI], const unsigned short* src, int s2) {
+  auto read_a = [&](u32x4 (&dst)[NP][MI], const unsigned short* src, int s2) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        dst[p][mi] = *reinterpret_cast<const bf16x8*>(src + p * PLANE + arow + mi * 32 * XLD + (((2 * s2 + h) ^ sw) << 3));
+        dst[p][mi] = *reinterpret_cast<const u32x4*>(src + p * PLANE + arow + mi * 32 * XLD + (((2 * s2 + h) ^ sw) << 3));
   };
 
-  bf16x8 av[2][3][MI], bw[2][3][NI];
+  u32x4 av[2][NP][MI], bw[2][NP][NI];
   long wblk[NI], wnext[NI];
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+  constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};   // small terms first
+  constexpr int PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 
   // prologue: slab 0 of the first tile -> buffer 0, slab 1 parked in registers, first fragments in flight
   setup_rows(ld_tile);
@@ -778,29 +807,20 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
       {
         const long kb = GEN ? (long)(it / nk) * tap_blocks + 2 * (it % nk) + 1 : 2 * it + 1;
 #pragma unroll
-        for (int j = 0; j < 24; ++j) {
-          acc[(j >> 1) & 1][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][PA[j >> 2]][(j >> 1) & 1], bw[0][PB[j >> 2]][j & 1],
-                                                                             acc[(j >> 1) & 1][j & 1], 0, 0, 0);
-          if (j < 6) {
+        for (int j = 0; j < NMF; ++j) {
+          acc[(j >> 1) & 1][j & 1] = mfma_planes<NP>(av[0][PA[j >> 2]][(j >> 1) & 1], bw[0][PB[j >> 2]][j & 1], acc[(j >> 1) & 1][j & 1]);
+          if (j < 2 * NP) {
             const int p = j >> 1, x = j & 1;
-            bw[1][p][x] = *reinterpret_cast<const bf16x8*>(wl + (wblk[x] + kb) * 1536 + p * 512);
-            av[1][p][x] = *reinterpret_cast<const bf16x8*>(cur + p * PLANE + arow + x * 32 * XLD + (((2 + h) ^ sw) << 3));
-          } else if (j < 18) {
-            const int i = (j - 6) / 3, st = (j - 6) % 3;
+            bw[1][p][x] = *reinterpret_cast<const u32x4*>(wl + (wblk[x] + kb) * (NP * 512) + p * 512);
+            av[1][p][x] = *reinterpret_cast<const u32x4*>(cur + p * PLANE + arow + x * 32 * XLD + (((2 + h) ^ sw) << 3));
+          } else if (j < 6 * NP) {
+            const int i = (j - 2 * NP) / NP, st = (j - 2 * NP) % NP;
             if (AMUL && st == 0) ra[i] *= rs[i];
             const int rowa = r0 + 32 * i;
             const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
-            const unsigned q0 = pk_bf16(ra[i][0], ra[i][1]), q1 = pk_bf16(ra[i][2], ra[i][3]);
-            *reinterpret_cast<u32x2*>(oth + st * PLANE + off) = u32x2{q0, q1};
-            if (st < 2) {
-              ra[i][0] -= __builtin_bit_cast(float, q0 << 16);
-              ra[i][1] -= __builtin_bit_cast(float, q0 & 0xffff0000u);
-              ra[i][2] -= __builtin_bit_cast(float, q1 << 16);
-              ra[i][3] -= __builtin_bit_cast(float, q1 & 0xffff0000u);
-            }
-          } else if (j == 18) {
-            load_tile();                               // global A loads two slabs ahead, as early as ra is free
+            *reinterpret_cast<u32x2*>(oth + st * PLANE + off) = peel4<NP>(ra[i], st + 1 < NP);
           }
+          if (j == (NP == 3 ? 18 : NMF - 1)) load_tile();   // global A loads two slabs ahead, as soon as ra is free
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -809,13 +829,12 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
       {
         const long kb = GEN ? (long)(it_next / nk) * tap_blocks + 2 * (it_next % nk) : 2 * it_next;
 #pragma unroll
-        for (int j = 0; j < 24; ++j) {
-          acc[(j >> 1) & 1][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][PA[j >> 2]][(j >> 1) & 1], bw[1][PB[j >> 2]][j & 1],
-                                                                             acc[(j >> 1) & 1][j & 1], 0, 0, 0);
-          if (j < 6) {
+        for (int j = 0; j < NMF; ++j) {
+          acc[(j >> 1) & 1][j & 1] = mfma_planes<NP>(av[1][PA[j >> 2]][(j >> 1) & 1], bw[1][PB[j >> 2]][j & 1], acc[(j >> 1) & 1][j & 1]);
+          if (j < 2 * NP) {
             const int p = j >> 1, x = j & 1;
-            bw[0][p][x] = *reinterpret_cast<const bf16x8*>(wl + (wsel[x] + kb) * 1536 + p * 512);
-            av[0][p][x] = *reinterpret_cast<const bf16x8*>(oth + p * PLANE + arow + x * 32 * XLD + ((h ^ sw) << 3));
+            bw[0][p][x] = *reinterpret_cast<const u32x4*>(wl + (wsel[x] + kb) * (NP * 512) + p * 512);
+            av[0][p][x] = *reinterpret_cast<const u32x4*>(oth + p * PLANE + arow + x * 32 * XLD + ((h ^ sw) << 3));
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -830,33 +849,40 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   }
 }
 
-// fp32 [rows][K] -> fragment-packed bf16 planes [rows/32][K/16][3][64 lanes][8]
-__global__ void pack_x6_kernel(const float* __restrict__ W, unsigned short* __restrict__ out, long rows, int K) {
+// fp32 [rows][K] -> fragment-packed planes [rows/32][K/16][NP][64 lanes][8] (NP = 3: bf16, NP = 2: fp16)
+template <int NP>
+__global__ void pack_planes_kernel(const float* __restrict__ W, unsigned short* __restrict__ out, long rows, int K) {
   const int k8n = K / 8;
   const long total = rows * k8n;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long row = i / k8n;
     const int k8 = (int)(i - row * k8n);
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8);
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8 + 4);
-    u32x2 a1, a2, a3, b1, b2, b3;
-    split3(lo, a1, a2, a3);
-    split3(hi, b1, b2, b3);
+    f32x4 lo = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8);
+    f32x4 hi = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8 + 4);
     const long blk = (row >> 5) * (K / 16) + (k8 >> 1);
-    unsigned short* q = out + blk * 1536 + (((k8 & 1) * 32 + (int)(row & 31)) << 3);
-    *reinterpret_cast<u32x4*>(q) = u32x4{a1[0], a1[1], b1[0], b1[1]};
-    *reinterpret_cast<u32x4*>(q + 512) = u32x4{a2[0], a2[1], b2[0], b2[1]};
-    *reinterpret_cast<u32x4*>(q + 1024) = u32x4{a3[0], a3[1], b3[0], b3[1]};
+    unsigned short* q = out + blk * (NP * 512) + (((k8 & 1) * 32 + (int)(row & 31)) << 3);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const bool sub = p + 1 < NP;
+      const u32x2 qa = peel4<NP>(lo, sub), qb = peel4<NP>(hi, sub);
+      *reinterpret_cast<u32x4*>(q + p * 512) = u32x4{qa[0], qa[1], qb[0], qb[1]};
+    }
   }
 }
 int launch_pack_x6(const float* W, unsigned short* out, long rows, int K, hipStream_t s) {
   RAMP_REQUIRE(rows > 0 && rows % 32 == 0 && K > 0 && K % 16 == 0, "pack_x6 needs rows % 32 == 0 and K % 16 == 0");
   const long total = rows * (K / 8);
-  hipLaunchKernelGGL(pack_x6_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, W, out, rows, K);
+  hipLaunchKernelGGL(pack_planes_kernel<3>, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, W, out, rows, K);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }
-
+int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, hipStream_t s) {
+  RAMP_REQUIRE(rows > 0 && rows % 32 == 0 && K > 0 && K % 16 == 0, "pack_h3 needs rows % 32 == 0 and K % 16 == 0");
+  const long total = rows * (K / 8);
+  hipLaunchKernelGGL(pack_planes_kernel<2>, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, W, out, rows, K);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 constexpr size_t X6_LDS = std::max<size_t>(6 * (size_t)128 * XLD * 2, (size_t)128 * 132 * 4);
 
@@ -869,8 +895,10 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
   const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
   if (a.wx_packed && a.Amul) {
     RAMP_REQUIRE(EPI == EPI_LINEAR && !GEN && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
+    RAMP_REQUIRE(a.wx_packed == 1, "the A-multiplier operand is built for the bf16x6 planes");
     hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
-  } else if (a.wx_packed) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
+  } else if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN, false, 2>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
+  else if (a.wx_packed) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
   else hipLaunchKernelGGL((gemm_x6_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
@@ -880,6 +908,8 @@ static int set_attr_x6() {
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<EPI, GEN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI, GEN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI, GEN, false, 2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
   return 0;
 }
