@@ -35,7 +35,8 @@ typedef struct ramp_config {
   int32_t context_dim;     /* 320 (2-D scene encoder) or 256 (3-D)                     */
   int32_t max_rows;        /* capacity in network rows per chunk (rows = B * n_rp)     */
   int32_t debug_taps;      /* 1: keep per-module outputs / output-grads for ramp_debug_read */
-  int32_t gemm_mode;       /* 0 = library default (env RAMP_GEMM_MODE=fp32|bf16x6), 1 = exact fp32 MFMA, 2 = bf16x6 split */
+  int32_t gemm_mode;       /* 0 = library default (env RAMP_GEMM_MODE=fp32|bf16x6|fp16x3), 1 = exact fp32 MFMA, 2 = bf16x6 split,
+                            * 3 = fp16x3 split with delayed operand scaling inside ramp_sample (ramp_score stays bf16x6) */
 } ramp_config;
 
 const char* ramp_last_error(void);
@@ -188,6 +189,10 @@ int ramp_debug_read(ramp_ctx* ctx, const char* kind, const char* module, float* 
                     int64_t* n_copied, void* stream);
 
 /* bookkeeping for bench / profiling */
+/* fp16x3 mode only: waits for `stream`, then *flag = 1 if any GEMM of the last ramp_sample found an operand that,
+ * scaled by the previous evaluation's maximum, left the fp16 range (the results of that call must be discarded and the
+ * job re-run with gemm_mode bf16x6); always 0 in the other modes. */
+int ramp_range_status(ramp_ctx* ctx, int32_t* flag, void* stream);
 /* per-launch HIP-event timing (eager, non-graph calls only).  Categories: 0 = MFMA GEMM (linears + k5/k1
  * convs), 1 = attention, 2 = GroupNorm/LayerNorm/GEGLU rows, 3 = stride-2 / first / last convs, 4 = sampler
  * (CFG, DDPM/DDIM update, APF).  ramp_profile_read sums elapsed ms, algorithmic FLOPs and launch counts

@@ -11,8 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libramp_hip.so")
 SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "sampler.hip", "scene.hip", "metrics.hip", "engine.hip"]
-# default GEMM mode 1 = bf16x6 split on the bf16 matrix cores (fp32-accurate, see gemm.hip); 0 = exact fp32 MFMA
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DRAMP_DEFAULT_GEMM_MODE=1"]
+# default GEMM mode 2 = fp16x3 split with delayed operand scaling, 1 = bf16x6 split (both fp32-accurate, see gemm.hip);
+# 0 = exact fp32 MFMA
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DRAMP_DEFAULT_GEMM_MODE=2"]
 # sampler.hip mirrors the reference's elementwise fp32 expressions rounding for rounding: hipcc's default
 # -ffp-contract=fast would fuse a*b - c*d into an FMA (HIP's __fmul_rn is a plain multiply), so it is off there.
 EXTRA_FLAGS = {"sampler.hip": ["-ffp-contract=off"]}
@@ -30,7 +31,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ramp_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ramp_hip.h"), os.path.abspath(__file__)]
     jobs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

@@ -42,6 +42,9 @@ struct GemmArgs {
   const float* A2 = nullptr; int lda2 = 0; int K1 = 0;    // K1 == K when A2 unused
   const float* W = nullptr;                                 // [taps][N][K], K contiguous
   const unsigned short* Wx = nullptr; long wx_plane = 0;    // optional bf16x6 planes [3][taps][N][K] (plane stride in elements)
+  // fp16x3 operand scaling (delayed): previous evaluation's max |A| of this call site, where to record this one's,
+  // where to flag a scaled operand leaving the fp16 range; 1 / (power-of-two scale the packed weights carry)
+  const float* a_absmax_in = nullptr; float* a_absmax_out = nullptr; int* range_flag = nullptr; float w_scale_inv = 1.f;
   const float* Amul = nullptr; int lda_mul = 0; int a_period = 0;   // optional: A_eff[m][k] = A[m][k % a_period] * Amul[m][k]
   int wx_packed = 0;                                        // 1: Wx is fragment-packed [taps*N/32][K/16][3][64][8] bf16 (launch_pack_x6); 2: [..][2][64][8] fp16 (launch_pack_h3)
   const float* bias = nullptr;                              // [N]
@@ -70,7 +73,7 @@ enum { EPI_LINEAR = 0, EPI_GEGLU_FWD = 1, EPI_GEGLU_BWD = 2 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_split3(const float* in, unsigned short* out, long n, hipStream_t s);   // fp32 -> 3 bf16 planes
 int launch_pack_x6(const float* W, unsigned short* out, long rows, int K, hipStream_t s);   // fp32 [rows][K] -> MFMA-fragment-packed planes
-int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, hipStream_t s);   // same, two fp16 planes
+int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, float scale, hipStream_t s);   // same, two fp16 planes
 int init_gemm_attributes();        // raise the dynamic-LDS limit of every GEMM instantiation (once)
 int init_attention_attributes();   // same for the attention kernels
 

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -150,9 +151,16 @@ struct ramp_ctx {
   float* scene_ws = nullptr; size_t scene_ws_cap = 0;
   // bf16x6 weight planes: fp32 weight base pointer -> (planes, element count)
   int gemm_mode = 0;                 // 0 = exact fp32 MFMA, 1 = bf16x6 split on the bf16 matrix cores
-  struct X6W { unsigned short* planes; size_t n; int K; unsigned short* packed; };
+  struct X6W { unsigned short* planes; size_t n; int K; unsigned short* packed; unsigned short* packed3; float w_scale_inv; };
   std::map<const float*, X6W> x6;
   int x6_pipe = 1;                   // 1 = fragment-packed weights + pipelined kernel (RAMP_X6_PIPE=0: LDS-staged weights)
+  // fp16x3 (gemm_mode 2): delayed operand scaling.  phase 0 = bf16x6; 1 = bf16x6 that records max|A| per GEMM call site
+  // (the calibration evaluation: the first score evaluation of every ramp_sample); 2 = fp16x3 scaled from the
+  // previous evaluation's maxima, recording its own.  obs[2][MAX_SITES] floats, ping-pong by evaluation.
+  static constexpr int MAX_SITES = 1024;
+  int phase = 0, site = 0;
+  float* obs = nullptr; float *obs_in = nullptr, *obs_out = nullptr;
+  int* range_flag = nullptr;
   // debug
   std::map<std::string, std::pair<float*, size_t>> dbg;
   int64_t launches = 0;
@@ -319,15 +327,24 @@ struct Run {
   int gemm(const GemmArgs& a) {
     prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, a.taps});
     GemmArgs b = a;
-    if (c->gemm_mode == 1 && b.N >= 128) {
+    if (c->gemm_mode >= 1 && b.N >= 128) {
       auto it = c->x6.upper_bound(b.W);
       if (it != c->x6.begin()) {
         --it;
         const auto& e = it->second;
         if (b.W >= it->first && b.W < it->first + e.n) {
           const size_t off = b.W - it->first;
-          if (c->x6_pipe && e.packed && e.K == b.K && off % (32ul * b.K) == 0 && b.N % 32 == 0) {
-            b.Wx = e.packed + 3 * off; b.wx_packed = 1;
+          const bool frag = c->x6_pipe && e.packed && e.K == b.K && off % (32ul * b.K) == 0 && b.N % 32 == 0;
+          if (frag) {
+            RAMP_REQUIRE(c->site < ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
+            if (c->phase == 2 && e.packed3) {
+              b.Wx = e.packed3 + 2 * off; b.wx_packed = 2; b.w_scale_inv = e.w_scale_inv;
+              b.a_absmax_in = c->obs_in + c->site; b.a_absmax_out = c->obs_out + c->site; b.range_flag = c->range_flag;
+            } else {
+              b.Wx = e.packed + 3 * off; b.wx_packed = 1;
+              if (c->phase >= 1) b.a_absmax_out = c->obs_out + c->site;
+            }
+            c->site++;
           } else {
             if (c->x6_pipe && getenv("RAMP_X6_WARN"))
               fprintf(stderr, "[ramp] x6 weight not fragment-packed: M %d N %d K %d taps %d (blob K %d, off %zu)\n", b.M, b.N, b.K, b.taps, e.K, off);
@@ -473,7 +490,7 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx) {
   for (int b = 1; b >= 0; --b) {
     STBlock& k = m.blk[b];
     const float* zin = (b == 0) ? m.a_z0 : m.blk[0].a_z2;
-    if (c->gemm_mode == 1 && c->x6_pipe) {
+    if (c->gemm_mode >= 1 && c->x6_pipe) {
       // d(hg) only (1024 wide); d(ag) = [d(hg) s1 | d(hg) s2] is formed by the next GEMM's operand loader from the
       // forward stash: the 2048-wide d(ag) never goes to HBM (saves a 2048-float write and a 2048-float read per token)
       CK(r.gemm(lin(dz, D, k.w2_b, nullptr, c->t_hg, 1024, M, 1024, D)));
@@ -765,6 +782,7 @@ int score_all(ramp_ctx* c, const float* x, int B, int n_rp, int t, float* f_out,
   for (int b0 = 0; b0 < B; b0 += cap_traj) {
     const int nb = std::min(cap_traj, B - b0), R = nb * n_rp, row0 = b0 * n_rp;
     float* fo = f_out ? f_out + (size_t)row0 * H * S : nullptr;
+    c->site = 0;                                       // every chunk walks the same GEMM call sites
     CK(net_forward(c, x + (size_t)b0 * H * S, row0, R, n_rp, t, fo, eps_out != nullptr, s));
     if (eps_out) CK(net_backward(c, row0, R, eps_out + (size_t)row0 * H * S, s));
   }
@@ -918,9 +936,11 @@ int ramp_finalize_weights(ramp_ctx* c) {
   // bf16x6 planes of every GEMM weight with N >= 128
   {
     const char* env = getenv("RAMP_GEMM_MODE");
-    c->gemm_mode = c->cfg.gemm_mode == 1 ? 0 : c->cfg.gemm_mode == 2 ? 1 : (env && std::string(env) == "bf16x6") ? 1 : (env && std::string(env) == "fp32") ? 0 : RAMP_DEFAULT_GEMM_MODE;
+    c->gemm_mode = c->cfg.gemm_mode == 1 ? 0 : c->cfg.gemm_mode == 2 ? 1 : c->cfg.gemm_mode == 3 ? 2
+                 : (env && std::string(env) == "fp16x3") ? 2 : (env && std::string(env) == "bf16x6") ? 1
+                 : (env && std::string(env) == "fp32") ? 0 : RAMP_DEFAULT_GEMM_MODE;
   }
-  if (c->gemm_mode == 1) {
+  if (c->gemm_mode >= 1) {
     const char* pe = getenv("RAMP_X6_PIPE");
     c->x6_pipe = !(pe && pe[0] == '0');
     auto reg = [&](const float* w, size_t n, int K) -> int {
@@ -932,9 +952,28 @@ int ramp_finalize_weights(ramp_ctx* c) {
         CK(dev_alloc(c, &q, (3 * n + 1) / 2 + 4));
         CK(launch_pack_x6(w, reinterpret_cast<unsigned short*>(q), (long)(n / K), K, 0));
       }
-      c->x6[w] = {reinterpret_cast<unsigned short*>(p), n, K, reinterpret_cast<unsigned short*>(q)};
+      float* q3 = nullptr; float wsi = 1.f;
+      if (q && c->gemm_mode == 2) {
+        // static power-of-two weight scale: max |w| -> [2^10, 2^11)
+        std::vector<float> hw(n);
+        RAMP_HIP_CHECK(hipMemcpy(hw.data(), w, n * sizeof(float), hipMemcpyDeviceToHost));
+        float mx = 0.f;
+        for (float v : hw) mx = std::max(mx, std::fabs(v));
+        float sc = 1.f;
+        if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }   // mx in [2^(e-1), 2^e)
+        CK(dev_alloc(c, &q3, n + 4));
+        CK(launch_pack_h3(w, reinterpret_cast<unsigned short*>(q3), (long)(n / K), K, sc, 0));
+        wsi = 1.f / sc;
+      }
+      c->x6[w] = {reinterpret_cast<unsigned short*>(p), n, K, reinterpret_cast<unsigned short*>(q),
+                  reinterpret_cast<unsigned short*>(q3), wsi};
       return 0;
     };
+    if (c->gemm_mode == 2) {
+      float* o; CK(dev_alloc(c, &o, 2 * ramp_ctx::MAX_SITES + 4));
+      c->obs = o; c->range_flag = reinterpret_cast<int*>(o + 2 * ramp_ctx::MAX_SITES);
+      RAMP_HIP_CHECK(hipMemset(o, 0, (2 * ramp_ctx::MAX_SITES + 4) * sizeof(float)));
+    }
     for (auto& r : c->rtbs) {
       if (!r.first) { CK(reg(r.c1.fwd, 5ul * r.cin * r.cout, r.cin)); CK(reg(r.c1.bwd, 5ul * r.cin * r.cout, r.cout)); }
       CK(reg(r.c2.fwd, 5ul * r.cout * r.cout, r.cout)); CK(reg(r.c2.bwd, 5ul * r.cout * r.cout, r.cout));
@@ -954,6 +993,10 @@ int ramp_finalize_weights(ramp_ctx* c) {
     for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C, u.C)); CK(reg(u.w_b, 4ul * u.C * u.C, u.C)); }
   }
   RAMP_HIP_CHECK(hipDeviceSynchronize());
+  if (getenv("RAMP_X6_WARN")) {
+    int n3 = 0; for (auto& kv : c->x6) n3 += kv.second.packed3 != nullptr;
+    fprintf(stderr, "[ramp] gemm_mode %d, x6_pipe %d, %zu weight blobs, %d with fp16 planes\n", c->gemm_mode, c->x6_pipe, c->x6.size(), n3);
+  }
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
   CK(init_attention_attributes());
   c->finalized = true;
@@ -1063,8 +1106,19 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
   if (chain) RAMP_HIP_CHECK(hipMemcpyAsync(c->s_chain, c->s_x, n * 4, hipMemcpyDeviceToDevice, s));
   ApfArgs ap; ap.cloud = c->s_cloud; ap.window = c->s_window; ap.B = B; ap.H = H; ap.S = S; ap.P = p->apf.n_points;
   ap.win = p->apf.window; ap.thr = p->apf.threshold; ap.strength = p->apf.strength;
+  if (c->gemm_mode == 2) RAMP_HIP_CHECK(hipMemsetAsync(c->range_flag, 0, sizeof(int), s));
   for (int j = 0; j < p->n_steps; ++j) {
-    CK(score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s));
+    if (c->gemm_mode == 2) {
+      // evaluation 0 calibrates (bf16x6 + recorded operand maxima); evaluation j >= 1 runs fp16x3 scaled from j - 1
+      c->phase = j == 0 ? 1 : 2;
+      c->obs_out = c->obs + (j & 1) * ramp_ctx::MAX_SITES;
+      c->obs_in = c->obs + ((j & 1) ^ 1) * ramp_ctx::MAX_SITES;
+      RAMP_HIP_CHECK(hipMemsetAsync(c->obs_out, 0, ramp_ctx::MAX_SITES * sizeof(float), s));
+    }
+    const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s);
+    if (getenv("RAMP_X6_WARN") && j < 2) fprintf(stderr, "[ramp] step %d phase %d sites %d\n", j, c->phase, c->site);
+    c->phase = 0;
+    CK(rc_score);
     CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = p->n_rp;
     m.w0 = (float)p->w0; m.w1 = (float)p->w1; m.w0p1 = (float)(1.0 + p->w0);
     m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised;
@@ -1254,8 +1308,21 @@ int ramp_op_gemm(const float* A, const float* W, const float* bias, const float*
       RAMP_HIP_CHECK(hipMalloc(&p, 2 * n * sizeof(unsigned short)));
       it = cache3.emplace(W, p).first;
     }
-    if (int rc = launch_pack_h3(W, it->second, (long)taps * N, K, as_stream(stream))) return rc;
+    if (int rc = launch_pack_h3(W, it->second, (long)taps * N, K, 1.f, as_stream(stream))) return rc;
     a.Wx = it->second; a.wx_packed = 2;
+    if (const char* sc = getenv("RAMP_H3_TEST_SCALE")) {          // micro-benchmark: exercise the scaling / recording path
+      static float* slots = nullptr;
+      if (!slots) { RAMP_HIP_CHECK(hipMalloc(&slots, 16)); }
+      const float v[4] = {(float)atof(sc), 0.f, 0.f, 0.f};
+      RAMP_HIP_CHECK(hipMemcpyAsync(slots, v, 16, hipMemcpyHostToDevice, as_stream(stream)));
+      a.a_absmax_in = slots; a.a_absmax_out = slots + 1; a.range_flag = reinterpret_cast<int*>(slots + 2);
+      if (int rc = launch_gemm(a, as_stream(stream))) return rc;
+      int flag = 0;
+      RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+      RAMP_HIP_CHECK(hipMemcpy(&flag, slots + 2, sizeof(int), hipMemcpyDeviceToHost));
+      RAMP_REQUIRE(flag == 0, "fp16x3 GEMM: the scaled operand left the fp16 range");
+      return 0;
+    }
   } else
   if (env && std::string(env) == "bf16x6" && N >= 128) {       // test / micro-benchmark path: split W on the fly
     static std::map<const float*, unsigned short*> cache;
@@ -1360,6 +1427,15 @@ int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
   return 0;
 }
 
+int ramp_range_status(ramp_ctx* c, int32_t* flag, void* stream) {
+  RAMP_REQUIRE(c && flag, "null argument");
+  *flag = 0;
+  if (c->range_flag) {
+    RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+    RAMP_HIP_CHECK(hipMemcpy(flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
 int ramp_workspace_bytes(ramp_ctx* c, int64_t* bytes) {
   RAMP_REQUIRE(c && bytes, "null argument");
   *bytes = (int64_t)c->arena.total;

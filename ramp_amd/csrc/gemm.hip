@@ -59,9 +59,9 @@ __device__ __forceinline__ void normal_cdf_pdf(float x, float& cdf, float& pdf) 
 // by this thread's own reads only (the caller issues the next barrier before reusing `smem`).
 // HALVES = WM: the C image holds one wave-row (MI * 32 tile rows) at a time (the pipelined x6 kernel lends it
 // only one operand buffer); the caller then needs no barrier before the call but one after it.
-template <int WM, int WN, int MI, int NI, int EPI, bool GEN, int HALVES = 1>
+template <int WM, int WN, int MI, int NI, int EPI, bool GEN, int HALVES = 1, bool OSC = false>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[MI][NI], float* smem, int tile, int tiles_n,
-                                         int tid, int wm, int wn, int r, int h) {
+                                         int tid, int wm, int wn, int r, int h, const float oscale = 1.f) {
   static_assert(HALVES == 1 || HALVES == WM, "C image: whole tile or one wave-row at a time");
   constexpr int BMT = WM * MI * 32, BM = BMT / HALVES, BN = WN * NI * 32, NT = WM * WN * 64;
   constexpr int CLD = BN + 4;
@@ -130,7 +130,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[MI][NI
         const bool ok = nok && m < a.M;
         const int mc = m < a.M ? m : 0;
         const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
-        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + b4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4);
+        if (OSC) v *= oscale;                          // undo the operand scales (powers of two: exact)
+        v += b4;
         if (EPI == EPI_LINEAR) {
           if (a.rowbias) v += *reinterpret_cast<const f32x4*>(a.rowbias + (long)a.rowvar[a.row0 + mc / a.L] * a.rb_stride + nc);
           if (a.resid) v += pre0[q];
@@ -163,8 +165,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[MI][NI
     for (int p = 0; p < PASSES; ++p) {
       const int row = p * RP + rr;
       const int m = m0 + row;
-      const f32x4 av = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4) + ba;
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(Cs + row * CLD + BN / 2 + cc * 4) + bg;
+      f32x4 av = *reinterpret_cast<const f32x4*>(Cs + row * CLD + cc * 4);
+      f32x4 gv = *reinterpret_cast<const f32x4*>(Cs + row * CLD + BN / 2 + cc * 4);
+      if (OSC) { av *= oscale; gv *= oscale; }
+      av += ba; gv += bg;
       f32x4 hv, s1, s2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -618,10 +622,25 @@ __device__ __forceinline__ u32x2 peel4(f32x4& v, bool subtract) {
   }
   return q;
 }
-template <int EPI, bool GEN, bool AMUL = false, int NP = 3>
+// REC: the launch also records max |A_eff| (atomic max into a.a_absmax_out) -- the fp16 planes of the NEXT evaluation of
+// the same call site are scaled from it (delayed scaling: A * 2^(10 - floor(log2 max)) lands in [2^10, 2^11) with
+// 2^4.9 of headroom before fp16 overflows and 2^-24 of the maximum still a normal number); a launch whose scaled
+// operand reaches 60000 raises a.range_flag.  All scales are powers of two and are undone exactly in the epilogue.
+template <int EPI, bool GEN, bool AMUL = false, int NP = 3, bool REC = false>
 __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   constexpr int NMF = (NP == 3 ? 6 : 3) * 4;           // MFMAs per k16 step
+  float s_a = 1.f, oscale = 1.f, amax = 0.f;
+  if (NP == 2) {
+    const float mx = a.a_absmax_in ? *a.a_absmax_in : 0.f;
+    if (mx > 0.f) {
+      int eb = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu);       // biased exponent: mx in [2^(eb-127), 2^(eb-126))
+      int sb = 264 - eb;                                                      // 2^(10 - (eb - 127))
+      sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+      s_a = __builtin_bit_cast(float, (unsigned)sb << 23);
+    }
+    oscale = a.w_scale_inv / s_a;
+  }
   constexpr int WM = 2, WN = 2, MI = 2, NI = 2;
   constexpr int BM = 128, BN = 128;
   constexpr int AI = 4;                               // fp32 float4 loads per thread (A)
@@ -709,6 +728,8 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       f32x4 v = AMUL ? ra[i] * rs[i] : ra[i];
+      if (REC) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      if (NP == 2) v *= s_a;
       const int rowa = r0 + 32 * i;
       const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
 #pragma unroll
@@ -816,6 +837,8 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
           } else if (j < 6 * NP) {
             const int i = (j - 2 * NP) / NP, st = (j - 2 * NP) % NP;
             if (AMUL && st == 0) ra[i] *= rs[i];
+            if (REC && st == 0) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(ra[i][0]), fabsf(ra[i][1])), fmaxf(fabsf(ra[i][2]), fabsf(ra[i][3]))));
+            if (NP == 2 && st == 0) ra[i] *= s_a;
             const int rowa = r0 + 32 * i;
             const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
             *reinterpret_cast<u32x2*>(oth + st * PLANE + off) = peel4<NP>(ra[i], st + 1 < NP);
@@ -843,22 +866,31 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
     }
     // the finished slab's buffer (plus its 9 KB margin) carries the C image, one wave-row at a time; the other
     // buffer already holds slab 0 of the next tile
-    epilogue<WM, WN, MI, NI, EPI, GEN, WM>(a, acc, smem + (parity ^ 1) * (C_IMG / 4), tile, tiles_n, tid, wm, wn, r, h);
+    epilogue<WM, WN, MI, NI, EPI, GEN, WM, NP == 2>(a, acc, smem + (parity ^ 1) * (C_IMG / 4), tile, tiles_n, tid, wm, wn, r, h, oscale);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) wblk[ni] = wnext[ni];
+  }
+  if (REC) {
+    // (the loader also staged the first slabs of a tile it never computes: rows of this matrix, so the maximum stays valid)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0) {
+      if (a.a_absmax_out) atomicMax(reinterpret_cast<unsigned*>(a.a_absmax_out), __builtin_bit_cast(unsigned, amax));
+      if (NP == 2 && a.range_flag && !(amax * s_a < 60000.f)) atomicOr(a.range_flag, 1);
+    }
   }
 }
 
 // fp32 [rows][K] -> fragment-packed planes [rows/32][K/16][NP][64 lanes][8] (NP = 3: bf16, NP = 2: fp16)
 template <int NP>
-__global__ void pack_planes_kernel(const float* __restrict__ W, unsigned short* __restrict__ out, long rows, int K) {
+__global__ void pack_planes_kernel(const float* __restrict__ W, unsigned short* __restrict__ out, long rows, int K, float scale) {
   const int k8n = K / 8;
   const long total = rows * k8n;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long row = i / k8n;
     const int k8 = (int)(i - row * k8n);
-    f32x4 lo = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8);
-    f32x4 hi = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8 + 4);
+    f32x4 lo = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8) * scale;
+    f32x4 hi = *reinterpret_cast<const f32x4*>(W + row * K + k8 * 8 + 4) * scale;
     const long blk = (row >> 5) * (K / 16) + (k8 >> 1);
     unsigned short* q = out + blk * (NP * 512) + (((k8 & 1) * 32 + (int)(row & 31)) << 3);
 #pragma unroll
@@ -872,14 +904,14 @@ __global__ void pack_planes_kernel(const float* __restrict__ W, unsigned short* 
 int launch_pack_x6(const float* W, unsigned short* out, long rows, int K, hipStream_t s) {
   RAMP_REQUIRE(rows > 0 && rows % 32 == 0 && K > 0 && K % 16 == 0, "pack_x6 needs rows % 32 == 0 and K % 16 == 0");
   const long total = rows * (K / 8);
-  hipLaunchKernelGGL(pack_planes_kernel<3>, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, W, out, rows, K);
+  hipLaunchKernelGGL(pack_planes_kernel<3>, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, W, out, rows, K, 1.f);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }
-int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, hipStream_t s) {
+int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, float scale, hipStream_t s) {
   RAMP_REQUIRE(rows > 0 && rows % 32 == 0 && K > 0 && K % 16 == 0, "pack_h3 needs rows % 32 == 0 and K % 16 == 0");
   const long total = rows * (K / 8);
-  hipLaunchKernelGGL(pack_planes_kernel<2>, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, W, out, rows, K);
+  hipLaunchKernelGGL(pack_planes_kernel<2>, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, W, out, rows, K, scale);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -893,12 +925,16 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
   const int slots = 512;
   const int rounds = (n_tiles + slots - 1) / slots;
   const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
+#define X6P_LAUNCH(...) hipLaunchKernelGGL((gemm_x6p_kernel<__VA_ARGS__>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles)
+  const bool rec = a.a_absmax_out != nullptr;
   if (a.wx_packed && a.Amul) {
     RAMP_REQUIRE(EPI == EPI_LINEAR && !GEN && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
-    RAMP_REQUIRE(a.wx_packed == 1, "the A-multiplier operand is built for the bf16x6 planes");
-    hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
-  } else if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN, false, 2>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
-  else if (a.wx_packed) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
+    if (a.wx_packed == 2) X6P_LAUNCH(EPI_LINEAR, false, true, 2, true);
+    else if (rec) X6P_LAUNCH(EPI_LINEAR, false, true, 3, true);
+    else X6P_LAUNCH(EPI_LINEAR, false, true, 3, false);
+  } else if (a.wx_packed == 2) X6P_LAUNCH(EPI, GEN, false, 2, true);
+  else if (a.wx_packed && rec) X6P_LAUNCH(EPI, GEN, false, 3, true);
+  else if (a.wx_packed) X6P_LAUNCH(EPI, GEN, false, 3, false);
   else hipLaunchKernelGGL((gemm_x6_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
@@ -907,13 +943,13 @@ template <int EPI, bool GEN>
 static int set_attr_x6() {
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<EPI, GEN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
-  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI, GEN>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
-  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI, GEN, false, 2>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
+#define X6P_ATTR(...) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<__VA_ARGS__>), \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS))
+  X6P_ATTR(EPI, GEN, false, 3, false);
+  X6P_ATTR(EPI, GEN, false, 3, true);
+  X6P_ATTR(EPI, GEN, false, 2, true);
   return 0;
 }
-
 template <int WM, int WN, int MI, int NI> struct Cfg {
   static constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   static constexpr size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
@@ -946,8 +982,9 @@ int init_gemm_attributes() {
   if (int e = set_attr<2, 2, 2, 2, EPI_GEGLU_BWD, false>()) return e;
   if (int e = set_attr<2, 2, 2, 1, EPI_LINEAR, true>()) return e;
   if (int e = set_attr<4, 1, 1, 1, EPI_LINEAR, true>()) return e;
-  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI_LINEAR, false, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
+  X6P_ATTR(EPI_LINEAR, false, true, 3, false);
+  X6P_ATTR(EPI_LINEAR, false, true, 3, true);
+  X6P_ATTR(EPI_LINEAR, false, true, 2, true);
   if (int e = set_attr_x6<EPI_LINEAR, false>()) return e;
   if (int e = set_attr_x6<EPI_LINEAR, true>()) return e;
   if (int e = set_attr_x6<EPI_GEGLU_FWD, false>()) return e;

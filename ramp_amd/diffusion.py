@@ -247,6 +247,11 @@ class _GaussianDiffusionBase(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(_lib.load().ramp_sample(m.ctx(), C.byref(p), _lib.ptr(noise), _lib.ptr(chain), _lib.ptr(x_out),
                                                _lib.current_stream()), "ramp_sample")
+            flag = C.c_int32(0)
+            _lib.check(_lib.load().ramp_range_status(m.ctx(), C.byref(flag), _lib.current_stream()), "ramp_range_status")
+            if flag.value:
+                raise _lib.RampHipError("fp16x3 GEMM: an operand left the fp16 range between two score evaluations; "
+                                        "rebuild the model with gemm_mode='bf16x6'")
         return x_out, chain
 
     # ------------------------------------------------------------------ loops (reference signatures)

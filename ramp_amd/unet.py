@@ -47,7 +47,7 @@ class TemporalUnetInference(nn.Module):
         self.scene_encoder = ObstacleEncoder() if obstacle_3d else ObstacleEncoderSet()
         self.max_rows = int(max_rows)
         self.debug_taps = bool(debug_taps)
-        self.gemm_mode = {"default": 0, "fp32": 1, "bf16x6": 2}[gemm_mode]
+        self.gemm_mode = {"default": 0, "fp32": 1, "bf16x6": 2, "fp16x3": 3}[gemm_mode]
         self._unet_keys = [k for k in unet_param_shapes(self.spec, with_scene_encoder=False)]
         self._unet_shapes = unet_param_shapes(self.spec, with_scene_encoder=False)
         self._weights: "OrderedDict[str, torch.Tensor]" = OrderedDict()   # host fp32 copies (checkpoint truth)

@@ -48,12 +48,14 @@ def test_ddpm_chain_free_running(tag, nwn, graph):
     assert np.array_equal(chain[:, :, 47], np.broadcast_to(synth.default_hard_conds(4, 48)[47], chain[:, :, 47].shape))
 
 
-def test_ddpm_chain_exact_fp32_mfma_mode():
-    """The exact-fp32 MFMA GEMM mode (v_mfma_f32_32x32x2_f32) against the same reference chain."""
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "fp16x3"])
+def test_ddpm_chain_every_gemm_mode(mode):
+    """The same reference chain in each GEMM mode: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bf16x6 (three bf16 planes,
+    six products) and fp16x3 (two scaled fp16 planes, three products; its first evaluation calibrates in bf16x6)."""
     g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
-    chain, _ = run(make_static(25, gemm_mode="fp32"), g, 4)
+    chain, _ = run(make_static(25, gemm_mode=mode), g, 4)
     err = np.abs(chain - g["chain"]).max()
-    print(f"ddpm plain fp32-MFMA mode: max {err:.2e}")
+    print(f"ddpm plain {mode} mode: max {err:.2e}")
     assert err < 1e-4
 
 
