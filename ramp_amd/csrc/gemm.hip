@@ -605,6 +605,15 @@ __device__ __forceinline__ f32x16 mfma_planes(const u32x4 a, const u32x4 b, cons
   if (NP == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }
+// x * s with plain v_mul_f32 (hipcc SLP-packs adjacent multiplies into v_pk_mul_f32, which costs ~13 extra cycles beside MFMAs)
+__device__ __forceinline__ void scale4(f32x4& v, float sc) {
+  float r0, r1, r2, r3;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r0) : "v"(v[0]), "v"(sc));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r1) : "v"(v[1]), "v"(sc));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r2) : "v"(v[2]), "v"(sc));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r3) : "v"(v[3]), "v"(sc));
+  v = f32x4{r0, r1, r2, r3};
+}
 // one plane of four floats: two packed 16-bit pairs, and (optionally) the floats with that plane removed
 template <int NP>
 __device__ __forceinline__ u32x2 peel4(f32x4& v, bool subtract) {
@@ -617,8 +626,15 @@ __device__ __forceinline__ u32x2 peel4(f32x4& v, bool subtract) {
     }
   } else {
     const half2v h0 = __builtin_convertvector(f32x2{v[0], v[1]}, half2v), h1 = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
-    if (subtract) { v[0] -= (float)h0[0]; v[1] -= (float)h0[1]; v[2] -= (float)h1[0]; v[3] -= (float)h1[1]; }
     q[0] = __builtin_bit_cast(unsigned, h0); q[1] = __builtin_bit_cast(unsigned, h1);
+    if (subtract) {     // residual in ONE mixed-precision FMA per element: x - h read straight from the packed fp16 half
+      float r0, r1, r2, r3;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(q[0]), "v"(v[0]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(q[0]), "v"(v[1]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(q[1]), "v"(v[2]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(q[1]), "v"(v[3]));
+      v = f32x4{r0, r1, r2, r3};
+    }
   }
   return q;
 }
@@ -671,19 +687,23 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 
   // ---- A loader (runs one slab ahead of the LDS stores, across tile boundaries) -------------------
   int ld_tile = t_begin, ld_it = 0;
-  const float* ap[AI];
-  const float* sp[AMUL ? AI : 1];
+  const char* abase = nullptr; const char* sbase = nullptr;     // uniform tile bases (plain linear): SGPR base + 32-bit lane offset
+  unsigned aoff[AI]; unsigned soff[AMUL ? AI : 1];
   int a_l[GEN ? AI : 1]; long a_m[GEN ? AI : 1];
   const int Lin = GEN ? a.L * a.a_stride : 0;
   auto setup_rows = [&](int tile) {
     const int tile_m = tile / tiles_n;
+    if (!GEN) {
+      abase = reinterpret_cast<const char*>(a.A + (long)tile_m * BM * a.lda);
+      if (AMUL) sbase = reinterpret_cast<const char*>(a.Amul + (long)tile_m * BM * a.lda_mul);
+    }
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       int m = tile_m * BM + r0 + 32 * i;
       if (!GEN) {
         m = m < a.M ? m : a.M - 1;
-        ap[i] = a.A + (long)m * a.lda + c4 * 4;
-        if (AMUL) sp[i] = a.Amul + (long)m * a.lda_mul + c4 * 4;
+        aoff[i] = (unsigned)(m - tile_m * BM) * (unsigned)a.lda * 4u + c4 * 16u;
+        if (AMUL) soff[i] = (unsigned)(m - tile_m * BM) * (unsigned)a.lda_mul * 4u + c4 * 16u;
       } else {
         const bool mv = m < a.M;
         m = mv ? m : 0;
@@ -701,10 +721,10 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         if (AMUL) {
-          ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0 % a.a_period);
-          rs[i] = *reinterpret_cast<const f32x4*>(sp[i] + k0);
+          ra[i] = *reinterpret_cast<const f32x4*>(abase + (long)(k0 % a.a_period) * 4 + aoff[i]);
+          rs[i] = *reinterpret_cast<const f32x4*>(sbase + (long)k0 * 4 + soff[i]);
         } else {
-          ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+          ra[i] = *reinterpret_cast<const f32x4*>(abase + (long)k0 * 4 + aoff[i]);
         }
       }
     } else {
@@ -728,8 +748,8 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       f32x4 v = AMUL ? ra[i] * rs[i] : ra[i];
-      if (REC) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-      if (NP == 2) v *= s_a;
+      if (REC) { amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), amax); amax = fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), amax); }
+      if (NP == 2) scale4(v, s_a);
       const int rowa = r0 + 32 * i;
       const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
 #pragma unroll
@@ -746,7 +766,9 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   };
 
   // ---- W fragments: straight from the packed planes ----------------------------------------------
-  const unsigned short* wl = a.Wx + lane * 8;
+  const char* wl = reinterpret_cast<const char*>(a.Wx);   // uniform: the fragment loads use an SGPR base + the lane's 16 bytes
+  const unsigned wlane = lane * 16;
+  constexpr long WBLK = NP * 1024;                    // bytes per fragment block
   auto w_blocks = [&](int tile, long (&blk)[NI]) {      // first fragment block of this wave's two 32-column groups
     const int tile_m = tile / tiles_n;
     const int n0 = (tile - tile_m * tiles_n) * BN + wn * 64;
@@ -763,9 +785,9 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
     else { const int tap = it / nk; kb = tap * tap_blocks + 2 * (it - tap * nk) + s2; }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const unsigned short* q = wl + (blk[ni] + kb) * (NP * 512);
+      const char* q = wl + (blk[ni] + kb) * WBLK;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) dst[p][ni] = *reinterpret_cast<const u32x4*>(q + p * 512);
+      for (int p = 0; p < NP; ++p) dst[p][ni] = *reinterpret_cast<const u32x4*>(q + p * 1024 + wlane);
     }
   };
 
@@ -832,13 +854,16 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
           acc[(j >> 1) & 1][j & 1] = mfma_planes<NP>(av[0][PA[j >> 2]][(j >> 1) & 1], bw[0][PB[j >> 2]][j & 1], acc[(j >> 1) & 1][j & 1]);
           if (j < 2 * NP) {
             const int p = j >> 1, x = j & 1;
-            bw[1][p][x] = *reinterpret_cast<const u32x4*>(wl + (wblk[x] + kb) * (NP * 512) + p * 512);
+            bw[1][p][x] = *reinterpret_cast<const u32x4*>(wl + (wblk[x] + kb) * WBLK + p * 1024 + wlane);
             av[1][p][x] = *reinterpret_cast<const u32x4*>(cur + p * PLANE + arow + x * 32 * XLD + (((2 + h) ^ sw) << 3));
           } else if (j < 6 * NP) {
             const int i = (j - 2 * NP) / NP, st = (j - 2 * NP) % NP;
             if (AMUL && st == 0) ra[i] *= rs[i];
-            if (REC && st == 0) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(ra[i][0]), fabsf(ra[i][1])), fmaxf(fabsf(ra[i][2]), fabsf(ra[i][3]))));
-            if (NP == 2 && st == 0) ra[i] *= s_a;
+            if (REC && st == 0) {                                 // two v_max3_f32 per float4
+              amax = fmaxf(fmaxf(fabsf(ra[i][0]), fabsf(ra[i][1])), amax);
+              amax = fmaxf(fmaxf(fabsf(ra[i][2]), fabsf(ra[i][3])), amax);
+            }
+            if (NP == 2 && st == 0) scale4(ra[i], s_a);
             const int rowa = r0 + 32 * i;
             const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
             *reinterpret_cast<u32x2*>(oth + st * PLANE + off) = peel4<NP>(ra[i], st + 1 < NP);
@@ -856,7 +881,7 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
           acc[(j >> 1) & 1][j & 1] = mfma_planes<NP>(av[1][PA[j >> 2]][(j >> 1) & 1], bw[1][PB[j >> 2]][j & 1], acc[(j >> 1) & 1][j & 1]);
           if (j < 2 * NP) {
             const int p = j >> 1, x = j & 1;
-            bw[0][p][x] = *reinterpret_cast<const u32x4*>(wl + (wsel[x] + kb) * (NP * 512) + p * 512);
+            bw[0][p][x] = *reinterpret_cast<const u32x4*>(wl + (wsel[x] + kb) * WBLK + p * 1024 + wlane);
             av[0][p][x] = *reinterpret_cast<const u32x4*>(oth + p * PLANE + arow + x * 32 * XLD + ((h ^ sw) << 3));
           }
           __builtin_amdgcn_sched_barrier(0);
