@@ -41,6 +41,12 @@ __global__ void permute3_kernel(const float* __restrict__ in, float* __restrict_
     out[((long)i[p0] * O1 + i[p1]) * O2 + i[p2]] = in[idx];
   }
 }
+// (a kernel node rather than a memset node: in the T = 50 jobs (config 5) the memset nodes of the captured graph were
+//  replayed with a stale fill pattern -- 0x1c1c1c1c instead of 0 -- on ROCm 7.2; eager runs and T = 25 graphs were fine)
+__global__ void zero_words_kernel(unsigned* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
 // rows of ff.net.0.proj (2F, K) -> tiles of [64 a-rows | 64 matching g-rows] (EPI_GEGLU_FWD); K = 1 for the bias
 __global__ void geglu_pack_kernel(const float* __restrict__ in, float* __restrict__ out, int F, int K) {
   const long n = (long)2 * F * K;
@@ -340,6 +346,7 @@ struct Run {
             if (c->phase == 2 && e.packed3) {
               b.Wx = e.packed3 + 2 * off; b.wx_packed = 2; b.w_scale_inv = e.w_scale_inv;
               b.a_absmax_in = c->obs_in + c->site; b.a_absmax_out = c->obs_out + c->site; b.range_flag = c->range_flag;
+              b.site_id = c->site;
             } else {
               b.Wx = e.packed + 3 * off; b.wx_packed = 1;
               if (c->phase >= 1) b.a_absmax_out = c->obs_out + c->site;
@@ -1106,17 +1113,28 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
   if (chain) RAMP_HIP_CHECK(hipMemcpyAsync(c->s_chain, c->s_x, n * 4, hipMemcpyDeviceToDevice, s));
   ApfArgs ap; ap.cloud = c->s_cloud; ap.window = c->s_window; ap.B = B; ap.H = H; ap.S = S; ap.P = p->apf.n_points;
   ap.win = p->apf.window; ap.thr = p->apf.threshold; ap.strength = p->apf.strength;
-  if (c->gemm_mode == 2) RAMP_HIP_CHECK(hipMemsetAsync(c->range_flag, 0, sizeof(int), s));
+  if (c->gemm_mode == 2) {
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<unsigned*>(c->range_flag), 1);
+    RAMP_HIP_CHECK(hipGetLastError());
+  }
   for (int j = 0; j < p->n_steps; ++j) {
     if (c->gemm_mode == 2) {
       // evaluation 0 calibrates (bf16x6 + recorded operand maxima); evaluation j >= 1 runs fp16x3 scaled from j - 1
       c->phase = j == 0 ? 1 : 2;
       c->obs_out = c->obs + (j & 1) * ramp_ctx::MAX_SITES;
       c->obs_in = c->obs + ((j & 1) ^ 1) * ramp_ctx::MAX_SITES;
-      RAMP_HIP_CHECK(hipMemsetAsync(c->obs_out, 0, ramp_ctx::MAX_SITES * sizeof(float), s));
+      hipLaunchKernelGGL(zero_words_kernel, dim3(ramp_ctx::MAX_SITES / 256), dim3(256), 0, s,
+                         reinterpret_cast<unsigned*>(c->obs_out), ramp_ctx::MAX_SITES);
+      RAMP_HIP_CHECK(hipGetLastError());
     }
     const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s);
     if (getenv("RAMP_X6_WARN") && j < 2) fprintf(stderr, "[ramp] step %d phase %d sites %d\n", j, c->phase, c->site);
+    if (getenv("RAMP_X6_WARN") && c->range_flag && !p->use_graph) {      // eager debugging: which evaluation trips the guard
+      int f = 0;
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(&f, c->range_flag, sizeof(int), hipMemcpyDeviceToHost);
+      if (f) { fprintf(stderr, "[ramp] range flag %d after evaluation %d\n", f, j); }
+    }
     c->phase = 0;
     CK(rc_score);
     CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = p->n_rp;
@@ -1433,6 +1451,14 @@ int ramp_range_status(ramp_ctx* c, int32_t* flag, void* stream) {
   if (c->range_flag) {
     RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
     RAMP_HIP_CHECK(hipMemcpy(flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (*flag && getenv("RAMP_X6_WARN")) {
+      std::vector<float> o(2 * ramp_ctx::MAX_SITES);
+      RAMP_HIP_CHECK(hipMemcpy(o.data(), c->obs, o.size() * sizeof(float), hipMemcpyDeviceToHost));
+      const int sidx = std::min(std::max(*flag - 1, 0), ramp_ctx::MAX_SITES - 4);
+      fprintf(stderr, "[ramp] fp16 range flag %d (call site + 1): recorded maxima (ping, pong) = %g, %g; neighbours:", *flag, o[sidx], o[ramp_ctx::MAX_SITES + sidx]);
+      for (int k = std::max(0, sidx - 3); k < sidx + 4; ++k) fprintf(stderr, " [%d] %g/%g", k, o[k], o[ramp_ctx::MAX_SITES + k]);
+      fprintf(stderr, "\n");
+    }
   }
   return 0;
 }

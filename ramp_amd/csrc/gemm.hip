@@ -639,9 +639,10 @@ __device__ __forceinline__ u32x2 peel4(f32x4& v, bool subtract) {
   return q;
 }
 // REC: the launch also records max |A_eff| (atomic max into a.a_absmax_out) -- the fp16 planes of the NEXT evaluation of
-// the same call site are scaled from it (delayed scaling: A * 2^(10 - floor(log2 max)) lands in [2^10, 2^11) with
-// 2^4.9 of headroom before fp16 overflows and 2^-24 of the maximum still a normal number); a launch whose scaled
-// operand reaches 60000 raises a.range_flag.  All scales are powers of two and are undone exactly in the epilogue.
+// the same call site are scaled from it (delayed scaling: A * 2^(5 - floor(log2 max)) lands in [2^5, 2^6): the operand
+// may grow 2^9.9-fold between two evaluations before fp16 overflows, elements down to 2^-8 of the maximum keep all
+// 22 bits and smaller ones an absolute error of 2^-30 of the maximum); a launch whose scaled operand reaches 60000,
+// or whose largest scaled element falls below 2^-3, raises a.range_flag.  All scales are powers of two and are undone exactly in the epilogue.
 template <int EPI, bool GEN, bool AMUL = false, int NP = 3, bool REC = false>
 __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
@@ -651,7 +652,7 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
     const float mx = a.a_absmax_in ? *a.a_absmax_in : 0.f;
     if (mx > 0.f) {
       int eb = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu);       // biased exponent: mx in [2^(eb-127), 2^(eb-126))
-      int sb = 264 - eb;                                                      // 2^(10 - (eb - 127))
+      int sb = 259 - eb;                                                      // 2^(5 - (eb - 127))
       sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
       s_a = __builtin_bit_cast(float, (unsigned)sb << 23);
     }
@@ -901,7 +902,10 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
     if (lane == 0) {
       if (a.a_absmax_out) atomicMax(reinterpret_cast<unsigned*>(a.a_absmax_out), __builtin_bit_cast(unsigned, amax));
-      if (NP == 2 && a.range_flag && !(amax * s_a < 60000.f)) atomicOr(a.range_flag, 1);
+      // overflow (the operand grew > 2^9.9-fold since the maximum was recorded) or loss of bits (it shrank > 2^8-fold:
+      // even its largest element no longer fills both planes); 1-based call site
+      if (NP == 2 && a.range_flag && (!(amax * s_a < 60000.f) || (amax > 0.f && amax * s_a < 0.125f)))
+        atomicMax(a.range_flag, a.site_id + 1);
     }
   }
 }
