@@ -46,6 +46,7 @@ struct GemmArgs {
   // where to flag a scaled operand leaving the fp16 range; 1 / (power-of-two scale the packed weights carry)
   const float* a_absmax_in = nullptr; float* a_absmax_out = nullptr; int* range_flag = nullptr; float w_scale_inv = 1.f;
   int site_id = 0;
+  int geglu_group = 64;                                     // EPI_GEGLU_FWD weight tiling: [group a-rows | group g-rows]
   const float* Amul = nullptr; int lda_mul = 0; int a_period = 0;   // optional: A_eff[m][k] = A[m][k % a_period] * Amul[m][k]
   int wx_packed = 0;                                        // 1: Wx is fragment-packed [taps*N/32][K/16][3][64][8] bf16 (launch_pack_x6); 2: [..][2][64][8] fp16 (launch_pack_h3)
   const float* bias = nullptr;                              // [N]

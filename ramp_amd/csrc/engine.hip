@@ -47,13 +47,14 @@ __global__ void zero_words_kernel(unsigned* __restrict__ p, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0u;
 }
-// rows of ff.net.0.proj (2F, K) -> tiles of [64 a-rows | 64 matching g-rows] (EPI_GEGLU_FWD); K = 1 for the bias
-__global__ void geglu_pack_kernel(const float* __restrict__ in, float* __restrict__ out, int F, int K) {
+// rows of ff.net.0.proj (2F, K) -> tiles of [G a-rows | G matching g-rows] (EPI_GEGLU_FWD; G = 64 for the block-level LDS
+// epilogue, 32 for the wave-private epilogue of the pipelined kernels); K = 1 for the bias
+__global__ void geglu_pack_kernel(const float* __restrict__ in, float* __restrict__ out, int F, int K, int G) {
   const long n = (long)2 * F * K;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
     const int p = (int)(idx / K), k = (int)(idx - (long)p * K);
-    const int t = p >> 7, c = p & 127;
-    const int src = c < 64 ? 64 * t + c : F + 64 * t + (c - 64);
+    const int t = p / (2 * G), c = p - t * 2 * G;
+    const int src = c < G ? G * t + c : F + G * t + (c - G);
     out[idx] = in[(long)src * K + k];
   }
 }
@@ -160,6 +161,7 @@ struct ramp_ctx {
   struct X6W { unsigned short* planes; size_t n; int K; unsigned short* packed; unsigned short* packed3; float w_scale_inv; };
   std::map<const float*, X6W> x6;
   int x6_pipe = 1;                   // 1 = fragment-packed weights + pipelined kernel (RAMP_X6_PIPE=0: LDS-staged weights)
+  int geglu_group = 64;              // GEGLU weight tiling (32 with the pipelined kernels' wave-private epilogue)
   // fp16x3 (gemm_mode 2): delayed operand scaling.  phase 0 = bf16x6; 1 = bf16x6 that records max|A| per GEMM call site
   // (the calibration evaluation: the first score evaluation of every ramp_sample); 2 = fp16x3 scaled from the
   // previous evaluation's maxima, recording its own.  obs[2][MAX_SITES] floats, ping-pong by evaluation.
@@ -306,8 +308,8 @@ int build_st(ramp_ctx* c, ST& s) {
     CK(pack_linear(c, t + ".ff.net.0.proj.weight", 2048, D, false, &k.w1_f, &k.w1_b));
     CK(get_raw(c, t + ".ff.net.0.proj.bias", {2048}, &k.b1));
     CK(dev_alloc(c, &k.w1_pk, 2048 * D)); CK(dev_alloc(c, &k.b1_pk, 2048));
-    hipLaunchKernelGGL(geglu_pack_kernel, dim3(1024), dim3(256), 0, 0, k.w1_f, k.w1_pk, 1024, D);
-    hipLaunchKernelGGL(geglu_pack_kernel, dim3(8), dim3(256), 0, 0, k.b1, k.b1_pk, 1024, 1);
+    hipLaunchKernelGGL(geglu_pack_kernel, dim3(1024), dim3(256), 0, 0, k.w1_f, k.w1_pk, 1024, D, c->geglu_group);
+    hipLaunchKernelGGL(geglu_pack_kernel, dim3(8), dim3(256), 0, 0, k.b1, k.b1_pk, 1024, 1, c->geglu_group);
     RAMP_HIP_CHECK(hipGetLastError());
     CK(pack_linear(c, t + ".ff.net.2.weight", D, 1024, false, &k.w2_f, &k.w2_b));
     CK(get_raw(c, t + ".ff.net.2.bias", {D}, &k.b2));
@@ -476,6 +478,7 @@ int st_forward(Run& r, ST& m, const float* x) {
     LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(k.a_z1, k.ln3_g, k.ln3_b, c->t_ln, M, r.s));
     GemmArgs u = lin(c->t_ln, D, k.w1_pk, k.b1_pk, k.a_ag, 2048, M, 2048, D);
     u.epi = EPI_GEGLU_FWD; u.aux_out = c->t_hg; u.ld_aux = 1024;        // writes ag (stash) and hg = a * gelu(g)
+    u.geglu_group = c->geglu_group;
     CK(r.gemm(u));
     GemmArgs f = lin(c->t_hg, 1024, k.w2_f, k.b2, k.a_z2, D, M, D, 1024);
     f.resid = k.a_z1; f.ldr = D;
@@ -847,6 +850,15 @@ int ramp_load_weight(ramp_ctx* c, const char* name, const float* data, const int
 
 int ramp_finalize_weights(ramp_ctx* c) {
   RAMP_REQUIRE(c && !c->finalized, "bad context state");
+  {
+    const char* env = getenv("RAMP_GEMM_MODE");
+    c->gemm_mode = c->cfg.gemm_mode == 1 ? 0 : c->cfg.gemm_mode == 2 ? 1 : c->cfg.gemm_mode == 3 ? 2
+                 : (env && std::string(env) == "fp16x3") ? 2 : (env && std::string(env) == "bf16x6") ? 1
+                 : (env && std::string(env) == "fp32") ? 0 : RAMP_DEFAULT_GEMM_MODE;
+    const char* pe = getenv("RAMP_X6_PIPE");
+    c->x6_pipe = !(pe && pe[0] == '0');
+    c->geglu_group = (c->gemm_mode >= 1 && c->x6_pipe) ? 32 : 64;
+  }
   const int nl = c->cfg.n_levels, S = c->cfg.state_dim, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim;
   const size_t cap = (size_t)c->cfg.max_rows;
   std::vector<int> dims = {S};
@@ -941,15 +953,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
   c->skip_grad.assign(nl, nullptr);
   for (int k = 1; k < nl; ++k) CK(dev_alloc(c, &c->skip_grad[k], cap * c->sts[k].L * c->sts[k].C));
   // bf16x6 planes of every GEMM weight with N >= 128
-  {
-    const char* env = getenv("RAMP_GEMM_MODE");
-    c->gemm_mode = c->cfg.gemm_mode == 1 ? 0 : c->cfg.gemm_mode == 2 ? 1 : c->cfg.gemm_mode == 3 ? 2
-                 : (env && std::string(env) == "fp16x3") ? 2 : (env && std::string(env) == "bf16x6") ? 1
-                 : (env && std::string(env) == "fp32") ? 0 : RAMP_DEFAULT_GEMM_MODE;
-  }
   if (c->gemm_mode >= 1) {
-    const char* pe = getenv("RAMP_X6_PIPE");
-    c->x6_pipe = !(pe && pe[0] == '0');
     auto reg = [&](const float* w, size_t n, int K) -> int {
       if (!w || c->x6.count(w)) return 0;
       float *p, *q = nullptr;

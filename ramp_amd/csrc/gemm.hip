@@ -593,6 +593,119 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 //   barrier
 //   step 1 of slab s : MFMAs(s, k16 1)  ||  W(s+1, k16 0) -> regs, A frags (s+1, k16 0) <- LDS, global A loads of slab s+2
 // so every global / LDS access of a wave is issued one k16 step (24 MFMAs) before its consumer.
+// Wave-private epilogue of the pipelined kernels: every wave transposes its own 64 x 64 quadrant through 8.5 KB of LDS
+// that only it touches (two passes of 32 rows), so the block needs no barrier inside the epilogue and all four waves
+// work at once; the rows still leave as 16-byte stores (a store instruction covers 4 rows x 256 contiguous bytes).
+// GEGLU forward expects the weights tiled [32 a-rows | 32 g-rows] so that a wave's two 32-column halves hold matching
+// (a, g) pairs.  Same fused math as `epilogue` (bias, per-row-variant bias, residuals, GEGLU forward / backward).
+template <int EPI, bool GEN, bool OSC>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x16 (&acc)[2][2], float* Sw, int tile, int tiles_n,
+                                              int lane, int wm, int wn, int r, int h, const float oscale) {
+  constexpr int SLD = 68;                                  // floats per scratch row (64 + pad: conflict-free b128 reads)
+  const int tile_m = tile / tiles_n;
+  const int n0 = (tile - tile_m * tiles_n) * 128;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m0 = tile_m * 128 + wm * 64 + mi * 32;
+    if (EPI == EPI_GEGLU_FWD) {
+      const int rl0 = lane >> 3, c = (lane & 7) * 4;       // 4 passes of 8 rows; 8 lanes per row
+      const int nb = n0 + wn * 64;
+      const int half = a.N >> 1, j = (n0 >> 1) + wn * 32 + c;
+      f32x4 ba = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+      if (a.bias) { ba = *reinterpret_cast<const f32x4*>(a.bias + nb + c); bg = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 + c); }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          Sw[((reg & 3) + 8 * (reg >> 2) + 4 * h) * SLD + ni * 32 + r] = acc[mi][ni][reg];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int rl = p * 8 + rl0, m = m0 + rl;
+        f32x4 av = *reinterpret_cast<const f32x4*>(Sw + rl * SLD + c);
+        f32x4 gv = *reinterpret_cast<const f32x4*>(Sw + rl * SLD + 32 + c);
+        if (OSC) { av *= oscale; gv *= oscale; }
+        av += ba; gv += bg;
+        f32x4 hv, s1, s2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float cdf, pdf;
+          normal_cdf_pdf(gv[e], cdf, pdf);
+          s1[e] = gv[e] * cdf;                           // gelu(g)
+          s2[e] = av[e] * (cdf + gv[e] * pdf);           // a * gelu'(g)
+          hv[e] = av[e] * s1[e];                         // hg = a * gelu(g)
+        }
+        if (m < a.M) {
+          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + j) = s1;            // stash for the VJP: no transcendental
+          *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + half + j) = s2;     // is needed in the backward epilogue
+          *reinterpret_cast<f32x4*>(a.aux_out + (long)m * a.ld_aux + j) = hv;
+        }
+      }
+    } else {
+      const int rl0 = lane >> 4, c = (lane & 15) * 4;      // 8 passes of 4 rows; 16 lanes per row
+      const int n = n0 + wn * 64 + c;
+      const bool nok = n < a.N;
+      const int nc = nok ? n : 0;
+      // the global operands of the fused math are requested before the transpose (their latency hides behind it)
+      f32x4 pre0[8], pre1[EPI == EPI_GEGLU_BWD ? 8 : 1];
+      if (EPI == EPI_LINEAR) {
+        if (a.resid) {
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            const int m = m0 + p * 4 + rl0, mc = m < a.M ? m : 0;
+            const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
+            pre0[p] = *reinterpret_cast<const f32x4*>(a.resid + orow * a.ldr + nc);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int m = m0 + p * 4 + rl0, mc = m < a.M ? m : 0;
+          pre0[p] = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + nc);
+          pre1[p] = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + a.N + nc);
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          Sw[((reg & 3) + 8 * (reg >> 2) + 4 * h) * SLD + ni * 32 + r] = acc[mi][ni][reg];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      f32x4 b4 = {0, 0, 0, 0};
+      if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + nc);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int rl = p * 4 + rl0, m = m0 + rl;
+        const bool ok = nok && m < a.M;
+        const int mc = m < a.M ? m : 0;
+        const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Sw + rl * SLD + c);
+        if (OSC) v *= oscale;                            // undo the operand scales (powers of two: exact)
+        v += b4;
+        if (EPI == EPI_LINEAR) {
+          if (a.rowbias) v += *reinterpret_cast<const f32x4*>(a.rowbias + (long)a.rowvar[a.row0 + mc / a.L] * a.rb_stride + nc);
+          if (a.resid) v += pre0[p];
+          if (GEN && a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + orow * a.ldr2 + nc);
+          if (ok) {
+            if (!GEN || n < a.N1) *reinterpret_cast<f32x4*>(a.C + orow * a.ldc + n) = v;
+            else *reinterpret_cast<f32x4*>(a.C2 + orow * a.ldc2 + (n - a.N1)) = v;
+          }
+        } else {
+          const f32x4 da = v * pre0[p], dg = v * pre1[p];
+          if (ok) {
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + n) = da;
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + a.N + n) = dg;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch is rewritten by the next pass
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // AMUL: A_eff[m][k] = A[m][k % a_period] * Amul[m][k] (the GEGLU VJP d(ag) = [d(hg) s1 | d(hg) s2] formed while the
 // operand is staged, instead of a 2048-wide d(ag) round trip through HBM).
 // NP = 3: bf16x6 (three 8-bit planes, six products).  NP = 2: fp16x3 (two 11-bit planes h1 + h2 = 22 significand bits,
@@ -892,7 +1005,16 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
     }
     // the finished slab's buffer (plus its 9 KB margin) carries the C image, one wave-row at a time; the other
     // buffer already holds slab 0 of the next tile
-    epilogue<WM, WN, MI, NI, EPI, GEN, WM, NP == 2>(a, acc, smem + (parity ^ 1) * (C_IMG / 4), tile, tiles_n, tid, wm, wn, r, h, oscale);
+    {
+      // scratch of wave w: 8.5 KB inside the finished slab's buffer + margins (the other buffer holds the next slab);
+      // waves 0..2 in the contiguous buffer + margin region, wave 3 in the margin at the far end
+      const int pc = parity ^ 1;
+      constexpr int WS = 32 * 68;                                     // floats per wave scratch
+      static_assert(3 * WS * 4 <= C_IMG && WS * 4 <= MARGIN, "wave scratch does not fit");
+      float* Sw = wave < 3 ? smem + pc * (C_IMG / 4) + wave * WS : smem + (pc ? 0 : (C_IMG + BUF * 2) / 4);
+      epilogue_wave<EPI, GEN, NP == 2>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale);
+      __syncthreads();                                                // the next slab's stores reuse this buffer
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) wblk[ni] = wnext[ni];
   }
@@ -1045,6 +1167,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if (a.epi == EPI_GEGLU_FWD) {
     RAMP_REQUIRE(!gen && a.N % 256 == 0 && a.aux_out && !a.resid && !a.rowbias,
                  "GEGLU-forward epilogue needs a plain linear with N % 256 == 0 and aux_out");
+    RAMP_REQUIRE((x6 && a.wx_packed != 0) == (a.geglu_group == 32), "GEGLU weight tiling: [32 a | 32 g] for the pipelined kernels, [64 a | 64 g] otherwise");
     if (x6) return launch_x6<EPI_GEGLU_FWD, false>(a, s);
     return launch_cfg<2, 2, 2, 2, EPI_GEGLU_FWD, false>(a, 2, s);
   }
