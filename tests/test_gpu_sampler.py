@@ -328,3 +328,19 @@ def test_dynamic_run_inference_terminates_and_respects_constraints():
     last = chain[-1, 0].cpu().numpy()
     assert np.allclose(last[0, :2], [0.05, -0.05]) and np.allclose(last[-1], [0.15, 0.05, 0, 0])
     assert np.isfinite(chain.cpu().numpy()).all()
+
+
+def test_fp16x3_chunking_and_repeat_are_bitwise():
+    """fp16x3 operand scales come from the maxima over ALL rows of the previous evaluation, so splitting the rows into
+    chunks (max_rows 16 -> 8 rows x 4 chunks here) must not change a bit, and neither must running the job again."""
+    g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
+    noise = synth.make_noise((26, 16, 48, 4), seed=77)
+    noise[:, :4] = g["noise"]
+    gg = {"noise": noise, "cloud": g["cloud"]}
+    whole, _ = run(make_static(25, max_rows=64, gemm_mode="fp16x3"), gg, 16)
+    dm = make_static(25, max_rows=8, gemm_mode="fp16x3")
+    a, _ = run(dm, gg, 16)
+    b, _ = run(dm, gg, 16)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, whole)
+    assert np.abs(a[:, :4] - g["chain"]).max() < 1e-4
