@@ -926,6 +926,7 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   load_tile();
   w_blocks(t_begin, wblk);
   load_w(bw[0], wblk, 0, 0);
+  load_w(bw[1], wblk, 0, 1);                          // (the first slab of a tile finds both of its steps' fragments loaded)
   store_tile(Ax);
   advance_loader();
   load_tile();
@@ -968,7 +969,7 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
           acc[(j >> 1) & 1][j & 1] = mfma_planes<NP>(av[0][PA[j >> 2]][(j >> 1) & 1], bw[0][PB[j >> 2]][j & 1], acc[(j >> 1) & 1][j & 1]);
           if (j < 2 * NP) {
             const int p = j >> 1, x = j & 1;
-            bw[1][p][x] = *reinterpret_cast<const u32x4*>(wl + (wblk[x] + kb) * WBLK + p * 1024 + wlane);
+            if (it != 0) bw[1][p][x] = *reinterpret_cast<const u32x4*>(wl + (wblk[x] + kb) * WBLK + p * 1024 + wlane);
             av[1][p][x] = *reinterpret_cast<const u32x4*>(cur + p * PLANE + arow + x * 32 * XLD + (((2 + h) ^ sw) << 3));
           } else if (j < 6 * NP) {
             const int i = (j - 2 * NP) / NP, st = (j - 2 * NP) % NP;
@@ -1005,6 +1006,9 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
     }
     // the finished slab's buffer (plus its 9 KB margin) carries the C image, one wave-row at a time; the other
     // buffer already holds slab 0 of the next tile
+    // vmcnt is in order on gfx9: a load younger than the epilogue's 32 stores cannot be waited for before those stores
+    // are acknowledged, so everything the next tile needs during its first slab is requested BEFORE the epilogue
+    load_w(bw[1], wnext, 0, 1);
     {
       // scratch of wave w: 8.5 KB inside the finished slab's buffer + margins (the other buffer holds the next slab);
       // waves 0..2 in the contiguous buffer + margin region, wave 3 in the margin at the far end
