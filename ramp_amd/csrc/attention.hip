@@ -19,6 +19,15 @@
 
 namespace ramp {
 
+// Every wave owns one (row, head) problem and its own LDS tile, so nothing is shared across the block: the waves only
+// need their own LDS writes ordered before their own (cross-lane) LDS reads.  A wave's LDS instructions execute in
+// issue order, so a compiler-level fence is enough; a block barrier here would make four independent problems march
+// in lockstep through their load / MFMA / store phases.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int L> struct A2 {
@@ -150,7 +159,7 @@ __device__ __forceinline__ void transpose_tiles(f32x4 (&m)[A2<L>::T][A2<L>::T], 
     for (int ti = 0; ti < C::T; ++ti)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) tile[(16 * tj + 4 * g + reg) * C::TS + 16 * ti + c] = m[tj][ti][reg];
-  __syncthreads();
+  wave_sync();
   f32x4 n[C::T][C::T];
 #pragma unroll
   for (int ti = 0; ti < C::T; ++ti)
@@ -158,7 +167,7 @@ __device__ __forceinline__ void transpose_tiles(f32x4 (&m)[A2<L>::T][A2<L>::T], 
     for (int tj = 0; tj < C::T; ++tj)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) n[ti][tj][reg] = tile[(16 * tj + c) * C::TS + 16 * ti + 4 * g + reg];
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int a = 0; a < C::T; ++a)
 #pragma unroll
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(const float* __restrict_
   }
   softmax_keys<L>(st, lane);                            // P^T
   load_tile_lds<L>(tile, qb + 512, 768, lane);          // V
-  __syncthreads();
+  wave_sync();
   float* ob = live ? o + (long)row * L * 256 + head * 64 : nullptr;
   if (live) mma_transposed_store<L>(tile, st, ob, 256, 1.f, lane);    // O^T = V^T P^T
 }
@@ -234,20 +243,20 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const float* __restrict_
   }
   // dQ^T = K^T dS^T / 8
   load_tile_lds<L>(tile, qb + 256, 768, lane);
-  __syncthreads();
+  wave_sync();
   if (live) mma_transposed_store<L>(tile, ds, gb, 768, 0.125f, lane);
-  __syncthreads();
+  wave_sync();
   // key on the lane for the products that contract over the query
   transpose_tiles<L>(pt, tile, lane);                   // P  [query-major]
   transpose_tiles<L>(ds, tile, lane);                   // dS [query-major]
   // dV^T = dO^T P
   load_tile_lds<L>(tile, db, 256, lane);
-  __syncthreads();
+  wave_sync();
   if (live) mma_transposed_store<L>(tile, pt, gb + 512, 768, 1.f, lane);
-  __syncthreads();
+  wave_sync();
   // dK^T = Q^T dS / 8
   load_tile_lds<L>(tile, qb, 768, lane);
-  __syncthreads();
+  wave_sync();
   if (live) mma_transposed_store<L>(tile, ds, gb + 256, 768, 0.125f, lane);
 }
 
