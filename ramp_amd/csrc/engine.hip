@@ -335,7 +335,7 @@ struct Run {
   int gemm(const GemmArgs& a) {
     prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, a.taps});
     GemmArgs b = a;
-    if (c->gemm_mode >= 1 && b.N >= 128) {
+    if (c->gemm_mode >= 1 && (b.N >= 128 || (c->x6_pipe && b.N >= 64))) {
       auto it = c->x6.upper_bound(b.W);
       if (it != c->x6.begin()) {
         --it;
@@ -1321,7 +1321,7 @@ int ramp_op_gemm(const float* A, const float* W, const float* bias, const float*
   GemmArgs a; a.A = A; a.lda = K; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.C = C; a.ldc = N;
   a.M = M; a.N = N; a.K = K; a.taps = taps; a.shift0 = shift0; a.shift_step = shift_step; a.L = L;
   const char* env = getenv("RAMP_GEMM_MODE");
-  if (env && std::string(env) == "fp16x3" && N >= 128 && N % 32 == 0 && K % 16 == 0) {
+  if (env && std::string(env) == "fp16x3" && N >= 64 && N % 32 == 0 && K % 16 == 0) {
     static std::map<const float*, unsigned short*> cache3;
     const long n = (long)taps * N * K;
     auto it = cache3.find(W);
@@ -1346,7 +1346,8 @@ int ramp_op_gemm(const float* A, const float* W, const float* bias, const float*
       return 0;
     }
   } else
-  if (env && std::string(env) == "bf16x6" && N >= 128) {       // test / micro-benchmark path: split W on the fly
+  if (env && std::string(env) == "bf16x6" && (N >= 128 || (N >= 64 && N % 32 == 0 && K % 16 == 0 && !(getenv("RAMP_X6_PIPE") && getenv("RAMP_X6_PIPE")[0] == '0')))) {
+    // test / micro-benchmark path: split W on the fly
     static std::map<const float*, unsigned short*> cache;
     const long n = (long)taps * N * K;
     auto it = cache.find(W);

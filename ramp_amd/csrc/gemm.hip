@@ -1164,7 +1164,9 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   RAMP_REQUIRE(a.a_stride >= 1 && a.c_rstride >= 1, "bad strides");
   const bool gen = a.taps > 1 || a.a_stride != 1 || a.c_rstride != 1 || a.c_roff != 0 || a.A2 || a.C2 || a.resid2 ||
                    a.shift0 != 0;
-  const bool x6 = a.Wx != nullptr && a.N >= 128;
+  // fragment-packed split-precision weights also serve N = 64 (half of every 128-wide tile is discarded, which still
+  // beats the fp32 matrix pipe: the 64-channel 5-tap convolutions were fp32-MFMA-bound at 65-80 TFLOP/s)
+  const bool x6 = a.Wx != nullptr && (a.N >= 128 || (a.wx_packed && a.N >= 64));
   RAMP_REQUIRE(a.Amul == nullptr || (x6 && a.wx_packed && !gen && a.epi == EPI_LINEAR && al16(a.Amul)),
                "the A-multiplier operand needs the pipelined bf16x6 kernel");
   RAMP_REQUIRE(!x6 || (al16(a.Wx) && a.K % 8 == 0 && (a.wx_packed ? a.N % 32 == 0 : a.wx_plane > 0)), "bad bf16x6 weight planes");
@@ -1181,8 +1183,8 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (x6) return launch_x6<EPI_GEGLU_BWD, false>(a, s);
     return launch_cfg<2, 2, 2, 2, EPI_GEGLU_BWD, false>(a, 2, s);
   }
+  if (x6) return gen ? launch_x6<EPI_LINEAR, true>(a, s) : launch_x6<EPI_LINEAR, false>(a, s);
   if (a.N >= 128) {                                              // 128 x 128, 2 blocks / CU
-    if (x6) return gen ? launch_x6<EPI_LINEAR, true>(a, s) : launch_x6<EPI_LINEAR, false>(a, s);
     if (!gen) return launch_cfg<2, 2, 2, 2, EPI_LINEAR, false>(a, 2, s);
     return launch_cfg<2, 2, 2, 2, EPI_LINEAR, true>(a, 2, s);
   }
