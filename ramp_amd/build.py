@@ -31,7 +31,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ramp_hip.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_x6p_body.inc"), os.path.join(HERE, "..", "include", "ramp_hip.h"), os.path.abspath(__file__)]
     jobs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

@@ -756,284 +756,19 @@ __device__ __forceinline__ u32x2 peel4(f32x4& v, bool subtract) {
 // may grow 2^9.9-fold between two evaluations before fp16 overflows, elements down to 2^-8 of the maximum keep all
 // 22 bits and smaller ones an absolute error of 2^-30 of the maximum); a launch whose scaled operand reaches 60000,
 // or whose largest scaled element falls below 2^-3, raises a.range_flag.  All scales are powers of two and are undone exactly in the epilogue.
+// Two blocks per CU (bf16x6, and the fp16x3 A-multiplier variant whose extra operand registers do not fit three) ...
 template <int EPI, bool GEN, bool AMUL = false, int NP = 3, bool REC = false>
 __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
-  constexpr int NMF = (NP == 3 ? 6 : 3) * 4;           // MFMAs per k16 step
-  float s_a = 1.f, oscale = 1.f, amax = 0.f;
-  if (NP == 2) {
-    const float mx = a.a_absmax_in ? *a.a_absmax_in : 0.f;
-    if (mx > 0.f) {
-      int eb = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu);       // biased exponent: mx in [2^(eb-127), 2^(eb-126))
-      int sb = 259 - eb;                                                      // 2^(5 - (eb - 127))
-      sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
-      s_a = __builtin_bit_cast(float, (unsigned)sb << 23);
-    }
-    oscale = a.w_scale_inv / s_a;
-  }
-  constexpr int WM = 2, WN = 2, MI = 2, NI = 2;
-  constexpr int BM = 128, BN = 128;
-  constexpr int AI = 4;                               // fp32 float4 loads per thread (A)
-  constexpr int PLANE = BM * XLD;                     // bf16 elements per LDS plane
-  constexpr int BUF = NP * PLANE;                     // one A buffer: NP planes
-  // LDS: [margin | buffer 0 | buffer 1 | margin]; a half-tile C image (64 x 132 floats) = one buffer + one margin
-  constexpr int C_IMG = 64 * (BN + 4) * 4;            // bytes
-  constexpr int MARGIN = C_IMG - BUF * 2;             // bytes
-  static_assert(MARGIN > 0 && MARGIN % 16 == 0, "C image must cover a buffer");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned short* Ax = reinterpret_cast<unsigned short*>(smem) + MARGIN / 2;   // [2][3][BM][XLD]
-
-  const int bid = blockIdx.x, nb = gridDim.x;
-  const int xcd = bid & 7, slot = bid >> 3, bpx = nb >> 3;
-  const long xlo = (long)xcd * n_tiles / 8, xhi = (long)(xcd + 1) * n_tiles / 8;
-  const int t_begin = (int)xlo + slot, t_end = (int)xhi, t_step = bpx;
-  if (t_begin >= t_end) return;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int c4 = tid & 7, r0 = tid >> 3;              // A staging: float4 column / first row (rows r0 + 32 i)
-
-  const int nk = a.K / BK;
-  const int total = GEN ? a.taps * nk : nk;
-  const int nk16 = a.K / 16;
-  const long tap_blocks = (long)(a.N / 32) * nk16;    // fragment blocks per tap
-
-  // ---- A loader (runs one slab ahead of the LDS stores, across tile boundaries) -------------------
-  int ld_tile = t_begin, ld_it = 0;
-  const char* abase = nullptr; const char* sbase = nullptr;     // uniform tile bases (plain linear): SGPR base + 32-bit lane offset
-  unsigned aoff[AI]; unsigned soff[AMUL ? AI : 1];
-  int a_l[GEN ? AI : 1]; long a_m[GEN ? AI : 1];
-  const int Lin = GEN ? a.L * a.a_stride : 0;
-  auto setup_rows = [&](int tile) {
-    const int tile_m = tile / tiles_n;
-    if (!GEN) {
-      abase = reinterpret_cast<const char*>(a.A + (long)tile_m * BM * a.lda);
-      if (AMUL) sbase = reinterpret_cast<const char*>(a.Amul + (long)tile_m * BM * a.lda_mul);
-    }
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      int m = tile_m * BM + r0 + 32 * i;
-      if (!GEN) {
-        m = m < a.M ? m : a.M - 1;
-        aoff[i] = (unsigned)(m - tile_m * BM) * (unsigned)a.lda * 4u + c4 * 16u;
-        if (AMUL) soff[i] = (unsigned)(m - tile_m * BM) * (unsigned)a.lda_mul * 4u + c4 * 16u;
-      } else {
-        const bool mv = m < a.M;
-        m = mv ? m : 0;
-        const int seg = m / a.L, l = m - seg * a.L;
-        a_l[i] = mv ? l * a.a_stride : -(1 << 28);
-        a_m[i] = (long)seg * Lin + l * a.a_stride;
-      }
-    }
-  };
-  f32x4 ra[AI];
-  f32x4 rs[AMUL ? AI : 1];
-  auto load_tile = [&]() {
-    if (!GEN) {
-      const int k0 = ld_it * BK;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        if (AMUL) {
-          ra[i] = *reinterpret_cast<const f32x4*>(abase + (long)(k0 % a.a_period) * 4 + aoff[i]);
-          rs[i] = *reinterpret_cast<const f32x4*>(sbase + (long)k0 * 4 + soff[i]);
-        } else {
-          ra[i] = *reinterpret_cast<const f32x4*>(abase + (long)k0 * 4 + aoff[i]);
-        }
-      }
-    } else {
-      const int tap = ld_it / nk;
-      const int k0 = (ld_it - tap * nk) * BK;
-      const int sh = a.shift0 + tap * a.shift_step;
-      const bool src1 = k0 < a.K1;                     // branch-free: the loader sits inside the MFMA stream
-      const float* Ab = src1 ? a.A : a.A2;
-      const int ld = src1 ? a.lda : a.lda2, kc = src1 ? k0 : k0 - a.K1;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        const int l = a_l[i] + sh;
-        const bool ok = l >= 0 && l < Lin;
-        const long row = ok ? a_m[i] + sh : a_m[i];
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Ab + row * ld + kc + c4 * 4);
-        ra[i] = ok ? v : f32x4{0, 0, 0, 0};
-      }
-    }
-  };
-  auto store_tile = [&](unsigned short* dst) {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      f32x4 v = AMUL ? ra[i] * rs[i] : ra[i];
-      if (REC) { amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), amax); amax = fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), amax); }
-      if (NP == 2) scale4(v, s_a);
-      const int rowa = r0 + 32 * i;
-      const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        *reinterpret_cast<u32x2*>(dst + p * PLANE + off) = peel4<NP>(v, p + 1 < NP);
-      }
-    }
-  };
-  auto advance_loader = [&]() {
-    if (++ld_it == total) {
-      ld_it = 0;
-      if (ld_tile + t_step < t_end) { ld_tile += t_step; setup_rows(ld_tile); }
-    }
-  };
-
-  // ---- W fragments: straight from the packed planes ----------------------------------------------
-  const char* wl = reinterpret_cast<const char*>(a.Wx);   // uniform: the fragment loads use an SGPR base + the lane's 16 bytes
-  const unsigned wlane = lane * 16;
-  constexpr long WBLK = NP * 1024;                    // bytes per fragment block
-  auto w_blocks = [&](int tile, long (&blk)[NI]) {      // first fragment block of this wave's two 32-column groups
-    const int tile_m = tile / tiles_n;
-    const int n0 = (tile - tile_m * tiles_n) * BN + wn * 64;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      int n = n0 + ni * 32;
-      n = n <= a.N - 32 ? n : a.N - 32;                  // columns past N only feed outputs that are never stored
-      blk[ni] = (long)(n >> 5) * nk16;
-    }
-  };
-  auto load_w = [&](u32x4 (&dst)[NP][NI], const long (&blk)[NI], int it, int s2) {
-    long kb;
-    if (!GEN) kb = 2 * it + s2;
-    else { const int tap = it / nk; kb = tap * tap_blocks + 2 * (it - tap * nk) + s2; }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const char* q = wl + (blk[ni] + kb) * WBLK;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) dst[p][ni] = *reinterpret_cast<const u32x4*>(q + p * 1024 + wlane);
-    }
-  };
-
-  const int r = lane & 31, h = lane >> 5;
-  const int arow = (wm * 64 + r) * XLD;
-  const int sw = (r >> 2) & 3;
-  auto read_a = [&](u32x4 (&dst)[NP][MI], const unsigned short* src, int s2) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        dst[p][mi] = *reinterpret_cast<const u32x4*>(src + p * PLANE + arow + mi * 32 * XLD + (((2 * s2 + h) ^ sw) << 3));
-  };
-
-  u32x4 av[2][NP][MI], bw[2][NP][NI];
-  long wblk[NI], wnext[NI];
-  constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};   // small terms first
-  constexpr int PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
-
-  // prologue: slab 0 of the first tile -> buffer 0, slab 1 parked in registers, first fragments in flight
-  setup_rows(ld_tile);
-  load_tile();
-  w_blocks(t_begin, wblk);
-  load_w(bw[0], wblk, 0, 0);
-  load_w(bw[1], wblk, 0, 1);                          // (the first slab of a tile finds both of its steps' fragments loaded)
-  store_tile(Ax);
-  advance_loader();
-  load_tile();
-  __syncthreads();
-  read_a(av[0], Ax, 0);
-
-  int parity = 0;
-  for (int tile = t_begin; tile < t_end; tile += t_step) {
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-    if (tile + t_step < t_end) w_blocks(tile + t_step, wnext);
-    else {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wnext[ni] = wblk[ni];
-    }
-    for (int it = 0; it < total; ++it) {
-      // ---- slab boundary (scheduling-region boundary): uniform bookkeeping only
-      advance_loader();                                  // the A loader now points at slab it + 2
-      const bool last = it + 1 == total;
-      const int it_next = last ? 0 : it + 1;
-      long wsel[NI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wsel[ni] = last ? wnext[ni] : wblk[ni];
-      unsigned short* cur = Ax + parity * BUF;
-      unsigned short* oth = Ax + (parity ^ 1) * BUF;
-
-      // Hand-interleaved issue order, pinned with sched_barrier(0): every MFMA is followed by a small piece of the
-      // staging work of the NEXT step (one fragment load pair, or one plane of one float4 of the split), so a
-      // single wave keeps the matrix pipe fed while its own loads / VALU / LDS stores issue in the gaps.
-      // ---- step 0: MFMAs (slab, k16 0)  ||  W (slab, k16 1), A frags (slab, k16 1), split + store of the next slab
-      {
-        const long kb = GEN ? (long)(it / nk) * tap_blocks + 2 * (it % nk) + 1 : 2 * it + 1;
-#pragma unroll
-        for (int j = 0; j < NMF; ++j) {
-          acc[(j >> 1) & 1][j & 1] = mfma_planes<NP>(av[0][PA[j >> 2]][(j >> 1) & 1], bw[0][PB[j >> 2]][j & 1], acc[(j >> 1) & 1][j & 1]);
-          if (j < 2 * NP) {
-            const int p = j >> 1, x = j & 1;
-            if (it != 0) bw[1][p][x] = *reinterpret_cast<const u32x4*>(wl + (wblk[x] + kb) * WBLK + p * 1024 + wlane);
-            av[1][p][x] = *reinterpret_cast<const u32x4*>(cur + p * PLANE + arow + x * 32 * XLD + (((2 + h) ^ sw) << 3));
-          } else if (j < 6 * NP) {
-            const int i = (j - 2 * NP) / NP, st = (j - 2 * NP) % NP;
-            if (AMUL && st == 0) ra[i] *= rs[i];
-            if (REC && st == 0) {                                 // two v_max3_f32 per float4
-              amax = fmaxf(fmaxf(fabsf(ra[i][0]), fabsf(ra[i][1])), amax);
-              amax = fmaxf(fmaxf(fabsf(ra[i][2]), fabsf(ra[i][3])), amax);
-            }
-            if (NP == 2 && st == 0) scale4(ra[i], s_a);
-            const int rowa = r0 + 32 * i;
-            const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
-            *reinterpret_cast<u32x2*>(oth + st * PLANE + off) = peel4<NP>(ra[i], st + 1 < NP);
-          }
-          if (j == (NP == 3 ? 18 : NMF - 1)) load_tile();   // global A loads two slabs ahead, as soon as ra is free
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      __syncthreads();
-      // ---- step 1: MFMAs (slab, k16 1)  ||  W / A frags of (next slab, k16 0), global A loads two slabs ahead
-      {
-        const long kb = GEN ? (long)(it_next / nk) * tap_blocks + 2 * (it_next % nk) : 2 * it_next;
-#pragma unroll
-        for (int j = 0; j < NMF; ++j) {
-          acc[(j >> 1) & 1][j & 1] = mfma_planes<NP>(av[1][PA[j >> 2]][(j >> 1) & 1], bw[1][PB[j >> 2]][j & 1], acc[(j >> 1) & 1][j & 1]);
-          if (j < 2 * NP) {
-            const int p = j >> 1, x = j & 1;
-            bw[0][p][x] = *reinterpret_cast<const u32x4*>(wl + (wsel[x] + kb) * WBLK + p * 1024 + wlane);
-            av[0][p][x] = *reinterpret_cast<const u32x4*>(oth + p * PLANE + arow + x * 32 * XLD + ((h ^ sw) << 3));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      parity ^= 1;
-    }
-    // the finished slab's buffer (plus its 9 KB margin) carries the C image, one wave-row at a time; the other
-    // buffer already holds slab 0 of the next tile
-    // vmcnt is in order on gfx9: a load younger than the epilogue's 32 stores cannot be waited for before those stores
-    // are acknowledged, so everything the next tile needs during its first slab is requested BEFORE the epilogue
-    load_w(bw[1], wnext, 0, 1);
-    {
-      // scratch of wave w: 8.5 KB inside the finished slab's buffer + margins (the other buffer holds the next slab);
-      // waves 0..2 in the contiguous buffer + margin region, wave 3 in the margin at the far end
-      const int pc = parity ^ 1;
-      constexpr int WS = 32 * 68;                                     // floats per wave scratch
-      static_assert(3 * WS * 4 <= C_IMG && WS * 4 <= MARGIN, "wave scratch does not fit");
-      float* Sw = wave < 3 ? smem + pc * (C_IMG / 4) + wave * WS : smem + (pc ? 0 : (C_IMG + BUF * 2) / 4);
-      epilogue_wave<EPI, GEN, NP == 2>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale);
-      __syncthreads();                                                // the next slab's stores reuse this buffer
-    }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wblk[ni] = wnext[ni];
-  }
-  if (REC) {
-    // (the loader also staged the first slabs of a tile it never computes: rows of this matrix, so the maximum stays valid)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if (lane == 0) {
-      if (a.a_absmax_out) atomicMax(reinterpret_cast<unsigned*>(a.a_absmax_out), __builtin_bit_cast(unsigned, amax));
-      // overflow (the operand grew > 2^9.9-fold since the maximum was recorded) or loss of bits (it shrank > 2^8-fold:
-      // even its largest element no longer fills both planes); 1-based call site
-      if (NP == 2 && a.range_flag && (!(amax * s_a < 60000.f) || (amax > 0.f && amax * s_a < 0.125f)))
-        atomicMax(a.range_flag, a.site_id + 1);
-    }
-  }
+#include "gemm_x6p_body.inc"
+}
+// ... or three (fp16x3: 168 VGPRs, 51 KB of LDS): a third resident block covers the epilogue-store stalls of the others;
+// the compiler spills registers around the epilogue (once per tile), none inside the slab loop.  Used where it
+// measured faster (launch_x6).
+template <int EPI, bool GEN, bool AMUL = false, int NP = 2, bool REC = true>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
+#include "gemm_x6p_body.inc"
 }
 
 // fp32 [rows][K] -> fragment-packed planes [rows/32][K/16][NP][64 lanes][8] (NP = 3: bf16, NP = 2: fp16)
@@ -1072,22 +807,30 @@ int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, float 
 }
 
 constexpr size_t X6_LDS = std::max<size_t>(6 * (size_t)128 * XLD * 2, (size_t)128 * 132 * 4);
+constexpr size_t X6P_LDS3 = 2 * (9216 + 3 * (size_t)128 * XLD * 2);    // pipelined, 3 planes: 67584 B (2 blocks / CU)
+constexpr size_t X6P_LDS2 = 2 * (9728 + 2 * (size_t)128 * XLD * 2);    // pipelined, 2 planes: 52224 B (3 blocks / CU)
+static_assert(X6P_LDS3 <= X6_LDS, "bf16x6 pipelined layout");
 
 template <int EPI, bool GEN>
 static int launch_x6(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + 127) / 128, tiles_n = (a.N + 127) / 128;
   const int n_tiles = tiles_m * tiles_n;
-  const int slots = 512;
+  // fp16x3 GEGLU forward (the kernel with the longest epilogue): 3 blocks per CU.  The plain shapes measured slower that
+  // way (the ~60 registers spilled around every tile's epilogue cost more than the third block hides: 228 -> 172 TFLOP/s
+  // at 393216 x 256 x 256), GEGLU forward faster (189 -> 201).
+  const bool three = a.wx_packed == 2 && !a.Amul && EPI == EPI_GEGLU_FWD;
+  const int slots = three ? 768 : 512;
   const int rounds = (n_tiles + slots - 1) / slots;
   const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
-#define X6P_LAUNCH(...) hipLaunchKernelGGL((gemm_x6p_kernel<__VA_ARGS__>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles)
+#define X6P_LAUNCH(...) hipLaunchKernelGGL((gemm_x6p_kernel<__VA_ARGS__>), dim3(nb), dim3(256), X6P_LDS3, s, a, tiles_n, n_tiles)
   const bool rec = a.a_absmax_out != nullptr;
   if (a.wx_packed && a.Amul) {
     RAMP_REQUIRE(EPI == EPI_LINEAR && !GEN && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
-    if (a.wx_packed == 2) X6P_LAUNCH(EPI_LINEAR, false, true, 2, true);
+    if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true>), dim3(nb), dim3(256), X6P_LDS2, s, a, tiles_n, n_tiles);
     else if (rec) X6P_LAUNCH(EPI_LINEAR, false, true, 3, true);
     else X6P_LAUNCH(EPI_LINEAR, false, true, 3, false);
-  } else if (a.wx_packed == 2) X6P_LAUNCH(EPI, GEN, false, 2, true);
+  } else if (three) hipLaunchKernelGGL((gemm_x6p3_kernel<EPI, GEN>), dim3(nb), dim3(256), X6P_LDS2, s, a, tiles_n, n_tiles);
+  else if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN, false, 2, true>), dim3(nb), dim3(256), X6P_LDS2, s, a, tiles_n, n_tiles);
   else if (a.wx_packed && rec) X6P_LAUNCH(EPI, GEN, false, 3, true);
   else if (a.wx_packed) X6P_LAUNCH(EPI, GEN, false, 3, false);
   else hipLaunchKernelGGL((gemm_x6_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
@@ -1099,10 +842,13 @@ static int set_attr_x6() {
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<EPI, GEN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS));
 #define X6P_ATTR(...) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<__VA_ARGS__>), \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS))
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS3))
   X6P_ATTR(EPI, GEN, false, 3, false);
   X6P_ATTR(EPI, GEN, false, 3, true);
-  X6P_ATTR(EPI, GEN, false, 2, true);
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p3_kernel<EPI, GEN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI, GEN, false, 2, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2));
   return 0;
 }
 template <int WM, int WN, int MI, int NI> struct Cfg {
@@ -1139,7 +885,8 @@ int init_gemm_attributes() {
   if (int e = set_attr<4, 1, 1, 1, EPI_LINEAR, true>()) return e;
   X6P_ATTR(EPI_LINEAR, false, true, 3, false);
   X6P_ATTR(EPI_LINEAR, false, true, 3, true);
-  X6P_ATTR(EPI_LINEAR, false, true, 2, true);
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2));
   if (int e = set_attr_x6<EPI_LINEAR, false>()) return e;
   if (int e = set_attr_x6<EPI_LINEAR, true>()) return e;
   if (int e = set_attr_x6<EPI_GEGLU_FWD, false>()) return e;

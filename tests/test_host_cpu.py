@@ -169,3 +169,38 @@ def test_compat_layer_against_reference_fixture(tmp_path):
     compat.load_checkpoint(dm2, str(tmp_path / "models"), "m1", use_ema=True)
     got = dm2.state_dict()
     assert all(torch.equal(got[k], full[k]) for k in full)
+
+
+def test_gemm_kernels_keep_their_occupancy():
+    """The GEMM kernels are tuned for a fixed number of resident blocks per CU (2, or 3 for the fp16x3 main variants);
+    one careless change pushes a variant past the register budget and silently halves its occupancy.  Read the
+    register counts back from the compiled code object."""
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "ramp_amd", "lib", "obj", "gemm.o")
+    if not (os.path.exists(obj) and all(os.path.exists(f"{llvm}/{t}") for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"))):
+        pytest.skip("no built object / no llvm tools")
+    d = tempfile.mkdtemp()
+    try:
+        subprocess.check_call([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, f"{d}/fat.bin"])
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               f"--input={d}/fat.bin", f"--output={d}/k.co", "--unbundle"])
+        notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", f"{d}/k.co"], text=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    names = re.findall(r"\.name:\s+(\S+)", notes)
+    vgprs = [int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", notes)]
+    assert len(names) == len(vgprs) and names
+    seen = {"x6p": 0, "x6p3": 0}
+    for n, v in zip(names, vgprs):
+        if "gemm_x6p3_kernel" in n:
+            assert v <= 168, (n, v); seen["x6p3"] += 1
+        elif "gemm_x6p_kernel" in n or "gemm_x6_kernel" in n:
+            assert v <= 256, (n, v); seen["x6p"] += 1
+        elif "gemm_kernelILi4ELi1ELi1ELi1" in n:
+            assert v <= 168, (n, v)                      # 128 x 32 tiles: three blocks per CU
+        elif "gemm_kernel" in n:
+            assert v <= 256, (n, v)
+    assert seen["x6p"] >= 8 and seen["x6p3"] >= 1
