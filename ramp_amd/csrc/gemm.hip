@@ -760,7 +760,9 @@ __device__ __forceinline__ u32x2 peel4(f32x4& v, bool subtract) {
 template <int EPI, bool GEN, bool AMUL = false, int NP = 3, bool REC = false>
 __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
+#define X6P_THREE 0
 #include "gemm_x6p_body.inc"
+#undef X6P_THREE
 }
 // ... or three (fp16x3: 168 VGPRs, 51 KB of LDS): a third resident block covers the epilogue-store stalls of the others;
 // the compiler spills registers around the epilogue (once per tile), none inside the slab loop.  Used where it
@@ -768,7 +770,9 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 template <int EPI, bool GEN, bool AMUL = false, int NP = 2, bool REC = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
+#define X6P_THREE 1
 #include "gemm_x6p_body.inc"
+#undef X6P_THREE
 }
 
 // fp32 [rows][K] -> fragment-packed planes [rows/32][K/16][NP][64 lanes][8] (NP = 3: bf16, NP = 2: fp16)
@@ -808,7 +812,8 @@ int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, float 
 
 constexpr size_t X6_LDS = std::max<size_t>(6 * (size_t)128 * XLD * 2, (size_t)128 * 132 * 4);
 constexpr size_t X6P_LDS3 = 2 * (9216 + 3 * (size_t)128 * XLD * 2);    // pipelined, 3 planes: 67584 B (2 blocks / CU)
-constexpr size_t X6P_LDS2 = 2 * (9728 + 2 * (size_t)128 * XLD * 2);    // pipelined, 2 planes: 52224 B (3 blocks / CU)
+constexpr size_t X6P_LDS2 = 2 * (9728 + 2 * (size_t)128 * XLD * 2);    // pipelined, 2 planes, 3 blocks / CU: 52224 B
+constexpr size_t X6P_LDS2R = 2 * (17408 + 2 * (size_t)128 * XLD * 2);  // pipelined, 2 planes, 2 blocks / CU (roomy): 67584 B
 static_assert(X6P_LDS3 <= X6_LDS, "bf16x6 pipelined layout");
 
 template <int EPI, bool GEN>
@@ -826,11 +831,11 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
   const bool rec = a.a_absmax_out != nullptr;
   if (a.wx_packed && a.Amul) {
     RAMP_REQUIRE(EPI == EPI_LINEAR && !GEN && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
-    if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true>), dim3(nb), dim3(256), X6P_LDS2, s, a, tiles_n, n_tiles);
+    if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true>), dim3(nb), dim3(256), X6P_LDS2R, s, a, tiles_n, n_tiles);
     else if (rec) X6P_LAUNCH(EPI_LINEAR, false, true, 3, true);
     else X6P_LAUNCH(EPI_LINEAR, false, true, 3, false);
   } else if (three) hipLaunchKernelGGL((gemm_x6p3_kernel<EPI, GEN>), dim3(nb), dim3(256), X6P_LDS2, s, a, tiles_n, n_tiles);
-  else if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN, false, 2, true>), dim3(nb), dim3(256), X6P_LDS2, s, a, tiles_n, n_tiles);
+  else if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI, GEN, false, 2, true>), dim3(nb), dim3(256), X6P_LDS2R, s, a, tiles_n, n_tiles);
   else if (a.wx_packed && rec) X6P_LAUNCH(EPI, GEN, false, 3, true);
   else if (a.wx_packed) X6P_LAUNCH(EPI, GEN, false, 3, false);
   else hipLaunchKernelGGL((gemm_x6_kernel<EPI, GEN>), dim3(nb), dim3(256), X6_LDS, s, a, tiles_n, n_tiles);
@@ -848,7 +853,7 @@ static int set_attr_x6() {
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p3_kernel<EPI, GEN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2));
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI, GEN, false, 2, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2R));
   return 0;
 }
 template <int WM, int WN, int MI, int NI> struct Cfg {
@@ -886,7 +891,7 @@ int init_gemm_attributes() {
   X6P_ATTR(EPI_LINEAR, false, true, 3, false);
   X6P_ATTR(EPI_LINEAR, false, true, 3, true);
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2R));
   if (int e = set_attr_x6<EPI_LINEAR, false>()) return e;
   if (int e = set_attr_x6<EPI_LINEAR, true>()) return e;
   if (int e = set_attr_x6<EPI_GEGLU_FWD, false>()) return e;
