@@ -193,6 +193,9 @@ int ramp_debug_read(ramp_ctx* ctx, const char* kind, const char* module, float* 
  * scaled by the previous evaluation's maximum, left the fp16 range (the results of that call must be discarded and the
  * job re-run with gemm_mode bf16x6); always 0 in the other modes. */
 int ramp_range_status(ramp_ctx* ctx, int32_t* flag, void* stream);
+/* fp16x3 mode: bf16x6_only != 0 makes the following ramp_sample calls run every evaluation with the bf16x6 kernels
+ * (what the Python wrapper does to repeat a job whose range flag was raised); 0 restores fp16x3. */
+int ramp_set_fallback(ramp_ctx* ctx, int32_t bf16x6_only);
 /* per-launch HIP-event timing (eager, non-graph calls only).  Categories: 0 = MFMA GEMM (linears + k5/k1
  * convs), 1 = attention, 2 = GroupNorm/LayerNorm/GEGLU rows, 3 = stride-2 / first / last convs, 4 = sampler
  * (CFG, DDPM/DDIM update, APF).  ramp_profile_read sums elapsed ms, algorithmic FLOPs and launch counts

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "ramp_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64, c_i64p, C.c_void_p]),
     "ramp_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "ramp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64p]),
+    "ramp_set_fallback": (C.c_int, [C.c_void_p, C.c_int32]),
     "ramp_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "ramp_workspace_bytes": (C.c_int, [C.c_void_p, c_i64p]),
     "ramp_launch_count": (C.c_int, [C.c_void_p, c_i64p]),

@@ -167,6 +167,7 @@ struct ramp_ctx {
   // previous evaluation's maxima, recording its own.  obs[2][MAX_SITES] floats, ping-pong by evaluation.
   static constexpr int MAX_SITES = 1024;
   int phase = 0, site = 0;
+  int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   float* obs = nullptr; float *obs_in = nullptr, *obs_out = nullptr;
   int* range_flag = nullptr;
   // debug
@@ -1122,7 +1123,7 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
     RAMP_HIP_CHECK(hipGetLastError());
   }
   for (int j = 0; j < p->n_steps; ++j) {
-    if (c->gemm_mode == 2) {
+    if (c->gemm_mode == 2 && !c->force_x6) {
       // evaluation 0 calibrates (bf16x6 + recorded operand maxima); evaluation j >= 1 runs fp16x3 scaled from j - 1
       c->phase = j == 0 ? 1 : 2;
       c->obs_out = c->obs + (j & 1) * ramp_ctx::MAX_SITES;
@@ -1215,7 +1216,7 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
     put(&p->clip_denoised, 4); put(&p->n_hard, 4);
     const int has_apf = p->apf.cloud != nullptr; put(&has_apf, 4);
     put(&p->apf.n_points, 4); put(&p->apf.window, 4); put(&p->apf.threshold, 8); put(&p->apf.strength, 8); put(&p->apf.passes, 4);
-    const int ch = chain; put(&ch, 4);
+    const int ch = chain; put(&ch, 4); put(&c->force_x6, 4);
     if (key != c->graph_key || !c->graph_exec) {
       if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       hipStream_t cs;
@@ -1450,12 +1451,18 @@ int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
   return 0;
 }
 
+int ramp_set_fallback(ramp_ctx* c, int32_t bf16x6_only) {
+  RAMP_REQUIRE(c, "null argument");
+  c->force_x6 = bf16x6_only ? 1 : 0;
+  return 0;
+}
 int ramp_range_status(ramp_ctx* c, int32_t* flag, void* stream) {
   RAMP_REQUIRE(c && flag, "null argument");
   *flag = 0;
   if (c->range_flag) {
     RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
     RAMP_HIP_CHECK(hipMemcpy(flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (!c->force_x6 && getenv("RAMP_TEST_RANGE_FLAG")) *flag = 7;       // test hook: exercise the caller's fallback path
     if (*flag && getenv("RAMP_X6_WARN")) {
       std::vector<float> o(2 * ramp_ctx::MAX_SITES);
       RAMP_HIP_CHECK(hipMemcpy(o.data(), c->obs, o.size() * sizeof(float), hipMemcpyDeviceToHost));

@@ -17,6 +17,8 @@ reference indexes rows 0/1 of the output and is only valid for n_samples == 1, Q
 """
 from __future__ import annotations
 
+import warnings
+
 import ctypes as C
 from copy import copy
 from typing import Dict, Optional
@@ -67,9 +69,10 @@ class _GaussianDiffusionBase(nn.Module):
     def __init__(self, model=None, variance_schedule='exponential', n_diffusion_steps=100, clip_denoised=True,
                  predict_epsilon=False, loss_type='l2', context_model=None, compose=False, use_apf=False,
                  training=False, sampler: Optional[str] = None, cfg_weight: Optional[float] = None,
-                 compose_weights=None, use_graph: bool = True, **kwargs):
+                 compose_weights=None, use_graph: bool = True, fp16_fallback: bool = True, **kwargs):
         super().__init__()
         self.model = model
+        self.fp16_fallback = fp16_fallback      # fp16x3 range guard tripped -> repeat the job in bf16x6 (else raise)
         self.context_model = context_model
         self.n_diffusion_steps = n_diffusion_steps
         self.ddim_num_inference_steps = 8 if (compose and use_apf) else 5      # diffusion_model_static.py:40
@@ -245,13 +248,24 @@ class _GaussianDiffusionBase(nn.Module):
         x_out = torch.empty((B, H, S), device=dev, dtype=torch.float32)
         noise = noise.contiguous()
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().ramp_sample(m.ctx(), C.byref(p), _lib.ptr(noise), _lib.ptr(chain), _lib.ptr(x_out),
-                                               _lib.current_stream()), "ramp_sample")
+            lib = _lib.load()
+            _lib.check(lib.ramp_sample(m.ctx(), C.byref(p), _lib.ptr(noise), _lib.ptr(chain), _lib.ptr(x_out),
+                                       _lib.current_stream()), "ramp_sample")
             flag = C.c_int32(0)
-            _lib.check(_lib.load().ramp_range_status(m.ctx(), C.byref(flag), _lib.current_stream()), "ramp_range_status")
+            _lib.check(lib.ramp_range_status(m.ctx(), C.byref(flag), _lib.current_stream()), "ramp_range_status")
             if flag.value:
-                raise _lib.RampHipError("fp16x3 GEMM: an operand left the fp16 range between two score evaluations; "
-                                        "rebuild the model with gemm_mode='bf16x6'")
+                # an operand left the range the delayed fp16 scaling assumed: the result is discarded and the same job
+                # (same noise) is repeated with the range-free bf16x6 kernels -- never a silently degraded answer
+                if not self.fp16_fallback:
+                    raise _lib.RampHipError("fp16x3 GEMM: an operand left the fp16 range between two score evaluations "
+                                            f"(call site {flag.value - 1}); use gemm_mode='bf16x6'")
+                warnings.warn(f"fp16x3 range guard tripped at GEMM call site {flag.value - 1}: repeating the job in bf16x6")
+                _lib.check(lib.ramp_set_fallback(m.ctx(), 1), "ramp_set_fallback")
+                try:
+                    _lib.check(lib.ramp_sample(m.ctx(), C.byref(p), _lib.ptr(noise), _lib.ptr(chain), _lib.ptr(x_out),
+                                               _lib.current_stream()), "ramp_sample")
+                finally:
+                    _lib.check(lib.ramp_set_fallback(m.ctx(), 0), "ramp_set_fallback")
         return x_out, chain
 
     # ------------------------------------------------------------------ loops (reference signatures)

@@ -344,3 +344,24 @@ def test_fp16x3_chunking_and_repeat_are_bitwise():
     assert np.array_equal(a, b)
     assert np.array_equal(a, whole)
     assert np.abs(a[:, :4] - g["chain"]).max() < 1e-4
+
+
+def test_fp16x3_range_guard_falls_back_to_bf16x6(monkeypatch):
+    """When the fp16 range guard trips, the wrapper discards the result and repeats the SAME job with the bf16x6 kernels
+    (or raises if told not to fall back): the answer is bitwise the bf16x6-mode answer."""
+    from ramp_amd import _lib as L
+    g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
+    ref, _ = run(make_static(25, gemm_mode="bf16x6"), g, 4)
+    dm = make_static(25, gemm_mode="fp16x3")
+    plain, _ = run(dm, g, 4)
+    assert not np.array_equal(plain, ref)                      # the two modes round differently ...
+    monkeypatch.setenv("RAMP_TEST_RANGE_FLAG", "1")
+    with pytest.warns(UserWarning, match="range guard"):
+        fb, _ = run(dm, g, 4)
+    assert np.array_equal(fb, ref)                             # ... and the fallback IS the bf16x6 job
+    dm.fp16_fallback = False
+    with pytest.raises(L.RampHipError, match="fp16 range"):
+        run(dm, g, 4)
+    monkeypatch.delenv("RAMP_TEST_RANGE_FLAG")
+    again, _ = run(dm, g, 4)
+    assert np.array_equal(again, plain)                        # and the context is back in fp16x3 afterwards
