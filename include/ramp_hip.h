@@ -29,14 +29,15 @@ typedef struct ramp_ctx ramp_ctx;
 /* Architecture of TemporalUnetInference.__init__ (UnetInference.py:42-56, 93-145). */
 typedef struct ramp_config {
   int32_t state_dim;       /* S: 4 (Maze2D) or 6 (Maze3D)                              */
-  int32_t horizon;         /* H = n_support_points, multiple of 8, <= 128              */
+  int32_t horizon;         /* H = n_support_points: 48 or 64 (attention kernels)       */
   int32_t unet_input_dim;  /* 32                                                       */
   int32_t n_levels;        /* len(dim_mults) = 4 for UNET_DIM_MULTS[1] = (1,2,4,8)      */
   int32_t context_dim;     /* 320 (2-D scene encoder) or 256 (3-D)                     */
   int32_t max_rows;        /* capacity in network rows per chunk (rows = B * n_rp)     */
   int32_t debug_taps;      /* 1: keep per-module outputs / output-grads for ramp_debug_read */
   int32_t gemm_mode;       /* 0 = library default (env RAMP_GEMM_MODE=fp32|bf16x6|fp16x3), 1 = exact fp32 MFMA, 2 = bf16x6 split,
-                            * 3 = fp16x3 split with delayed operand scaling inside ramp_sample (ramp_score stays bf16x6) */
+                            * 3 = fp16x3 split with delayed operand scaling (ramp_sample calibrates on its first evaluation,
+                            *     ramp_score keeps its calibration from call to call; see ramp_score) */
 } ramp_config;
 
 const char* ramp_last_error(void);
@@ -75,9 +76,15 @@ int ramp_encode_scene(ramp_ctx* ctx, const float* cloud, int32_t n_obstacles, in
 /* TemporalUnetInference.forward / forward_no_energy (UnetInference.py:157-224).
  * x (B,H,S); each trajectory is evaluated n_rp times (rows b*n_rp + v).  f_out (B*n_rp,H,S)
  * receives forward_no_energy's output, eps_out (B*n_rp,H,S) the energy gradient; either may be
- * NULL.  t is the (batch-uniform) diffusion timestep, 0 <= t < T of the prepared table. */
+ * NULL.  t is the (batch-uniform) diffusion timestep, 0 <= t < T of the prepared table.
+ * fp16x3 mode: the first call after ramp_create / ramp_set_scene / ramp_sample / ramp_set_fallback runs the bf16x6
+ * kernels and records every GEMM call site's operand maximum; later calls run the fp16x3 kernels scaled from their
+ * predecessor's maxima.  If the range guard fires the evaluation is repeated at once with the bf16x6 kernels (one
+ * 4-byte read-back per call decides), so a flagged result is never returned. */
 int ramp_score(ramp_ctx* ctx, const float* x, int32_t B, int32_t n_rp, int32_t t,
                float* f_out, float* eps_out, void* stream);
+/* arithmetic the last ramp_score call's result was computed in: 0 exact fp32, 1 bf16x6, 2 fp16x3 */
+int ramp_score_mode(ramp_ctx* ctx, int32_t* mode);
 
 /* ---- sampler loops: run_inference -> conditional_sample -> p_sample_loop / ddim_p_sample_loop
  *      (diffusion_model_static.py:232-256, 347-384, 438-463; diffusion_model_3d.py:185-218) ---- */
@@ -164,10 +171,25 @@ int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32
  * x_out = sqrt_a_prev * x0 + dir_coef * (x - sqrt_a_t * x0) / sqrt_1m_a_t */
 int ramp_ddim_finish(const float* x, const float* x0, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
                      float dir_coef, float* x_out, int32_t B, int32_t H, int32_t S, void* stream);
-/* generic fp32 MFMA GEMM with taps: C[M,N] = sum_tap shift(A)[M,K] W[tap][N][K]^T + bias + resid */
+/* generic exact-fp32 MFMA GEMM with taps: C[M,N] = sum_tap shift(A)[M,K] W[tap][N][K]^T + bias + resid */
 int ramp_op_gemm(const float* A, const float* W, const float* bias, const float* resid, float* C,
                  int32_t M, int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step,
                  int32_t L, void* stream);
+/* the same product on a named GEMM kernel (parity tests, micro-benchmarks): mode 0 exact fp32, 1 bf16x6 with
+ * fragment-packed weights, 2 bf16x6 with LDS-staged weights, 3 fp16x3 (shapes a split kernel does not cover run fp32).
+ * fp16x3 only: a_absmax_prev > 0 is the operand maximum the delayed scaling assumes (0 = unscaled operand);
+ * *a_absmax_out_host receives the maximum |A| the launch recorded and *range_flag_out_host != 0 reports that the scaled
+ * operand left the fp16 range (either may be NULL).  Synchronises `stream`; packs W on every call. */
+int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const float* resid, float* C,
+                      int32_t M, int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step,
+                      int32_t L, int32_t mode, float a_absmax_prev, float* a_absmax_out_host,
+                      int32_t* range_flag_out_host, void* stream);
+/* micro-benchmark (profiling tools only): one GEMM shape on the kernel `mode` names (as ramp_op_gemm_mode), operands
+ * allocated and filled inside, weights packed once, `warmup` untimed then `iters` timed back-to-back launches on `stream`
+ * between two HIP events; *avg_us = microseconds per launch.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue
+ * (N = 2F), 8 A-multiplier operand (the FF1-dX loader; K = 2 x the operand width). */
+int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
+                    int32_t warmup, int32_t iters, float* avg_us, void* stream);
 int ramp_op_groupnorm(const float* x, const float* gamma, const float* beta, const float* tbias,
                       const float* resid, float* y, float* stats, int32_t R, int32_t L, int32_t C,
                       float eps, int32_t mish, void* stream);

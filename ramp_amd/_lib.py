@@ -52,6 +52,7 @@ PROTOTYPES = {
     "ramp_encode_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ramp_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
+    "ramp_score_mode": (C.c_int, [C.c_void_p, c_i32p]),
     "ramp_sample": (C.c_int, [C.c_void_p, C.POINTER(RampSampleParams), C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p]),
     "ramp_apf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RampApfParams), C.c_void_p]),
@@ -70,6 +71,8 @@ PROTOTYPES = {
     "ramp_ddim_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ramp_op_gemm": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]),
+    "ramp_op_gemm_mode": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 8 + [C.c_float, c_f32p, c_i32p, C.c_void_p]),
+    "ramp_bench_gemm": (C.c_int, [C.c_int32] * 9 + [c_f32p, C.c_void_p]),
     "ramp_op_groupnorm": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p]),
     "ramp_op_groupnorm_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p]),
     "ramp_op_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]),
@@ -120,6 +123,18 @@ def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().ramp_last_error()
         raise RampHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+GEMM_MODES = {"fp32": 0, "bf16x6": 1, "bf16x6-lds": 2, "fp16x3": 3}       # ramp_op_gemm_mode
+
+
+def op_gemm(A, W, bias, resid, out, M, N, K, taps, shift0, step, L, mode="fp32", a_absmax_prev=0.0):
+    """ramp_op_gemm_mode on torch tensors; returns (recorded max|A|, range flag) (zeros outside fp16x3)."""
+    amax, flag = C.c_float(0.0), C.c_int32(0)
+    check(load().ramp_op_gemm_mode(ptr(A), ptr(W), ptr(bias), ptr(resid), ptr(out), M, N, K, taps, shift0, step, L,
+                                   GEMM_MODES[mode], float(a_absmax_prev), C.byref(amax), C.byref(flag),
+                                   current_stream()), "ramp_op_gemm_mode")
+    return amax.value, flag.value
 
 
 def ptr(t) -> Optional[int]:

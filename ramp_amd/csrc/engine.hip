@@ -168,6 +168,8 @@ struct ramp_ctx {
   static constexpr int MAX_SITES = 1024;
   int phase = 0, site = 0;
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
+  // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
+  bool score_calibrated = false; int score_parity = 0; int score_last_mode = 0;
   float* obs = nullptr; float *obs_in = nullptr, *obs_out = nullptr;
   int* range_flag = nullptr;
   // debug
@@ -356,8 +358,6 @@ struct Run {
             }
             c->site++;
           } else {
-            if (c->x6_pipe && getenv("RAMP_X6_WARN"))
-              fprintf(stderr, "[ramp] x6 weight not fragment-packed: M %d N %d K %d taps %d (blob K %d, off %zu)\n", b.M, b.N, b.K, b.taps, e.K, off);
             b.Wx = e.planes + off; b.wx_plane = (long)e.n;
           }
         }
@@ -815,8 +815,7 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
   RAMP_REQUIRE(cfg->state_dim >= 2 && cfg->state_dim <= 16, "state_dim out of range");
   RAMP_REQUIRE(cfg->n_levels == 4, "only UNET_DIM_MULTS[1] = (1,2,4,8) is built");
   RAMP_REQUIRE(cfg->unet_input_dim == 32, "unet_input_dim must be 32");
-  RAMP_REQUIRE(cfg->horizon % 8 == 0 && cfg->horizon >= 48 && cfg->horizon <= 64,
-               "horizon must be 48 or 64 (attention kernel instantiations)");
+  RAMP_REQUIRE(cfg->horizon == 48 || cfg->horizon == 64, "horizon must be 48 or 64 (attention kernel instantiations)");
   RAMP_REQUIRE(cfg->context_dim > 0 && cfg->context_dim <= 512, "context_dim out of range");
   RAMP_REQUIRE(cfg->max_rows >= 1, "max_rows must be positive");
   int ndev = 0;
@@ -1005,10 +1004,6 @@ int ramp_finalize_weights(ramp_ctx* c) {
     for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C, u.C)); CK(reg(u.w_b, 4ul * u.C * u.C, u.C)); }
   }
   RAMP_HIP_CHECK(hipDeviceSynchronize());
-  if (getenv("RAMP_X6_WARN")) {
-    int n3 = 0; for (auto& kv : c->x6) n3 += kv.second.packed3 != nullptr;
-    fprintf(stderr, "[ramp] gemm_mode %d, x6_pipe %d, %zu weight blobs, %d with fp16 planes\n", c->gemm_mode, c->x6_pipe, c->x6.size(), n3);
-  }
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
   CK(init_attention_attributes());
   c->finalized = true;
@@ -1086,6 +1081,7 @@ int ramp_set_scene(ramp_ctx* c, const float* latents, int32_t n_variants, const 
   RAMP_HIP_CHECK(hipStreamSynchronize(s));
   RAMP_HIP_CHECK(hipFree(d));
   c->graph_key.clear();     // scene changed: cross_bias pointer may have moved
+  c->score_calibrated = false;
   return rc;
 }
 
@@ -1105,7 +1101,40 @@ int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, 
                void* stream) {
   RAMP_REQUIRE(c && x, "null argument");
   c->launches = 0;
-  return score_all(c, x, B, n_rp, t, f_out, eps_out, as_stream(stream));
+  hipStream_t s = as_stream(stream);
+  if (c->gemm_mode != 2 || c->force_x6) { c->score_last_mode = c->gemm_mode == 2 ? 1 : c->gemm_mode; return score_all(c, x, B, n_rp, t, f_out, eps_out, s); }
+  // fp16x3: the same delayed scaling as inside ramp_sample, with the calibration kept across calls.  The first
+  // evaluation after context creation / a scene change / a ramp_sample runs the bf16x6 kernels and records every call
+  // site's operand maximum; every later one runs fp16x3 scaled from its predecessor's maxima, and is repeated at once
+  // with the bf16x6 kernels (recording again) if the range guard fired -- the caller never sees a flagged result.
+  auto tables = [&](int parity) {
+    c->obs_out = c->obs + parity * ramp_ctx::MAX_SITES;
+    c->obs_in = c->obs + (parity ^ 1) * ramp_ctx::MAX_SITES;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(ramp_ctx::MAX_SITES / 256), dim3(256), 0, s,
+                       reinterpret_cast<unsigned*>(c->obs_out), ramp_ctx::MAX_SITES);
+  };
+  int rc = 0;
+  if (c->score_calibrated) {
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<unsigned*>(c->range_flag), 1);
+    tables(c->score_parity);
+    RAMP_HIP_CHECK(hipGetLastError());
+    c->phase = 2;
+    rc = score_all(c, x, B, n_rp, t, f_out, eps_out, s);
+    c->phase = 0;
+    CK(rc);
+    int flag = 0;
+    RAMP_HIP_CHECK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    RAMP_HIP_CHECK(hipStreamSynchronize(s));
+    if (!flag) { c->score_parity ^= 1; c->score_last_mode = 2; return 0; }
+  }
+  tables(c->score_parity);
+  RAMP_HIP_CHECK(hipGetLastError());
+  c->phase = 1;
+  rc = score_all(c, x, B, n_rp, t, f_out, eps_out, s);
+  c->phase = 0;
+  CK(rc);
+  c->score_calibrated = true; c->score_parity ^= 1; c->score_last_mode = 1;
+  return 0;
 }
 
 static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, bool chain) {
@@ -1133,13 +1162,6 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
       RAMP_HIP_CHECK(hipGetLastError());
     }
     const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s);
-    if (getenv("RAMP_X6_WARN") && j < 2) fprintf(stderr, "[ramp] step %d phase %d sites %d\n", j, c->phase, c->site);
-    if (getenv("RAMP_X6_WARN") && c->range_flag && !p->use_graph) {      // eager debugging: which evaluation trips the guard
-      int f = 0;
-      (void)hipStreamSynchronize(s);
-      (void)hipMemcpy(&f, c->range_flag, sizeof(int), hipMemcpyDeviceToHost);
-      if (f) { fprintf(stderr, "[ramp] range flag %d after evaluation %d\n", f, j); }
-    }
     c->phase = 0;
     CK(rc_score);
     CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = p->n_rp;
@@ -1201,6 +1223,7 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
   }
   RAMP_HIP_CHECK(hipMemcpyAsync(c->s_noise, noise, n_noise * 4, hipMemcpyDeviceToDevice, s));
   c->launches = 0;
+  c->score_calibrated = false;      // the loop below overwrites the delayed-scaling tables
   if (!p->use_graph) {
     CK(sample_body(c, p, s, chain));
   } else {
@@ -1241,20 +1264,36 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
 }
 
 // ---- kernel-level entry points ---------------------------------------------------------------------
+// The context-free entry points take small HOST arrays (window weights, waypoint indices).  They are staged through a
+// per-thread ring of device slots allocated once, so a call neither allocates nor synchronises; a slot is reused after
+// RING calls, by which time the stream-ordered kernel that read it has long been submitted behind 63 others.
+namespace {
+struct HostArgRing {
+  static constexpr int RING = 64, SLOT = 1024;       // bytes per slot: 129 window weights or 256 indices
+  char* base = nullptr; int next = 0; int device = -1;
+  int stage(const void* host, size_t bytes, hipStream_t s, void** out) {
+    RAMP_REQUIRE(bytes <= (size_t)SLOT, "host argument array too long");
+    int dev = 0; RAMP_HIP_CHECK(hipGetDevice(&dev));
+    if (!base || dev != device) { RAMP_HIP_CHECK(hipMalloc(&base, (size_t)RING * SLOT)); device = dev; next = 0; }
+    char* p = base + (size_t)(next++ % RING) * SLOT;
+    RAMP_HIP_CHECK(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, s));
+    *out = p;
+    return 0;
+  }
+};
+thread_local HostArgRing g_ring;
+}  // namespace
+
 int ramp_apf(float* traj, int32_t B, int32_t H, int32_t S, const ramp_apf_params* p, void* stream) {
   RAMP_REQUIRE(traj && p && p->cloud && p->window_weights_host, "null argument");
   RAMP_REQUIRE(p->window >= 0 && p->window <= 64, "bad window");
   hipStream_t s = as_stream(stream);
-  float* w = nullptr;
-  RAMP_HIP_CHECK(hipMalloc(&w, (2 * p->window + 1) * 4));
-  RAMP_HIP_CHECK(hipMemcpyAsync(w, p->window_weights_host, (2 * p->window + 1) * 4, hipMemcpyHostToDevice, s));
-  ApfArgs a; a.traj = traj; a.cloud = p->cloud; a.window = w; a.B = B; a.H = H; a.S = S; a.P = p->n_points; a.win = p->window;
-  a.thr = p->threshold; a.strength = p->strength;
-  int rc = 0;
-  for (int q = 0; q < std::max(1, p->passes) && rc == 0; ++q) rc = launch_apf(a, s);
-  RAMP_HIP_CHECK(hipStreamSynchronize(s));
-  RAMP_HIP_CHECK(hipFree(w));
-  return rc;
+  void* w = nullptr;
+  CK(g_ring.stage(p->window_weights_host, (2 * p->window + 1) * 4, s, &w));
+  ApfArgs a; a.traj = traj; a.cloud = p->cloud; a.window = static_cast<const float*>(w); a.B = B; a.H = H; a.S = S;
+  a.P = p->n_points; a.win = p->window; a.thr = p->threshold; a.strength = p->strength;
+  for (int q = 0; q < std::max(1, p->passes); ++q) CK(launch_apf(a, s));
+  return 0;
 }
 
 int ramp_apf_dynamic(float* traj, int32_t B, int32_t H, int32_t S, const double* points, int32_t n_points,
@@ -1271,16 +1310,13 @@ int ramp_hard_cond(float* x, int32_t B, int32_t H, int32_t S, int32_t n, const i
                    void* stream) {
   RAMP_REQUIRE(x && (n == 0 || (idx_host && val)), "null argument");
   if (n == 0) return 0;
+  RAMP_REQUIRE(n <= 256, "too many hard conditions");
   for (int j = 0; j < n; ++j) RAMP_REQUIRE(idx_host[j] >= 0 && idx_host[j] < H, "hard index out of range");
   hipStream_t s = as_stream(stream);
-  int* d = nullptr;
-  RAMP_HIP_CHECK(hipMalloc(&d, n * 4));
-  RAMP_HIP_CHECK(hipMemcpyAsync(d, idx_host, n * 4, hipMemcpyHostToDevice, s));
-  HardConds hc; hc.idx = d; hc.val = val; hc.n = n;
-  int rc = launch_hard_cond(x, hc, B, H, S, s);
-  RAMP_HIP_CHECK(hipStreamSynchronize(s));
-  RAMP_HIP_CHECK(hipFree(d));
-  return rc;
+  void* d = nullptr;
+  CK(g_ring.stage(idx_host, (size_t)n * 4, s, &d));
+  HardConds hc; hc.idx = static_cast<const int*>(d); hc.val = val; hc.n = n;
+  return launch_hard_cond(x, hc, B, H, S, s);
 }
 
 int ramp_traj_costs(const float* traj, int32_t B, int32_t H, int32_t S, const float* cloud, int32_t n_points,
@@ -1318,56 +1354,134 @@ int ramp_ddim_finish(const float* x, const float* x0, float sqrt_a_t, float sqrt
 
 int ramp_op_gemm(const float* A, const float* W, const float* bias, const float* resid, float* C, int32_t M, int32_t N,
                  int32_t K, int32_t taps, int32_t shift0, int32_t shift_step, int32_t L, void* stream) {
+  return ramp_op_gemm_mode(A, W, bias, resid, C, M, N, K, taps, shift0, shift_step, L, 0, 0.f, nullptr, nullptr, stream);
+}
+
+int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const float* resid, float* C, int32_t M,
+                      int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step, int32_t L, int32_t mode,
+                      float a_absmax_prev, float* a_absmax_out_host, int32_t* range_flag_out_host, void* stream) {
   RAMP_REQUIRE(A && W && C, "null argument");
+  RAMP_REQUIRE(mode >= 0 && mode <= 3, "mode: 0 fp32, 1 bf16x6, 2 bf16x6 (LDS-staged weights), 3 fp16x3");
+  hipStream_t s = as_stream(stream);
   GemmArgs a; a.A = A; a.lda = K; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.C = C; a.ldc = N;
   a.M = M; a.N = N; a.K = K; a.taps = taps; a.shift0 = shift0; a.shift_step = shift_step; a.L = L;
-  const char* env = getenv("RAMP_GEMM_MODE");
-  if (env && std::string(env) == "fp16x3" && N >= 64 && N % 32 == 0 && K % 16 == 0) {
-    static std::map<const float*, unsigned short*> cache3;
-    const long n = (long)taps * N * K;
-    auto it = cache3.find(W);
-    if (it == cache3.end()) {
-      unsigned short* p = nullptr;
-      RAMP_HIP_CHECK(hipMalloc(&p, 2 * n * sizeof(unsigned short)));
-      it = cache3.emplace(W, p).first;
-    }
-    if (int rc = launch_pack_h3(W, it->second, (long)taps * N, K, 1.f, as_stream(stream))) return rc;
-    a.Wx = it->second; a.wx_packed = 2;
-    if (const char* sc = getenv("RAMP_H3_TEST_SCALE")) {          // micro-benchmark: exercise the scaling / recording path
-      static float* slots = nullptr;
-      if (!slots) { RAMP_HIP_CHECK(hipMalloc(&slots, 16)); }
-      const float v[4] = {(float)atof(sc), 0.f, 0.f, 0.f};
-      RAMP_HIP_CHECK(hipMemcpyAsync(slots, v, 16, hipMemcpyHostToDevice, as_stream(stream)));
-      a.a_absmax_in = slots; a.a_absmax_out = slots + 1; a.range_flag = reinterpret_cast<int*>(slots + 2);
-      if (int rc = launch_gemm(a, as_stream(stream))) return rc;
-      int flag = 0;
-      RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-      RAMP_HIP_CHECK(hipMemcpy(&flag, slots + 2, sizeof(int), hipMemcpyDeviceToHost));
-      RAMP_REQUIRE(flag == 0, "fp16x3 GEMM: the scaled operand left the fp16 range");
-      return 0;
-    }
-  } else
-  if (env && std::string(env) == "bf16x6" && (N >= 128 || (N >= 64 && N % 32 == 0 && K % 16 == 0 && !(getenv("RAMP_X6_PIPE") && getenv("RAMP_X6_PIPE")[0] == '0')))) {
-    // test / micro-benchmark path: split W on the fly
-    static std::map<const float*, unsigned short*> cache;
-    const long n = (long)taps * N * K;
-    auto it = cache.find(W);
-    if (it == cache.end()) {
-      unsigned short* p = nullptr;
-      RAMP_HIP_CHECK(hipMalloc(&p, 3 * n * sizeof(unsigned short)));
-      it = cache.emplace(W, p).first;
-    }
-    const char* pe = getenv("RAMP_X6_PIPE");
-    if (!(pe && pe[0] == '0') && N % 32 == 0 && K % 16 == 0) {
-      if (int rc = launch_pack_x6(W, it->second, (long)taps * N, K, as_stream(stream))) return rc;
-      a.Wx = it->second; a.wx_packed = 1;
-    } else {
-      if (int rc = launch_split3(W, it->second, n, as_stream(stream))) return rc;
-      a.Wx = it->second; a.wx_plane = n;
-    }
+  const long n = (long)taps * N * K;
+  const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
+  unsigned short* planes = nullptr; float* slots = nullptr;
+  int rc = 0;
+  if (mode == 3 && frag_ok) {
+    // the product's static weight scale: max |w| -> [2^10, 2^11)  (ramp_finalize_weights)
+    std::vector<float> hw(n);
+    RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, n * sizeof(float), hipMemcpyDeviceToHost));
+    float mx = 0.f; for (float v : hw) mx = std::max(mx, std::fabs(v));
+    float sc = 1.f;
+    if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
+    RAMP_HIP_CHECK(hipMalloc(&planes, 2 * n * sizeof(unsigned short)));
+    RAMP_HIP_CHECK(hipMalloc(&slots, 16));
+    const float v[4] = {a_absmax_prev, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(slots, v, 16, hipMemcpyHostToDevice, s));
+    rc = launch_pack_h3(W, planes, (long)taps * N, K, sc, s);
+    a.Wx = planes; a.wx_packed = 2; a.w_scale_inv = 1.f / sc;
+    a.a_absmax_in = a_absmax_prev > 0.f ? slots : nullptr; a.a_absmax_out = slots + 1;
+    a.range_flag = reinterpret_cast<int*>(slots + 2);
+  } else if (mode == 1 && frag_ok) {
+    RAMP_HIP_CHECK(hipMalloc(&planes, 3 * n * sizeof(unsigned short)));
+    rc = launch_pack_x6(W, planes, (long)taps * N, K, s);
+    a.Wx = planes; a.wx_packed = 1;
+  } else if ((mode == 1 || mode == 2) && N >= 128) {
+    RAMP_HIP_CHECK(hipMalloc(&planes, 3 * n * sizeof(unsigned short)));
+    rc = launch_split3(W, planes, n, s);
+    a.Wx = planes; a.wx_plane = n;
   }
-  return launch_gemm(a, as_stream(stream));
+  if (rc == 0) rc = launch_gemm(a, s);
+  hipError_t e = hipStreamSynchronize(s);
+  if (rc == 0 && e == hipSuccess && slots) {
+    float back[4] = {0, 0, 0, 0};
+    e = hipMemcpy(back, slots, 16, hipMemcpyDeviceToHost);
+    if (a_absmax_out_host) *a_absmax_out_host = back[1];
+    int fl; std::memcpy(&fl, &back[2], 4);
+    if (range_flag_out_host) *range_flag_out_host = fl;
+  } else {
+    if (a_absmax_out_host) *a_absmax_out_host = 0.f;
+    if (range_flag_out_host) *range_flag_out_host = 0;
+  }
+  if (planes) (void)hipFree(planes);
+  if (slots) (void)hipFree(slots);
+  RAMP_HIP_CHECK(e);
+  return rc;
 }
+// micro-benchmark of one GEMM shape on a named kernel: packs once, `warmup` + `iters` back-to-back launches on `stream`,
+// HIP events around the timed ones.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue (N = 2F, writes the F-wide
+// product too), 8 A-multiplier operand (K = 2 * period).  Operands are allocated and filled here (uniform [-1, 1)).
+__global__ void fill_uniform_kernel(float* p, long n, unsigned seed, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = ((float)(h >> 8) * (1.f / 8388608.f) - 1.f) * scale;
+  }
+}
+int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
+                    int32_t warmup, int32_t iters, float* avg_us, void* stream) {
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 3, "bad arguments");
+  hipStream_t s = as_stream(stream);
+  DevArena ar;
+  auto fill = [&](float* p, size_t n, unsigned seed, float sc) {
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s, p, (long)n, seed, sc);
+  };
+  const bool geglu = flags & 4, amul = flags & 8;
+  const int Ka = amul ? K / 2 : K;
+  float* A = ar.alloc((size_t)M * Ka); float* W = ar.alloc((size_t)taps * N * K); float* C = ar.alloc((size_t)M * N);
+  float* bias = ar.alloc(N); float* R = (flags & 2) ? ar.alloc((size_t)M * N) : nullptr;
+  float* aux = geglu ? ar.alloc((size_t)M * N / 2) : nullptr; float* mul = amul ? ar.alloc((size_t)M * K) : nullptr;
+  float* slots = ar.alloc(4);
+  RAMP_REQUIRE(A && W && C && bias && slots && (!(flags & 2) || R) && (!geglu || aux) && (!amul || mul), "hipMalloc failed");
+  fill(A, (size_t)M * Ka, 1u, 1.f); fill(W, (size_t)taps * N * K, 2u, 1.f / std::sqrt((float)K * taps)); fill(bias, N, 3u, 1.f);
+  if (R) fill(R, (size_t)M * N, 4u, 1.f);
+  if (mul) fill(mul, (size_t)M * K, 5u, 1.f);
+  RAMP_HIP_CHECK(hipMemsetAsync(slots, 0, 16, s));
+  const float one = 1.f;
+  RAMP_HIP_CHECK(hipMemcpyAsync(slots, &one, 4, hipMemcpyHostToDevice, s));
+  GemmArgs a; a.A = A; a.lda = Ka; a.W = W; a.bias = (flags & 1) ? bias : nullptr; a.resid = R; a.ldr = N; a.C = C; a.ldc = N;
+  a.M = M; a.N = N; a.K = K; a.taps = taps; a.L = L;
+  if (taps > 1) { a.shift0 = -(taps / 2); a.shift_step = 1; }
+  if (geglu) { a.epi = EPI_GEGLU_FWD; a.aux_out = aux; a.ld_aux = N / 2; a.geglu_group = (mode == 1 || mode == 3) ? 32 : 64; }
+  if (amul) { a.Amul = mul; a.lda_mul = K; a.a_period = Ka; }
+  const long n = (long)taps * N * K;
+  const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
+  unsigned short* planes = nullptr;
+  if (mode == 3 && frag_ok) {
+    planes = reinterpret_cast<unsigned short*>(ar.alloc((size_t)n + 4));
+    RAMP_REQUIRE(planes, "hipMalloc failed");
+    const float sc = std::ldexp(1.f, 10) * std::sqrt((float)K * taps);      // max |w| ~ 1 / sqrt(K taps)
+    float scp = 1.f; { int e; std::frexp(sc, &e); scp = std::ldexp(1.f, e - 1); }
+    CK(launch_pack_h3(W, planes, (long)taps * N, K, scp, s));
+    a.Wx = planes; a.wx_packed = 2; a.w_scale_inv = 1.f / scp;
+    a.a_absmax_in = slots; a.a_absmax_out = slots + 1; a.range_flag = reinterpret_cast<int*>(slots + 2);
+  } else if (mode == 1 && frag_ok) {
+    planes = reinterpret_cast<unsigned short*>(ar.alloc((3 * (size_t)n + 1) / 2 + 4));
+    RAMP_REQUIRE(planes, "hipMalloc failed");
+    CK(launch_pack_x6(W, planes, (long)taps * N, K, s));
+    a.Wx = planes; a.wx_packed = 1;
+  } else if ((mode == 1 || mode == 2) && N >= 128) {
+    planes = reinterpret_cast<unsigned short*>(ar.alloc((3 * (size_t)n + 1) / 2 + 4));
+    RAMP_REQUIRE(planes, "hipMalloc failed");
+    CK(launch_split3(W, planes, n, s));
+    a.Wx = planes; a.wx_plane = n;
+  }
+  for (int i = 0; i < warmup; ++i) CK(launch_gemm(a, s));
+  hipEvent_t e0, e1;
+  RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+  RAMP_HIP_CHECK(hipEventRecord(e0, s));
+  int rc = 0;
+  for (int i = 0; i < iters && rc == 0; ++i) rc = launch_gemm(a, s);
+  RAMP_HIP_CHECK(hipEventRecord(e1, s));
+  RAMP_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  RAMP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *avg_us = ms * 1e3f / iters;
+  return rc;
+}
+
 int ramp_op_groupnorm(const float* x, const float* gamma, const float* beta, const float* tbias, const float* resid,
                       float* y, float* stats, int32_t R, int32_t L, int32_t C, float eps, int32_t mish, void* stream) {
   RAMP_REQUIRE(x && gamma && beta && y, "null argument");
@@ -1454,6 +1568,12 @@ int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
 int ramp_set_fallback(ramp_ctx* c, int32_t bf16x6_only) {
   RAMP_REQUIRE(c, "null argument");
   c->force_x6 = bf16x6_only ? 1 : 0;
+  c->score_calibrated = false;
+  return 0;
+}
+int ramp_score_mode(ramp_ctx* c, int32_t* mode) {
+  RAMP_REQUIRE(c && mode, "null argument");
+  *mode = c->score_last_mode;
   return 0;
 }
 int ramp_range_status(ramp_ctx* c, int32_t* flag, void* stream) {
@@ -1462,15 +1582,6 @@ int ramp_range_status(ramp_ctx* c, int32_t* flag, void* stream) {
   if (c->range_flag) {
     RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
     RAMP_HIP_CHECK(hipMemcpy(flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (!c->force_x6 && getenv("RAMP_TEST_RANGE_FLAG")) *flag = 7;       // test hook: exercise the caller's fallback path
-    if (*flag && getenv("RAMP_X6_WARN")) {
-      std::vector<float> o(2 * ramp_ctx::MAX_SITES);
-      RAMP_HIP_CHECK(hipMemcpy(o.data(), c->obs, o.size() * sizeof(float), hipMemcpyDeviceToHost));
-      const int sidx = std::min(std::max(*flag - 1, 0), ramp_ctx::MAX_SITES - 4);
-      fprintf(stderr, "[ramp] fp16 range flag %d (call site + 1): recorded maxima (ping, pong) = %g, %g; neighbours:", *flag, o[sidx], o[ramp_ctx::MAX_SITES + sidx]);
-      for (int k = std::max(0, sidx - 3); k < sidx + 4; ++k) fprintf(stderr, " [%d] %g/%g", k, o[k], o[ramp_ctx::MAX_SITES + k]);
-      fprintf(stderr, "\n");
-    }
   }
   return 0;
 }

@@ -146,12 +146,17 @@ class _GaussianDiffusionBase(nn.Module):
             pattern = self._row_pattern(B)
             # the step-at-a-time callers (p_mean_variance, the replanning loop) pass the same cloud every step
             m.ctx()                          # (re)creates the context and clears the key after a weight reload
-            key = (obstacle_pts.data_ptr(), obstacle_pts._version, tuple(obstacle_pts.shape), tuple(pattern))
-            if getattr(m, '_scene_key', None) == key:
+            # keyed on CONTENT: the cloud is a few KB, and a (data_ptr, _version) key of a temporary device copy is
+            # recycled by the caching allocator for the next same-shaped cloud
+            key = (tuple(obstacle_pts.shape), tuple(pattern))
+            ref = getattr(m, '_scene_ref', None)
+            if (getattr(m, '_scene_key', None) == key and ref is not None and ref.device == obstacle_pts.device
+                    and ref.dtype == obstacle_pts.dtype and torch.equal(ref, obstacle_pts)):
                 return
             lat = torch.cat([m.encode_scene(obstacle_pts), zero])
         m.set_scene(lat, pattern)
         m._scene_key = None if self.compose else key
+        m._scene_ref = None if self.compose else obstacle_pts.detach().clone()
         m.cached_batch_size = None          # the compat forward() cache is keyed differently
 
     @staticmethod
@@ -284,7 +289,9 @@ class _GaussianDiffusionBase(nn.Module):
             steps.append(t)
             noises.append(torch.randn_like(x))                      # drawn every step, zeroed at t == 0
             scales.append(1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(i)))
-        apf = [1 if (self.APF and self._supports_apf and j > self.apf_ddpm['after']) else 0 for j in range(len(steps))]
+        # compose: ddpm_sample_fn calls p_mean_variance_compose, which has no APF hook (static.py:188-229)
+        apf = [1 if (self.APF and self._supports_apf and not self.compose and j > self.apf_ddpm['after']) else 0
+               for j in range(len(steps))]
         cfg = dict(self.apf_ddpm, passes=1) if any(apf) else None
         x_out, chain = self._launch(B, torch.stack(noises), hard_conds, obstacle_pts, False, steps, apf, scales, cfg,
                                     return_chain)
@@ -392,7 +399,8 @@ class _GaussianDiffusionBase(nn.Module):
         plv = extract(self.posterior_log_variance_clipped, t, x.shape)
         if self.ddim:
             return mean, pv, plv, x0, ec
-        if self.APF and self._supports_apf and forward_t is not None and forward_t > self.apf_ddpm['after']:
+        if (self.APF and self._supports_apf and not self.compose and forward_t is not None
+                and forward_t > self.apf_ddpm['after']):
             from .apf import ObstacleField, avoidance
             field = ObstacleField(pts.reshape(-1, 2), distance_threshold=self.apf_ddpm['threshold'])
             mean = avoidance(mean, field, avoidance_window=self.apf_ddpm['window'],

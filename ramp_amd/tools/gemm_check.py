@@ -1,4 +1,4 @@
-"""Accuracy check of ramp_op_gemm against float64 (run with RAMP_GEMM_MODE=bf16x6 and RAMP_X6_PIPE=0/1)."""
+"""Accuracy check of ramp_op_gemm_mode against float64: gemm_check.py [fp32|bf16x6|bf16x6-lds|fp16x3]"""
 import os
 import sys
 
@@ -17,8 +17,7 @@ for (M, N, K, taps, L) in [(1000, 128, 32, 1, 1), (4096, 256, 256, 1, 1), (777, 
     b = torch.randn(N, device="cuda"); r = torch.randn(M, N, device="cuda")
     C = torch.empty(M, N, device="cuda")
     sh0, st = (-(taps // 2), 1) if taps > 1 else (0, 0)
-    _lib.check(lib.ramp_op_gemm(_lib.ptr(A), _lib.ptr(W), _lib.ptr(b), _lib.ptr(r), _lib.ptr(C), M, N, K, taps, sh0, st, L,
-                                _lib.current_stream()))
+    _lib.op_gemm(A, W, b, r, C, M, N, K, taps, sh0, st, L, mode=sys.argv[1] if len(sys.argv) > 1 else "fp16x3")
     A64 = A.double().view(M // L, L, K); ref = r.double() + b.double()
     acc = torch.zeros(M // L, L, N, dtype=torch.float64, device="cuda")
     for t in range(taps):

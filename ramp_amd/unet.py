@@ -54,6 +54,7 @@ class TemporalUnetInference(nn.Module):
         self._ctx: Optional[C.c_void_p] = None
         self._T_table = 0
         self._scene_key = None
+        self._scene_ref = None
         self.cached_scene_latents = None
         self.cached_batch_size = None
 
@@ -93,6 +94,7 @@ class TemporalUnetInference(nn.Module):
             self._ctx = None
             self._T_table = 0
             self._scene_key = None
+            self._scene_ref = None
 
     def __del__(self):
         try:
@@ -165,6 +167,7 @@ class TemporalUnetInference(nn.Module):
         uses variant row_pattern[r % len(row_pattern)]."""
         lat = latents.to(self._device(), torch.float32).contiguous()
         self._scene_key = None
+        self._scene_ref = None
         pat = (C.c_int32 * len(row_pattern))(*row_pattern)
         with torch.cuda.device(self._device()):
             _lib.check(_lib.load().ramp_set_scene(self.ctx(), _lib.ptr(lat), lat.shape[0], pat, len(row_pattern),
@@ -197,13 +200,23 @@ class TemporalUnetInference(nn.Module):
     def reset_cache(self):
         self.cached_scene_latents = None
         self.cached_batch_size = None
+        self._scene_key = None              # the samplers' content-keyed cache too: forces a re-encode
+        self._scene_ref = None
 
     # ------------------------------------------------------------------ forward
     def _run(self, x, time, obstacle_pts, compose, want_f, want_eps):
         if obstacle_pts is None:
             raise ValueError("obstacle_pts is required (the reference dereferences it unconditionally)")
         x = x.detach().to(self._device(), torch.float32).contiguous()
-        t = int(time.reshape(-1)[0]) if torch.is_tensor(time) else int(time)
+        if torch.is_tensor(time):
+            tv = time.reshape(-1)
+            # the time-conditioning tables are per step, not per row: the samplers always pass make_timesteps'
+            # batch-uniform vector (diffusion_model_static.py:16-18); per-row timesteps are refused, not ignored
+            if tv.numel() > 1 and not bool((tv == tv[0]).all()):
+                raise ValueError("per-row timesteps are not supported: `time` must be uniform over the batch")
+            t = int(tv[0])
+        else:
+            t = int(time)
         self.prepare_time_table(max(t + 1, self._T_table, 1))
         self.cache_scene_encoding(obstacle_pts, compose)
         n = x.shape[0]
@@ -233,6 +246,12 @@ class TemporalUnetInference(nn.Module):
         if n.value != out.numel():
             raise RuntimeError(f"tap {kind}/{module}: got {n.value} floats, expected {out.numel()}")
         return out
+
+    def score_mode(self) -> str:
+        """Arithmetic of the last single evaluation (forward / p_mean_variance): 'fp32', 'bf16x6' or 'fp16x3'."""
+        n = C.c_int32()
+        _lib.check(_lib.load().ramp_score_mode(self.ctx(), C.byref(n)))
+        return {0: "fp32", 1: "bf16x6", 2: "fp16x3"}[n.value]
 
     def workspace_bytes(self) -> int:
         n = C.c_int64()

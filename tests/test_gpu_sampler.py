@@ -1,5 +1,7 @@
 """Sampler-loop parity on the GPU: whole reverse-diffusion chains through the reference-compatible
 run_inference(), against chains captured from the reference itself with injected noise."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -346,22 +348,35 @@ def test_fp16x3_chunking_and_repeat_are_bitwise():
     assert np.abs(a[:, :4] - g["chain"]).max() < 1e-4
 
 
-def test_fp16x3_range_guard_falls_back_to_bf16x6(monkeypatch):
-    """When the fp16 range guard trips, the wrapper discards the result and repeats the SAME job with the bf16x6 kernels
-    (or raises if told not to fall back): the answer is bitwise the bf16x6-mode answer."""
+@pytest.mark.parametrize("how", ["grow", "shrink"])
+def test_fp16x3_range_guard_trips_inside_ramp_sample(how):
+    """The REAL on-device guard, no hooks: noise that makes an operand leave the range the delayed fp16 scaling assumed.
+    'grow': the noise of iteration 3 is 3e4 x larger, so the state (and the residual stream behind the first GroupNorm)
+    entering evaluation 4 is 2^14 larger than what evaluation 3 recorded; 'shrink': x_T is 1e4 x larger than every later
+    state (posterior_mean_coef2[T-1] = 0 wipes it), so evaluation 1 runs on maxima 2^13 too large.  The wrapper must
+    discard the job and repeat it with the bf16x6 kernels -- bitwise the bf16x6-mode answer -- or raise when told not to
+    fall back; afterwards the context runs fp16x3 again."""
     from ramp_amd import _lib as L
-    g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
+    g0 = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
+    noise = g0["noise"].copy()
+    if how == "grow":
+        noise[4] *= 3.0e4                 # noise[1 + j] is iteration j's randn_like
+    else:
+        noise[0] *= 1.0e4
+    g = {"noise": noise, "cloud": g0["cloud"]}
     ref, _ = run(make_static(25, gemm_mode="bf16x6"), g, 4)
+    assert np.isfinite(ref).all()
     dm = make_static(25, gemm_mode="fp16x3")
-    plain, _ = run(dm, g, 4)
-    assert not np.array_equal(plain, ref)                      # the two modes round differently ...
-    monkeypatch.setenv("RAMP_TEST_RANGE_FLAG", "1")
     with pytest.warns(UserWarning, match="range guard"):
         fb, _ = run(dm, g, 4)
-    assert np.array_equal(fb, ref)                             # ... and the fallback IS the bf16x6 job
+    assert np.array_equal(fb, ref)                             # the fallback IS the bf16x6 job
     dm.fp16_fallback = False
     with pytest.raises(L.RampHipError, match="fp16 range"):
         run(dm, g, 4)
-    monkeypatch.delenv("RAMP_TEST_RANGE_FLAG")
-    again, _ = run(dm, g, 4)
-    assert np.array_equal(again, plain)                        # and the context is back in fp16x3 afterwards
+    dm.fp16_fallback = True
+    plain, _ = run(dm, g0, 4)                                  # ordinary noise: no trip, fp16x3 arithmetic again
+    flag = C.c_int32(-1)
+    L.check(L.load().ramp_range_status(dm.model.ctx(), C.byref(flag), L.current_stream()))
+    assert flag.value == 0
+    assert np.abs(plain - g0["chain"]).max() < 1e-4
+    assert not np.array_equal(plain, run(make_static(25, gemm_mode="bf16x6"), g0, 4)[0])   # the modes round differently
