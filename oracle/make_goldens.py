@@ -17,6 +17,12 @@ What is captured:
   chain_ddpm_*.npz            full T=25 DDPM chains, B=4, with / without APF, with extra no-noise steps
   chain_ddim_*.npz            DDIM-5 of T=100 chains, with / without APF
   chain3d_ddpm.npz            3-D DDPM T=25: B independent n_samples=1 runs stacked
+  chain3d_h64_t50.npz         3-D DDPM, H=64, T=50 (the shape of BASELINE config 5): B independent n_samples=1 runs stacked
+  chain_c2.npz / chain_c3.npz the clouds of BASELINE configs 2 and 3 (16x64 2-D with the APF hook; 20x200 3-D), B = 4 / 2 golden
+                              trajectories that the full-size GPU tests embed in their B = 4096 batches
+  compose_static.npz          compose=True: one p_mean_variance_compose, a DDPM T=25 chain (use_apf=True: no hook on this
+                              path), the DDIM-8 of T=100 + APF chain on the 10-obstacle union cloud
+  compose_3d.npz              3-D compose (w1 = w2 = 5) DDPM T=25: B independent n_samples=1 runs stacked
   apf_cases.npz               avoidance() in/out pairs (hits, no-hit early-out, window clipped at ends)
   cost_cases.npz              compute_collision_with_pointcloud / compute_trajectory_costs
 """
@@ -254,6 +260,150 @@ def gen_chain3d(m3, sp3):
         chains.append(chain.detach().numpy())
     chain = np.concatenate(chains, axis=1)
     save("chain3d_ddpm.npz", chain=chain, noise=noise, cloud=cloud, latent=latent, T=T, w=5.75)
+
+
+def gen_chain3d_h64(m3b, sp3b):
+    """BASELINE config 5's shape: 3-D, H = 64, T = 50 DDPM (diffusion_model_3d.py:185-218), B independent runs."""
+    H, S, T, B = sp3b.horizon, sp3b.state_dim, 50, 2
+    cloud = synth.make_cloud(8, 40, 3, seed=45)
+    m3b.reset_cache()
+    latent = m3b.scene_encoder(torch.from_numpy(cloud)[None])[0].detach().numpy()
+    noise = synth.make_noise((T + 1, B, H, S), seed=778)
+    chains = []
+    for b in range(B):
+        dm = quiet(GaussianDiffusionModel3d, model=m3b, variance_schedule="exponential", n_diffusion_steps=T,
+                   predict_epsilon=True, compose=False, use_apf=False)
+        dm.eval()
+        m3b.reset_cache()
+        hc = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(S, H).items()}
+        with NoiseInjector([torch.from_numpy(noise[j, b:b + 1]) for j in range(T + 1)]) as inj:
+            chain = dm.run_inference(None, hc, n_samples=1, horizon=H, return_chain=True,
+                                     traj_normalized=torch.zeros(H, S), obstacle_pts=torch.from_numpy(cloud),
+                                     sample_fn=ddpm_sample_fn, guide=None, n_guide_steps=1, t_start_guide=7,
+                                     noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=0)
+            assert inj.used == T + 1
+        chains.append(chain.detach().numpy())
+    chain = np.concatenate(chains, axis=1)
+    assert chain.shape == (T + 1, B, H, S)
+    save("chain3d_h64_t50.npz", chain=chain, noise=noise, cloud=cloud, latent=latent, T=T, w=5.75)
+
+
+def gen_fullsize_seeds(m2, sp2, m3, sp3):
+    """Golden trajectories for the full-size property tests: BASELINE config 2's cloud (16 x 64 points: the 2-D encoder
+    built with num_obstacles=16, same weights -- SURVEY Q4) with the DDPM APF hook, and config 3's 20 x 200 3-D cloud."""
+    B, H, S = 4, sp2.horizon, sp2.state_dim
+    cloud = synth.make_cloud(16, 64, 2, seed=42)
+    enc6 = m2.scene_encoder
+    enc16 = ObstacleEncoderSet(num_obstacles=16)
+    enc16.load_state_dict(enc6.state_dict())
+    enc16.eval()
+    for p in enc16.parameters():
+        p.requires_grad_(False)
+    m2.scene_encoder = enc16
+    try:
+        m2.reset_cache()
+        latent = enc16(torch.from_numpy(cloud)[None])[0].detach().numpy()
+        noise = synth.make_noise((26, B, H, S), seed=1234)
+        chain, used = run_static(m2, sp2, 25, B, cloud, noise, ddim=False, use_apf=True)
+        assert used == 26
+        save("chain_c2.npz", chain=chain, noise=noise, cloud=cloud, latent=latent, T=25, use_apf=True)
+    finally:
+        m2.scene_encoder = enc6
+        m2.reset_cache()
+    H, S, T, B = sp3.horizon, sp3.state_dim, 25, 2
+    cloud = synth.make_cloud(20, 200, 3, seed=42)
+    m3.reset_cache()
+    latent = m3.scene_encoder(torch.from_numpy(cloud)[None])[0].detach().numpy()
+    noise = synth.make_noise((T + 1, B, H, S), seed=777)
+    chains = []
+    for b in range(B):
+        dm = quiet(GaussianDiffusionModel3d, model=m3, variance_schedule="exponential", n_diffusion_steps=T,
+                   predict_epsilon=True, compose=False, use_apf=False)
+        dm.eval()
+        m3.reset_cache()
+        hc = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(S, H).items()}
+        with NoiseInjector([torch.from_numpy(noise[j, b:b + 1]) for j in range(T + 1)]) as inj:
+            chain = dm.run_inference(None, hc, n_samples=1, horizon=H, return_chain=True,
+                                     traj_normalized=torch.zeros(H, S), obstacle_pts=torch.from_numpy(cloud),
+                                     sample_fn=ddpm_sample_fn, guide=None, n_guide_steps=1, t_start_guide=7,
+                                     noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=0)
+            assert inj.used == T + 1
+        chains.append(chain.detach().numpy())
+    m3.reset_cache()
+    save("chain_c3.npz", chain=np.concatenate(chains, axis=1), noise=noise, cloud=cloud, latent=latent, T=T, w=5.75)
+
+
+def gen_compose(m2, sp2):
+    """compose=True on the static wrapper (diffusion_model_static.py:188-229, 259-333): scene A + scene B + uncond."""
+    H, S, B = sp2.horizon, sp2.state_dim, 3
+    clouds = np.stack([synth.make_cloud(6, 64, 2, seed=1), synth.make_cloud(6, 64, 2, seed=2)])
+    pts = torch.from_numpy(clouds)
+    arrs = dict(clouds=clouds)
+    # (1) one p_mean_variance_compose, DDIM return signature (model_mean, ..., x_recon, e_comb)
+    dm = quiet(StaticGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=25,
+               predict_epsilon=True, compose=True, use_apf=False)
+    dm.eval()
+    m2.reset_cache()
+    x = synth.make_noise((B, H, S), seed=3)
+    t = torch.full((B,), 9, dtype=torch.long)
+    dm.ddim = True
+    mean, _, _, x0, ec = dm.p_mean_variance_compose(torch.from_numpy(x.copy()), None, None, t, traj_normalized=None,
+                                                    obstacle_pts=pts, compose=True)
+    arrs.update(pmv_x=x, pmv_t=9, pmv_mean=mean.detach().numpy(), pmv_x0=x0.detach().numpy(), pmv_ecomb=ec.detach().numpy())
+    hc = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(S, H).items()}
+    kw = dict(horizon=H, return_chain=True, traj_normalized=torch.zeros(H, S), obstacle_pts=pts, sample_fn=ddpm_sample_fn,
+              guide=None, n_guide_steps=1, t_start_guide=7, noise_std_extra_schedule_fn=lambda x: 0.5,
+              n_diffusion_steps_without_noise=0)
+    # (2) DDPM T=25 with use_apf=True: ddpm_sample_fn -> p_mean_variance_compose, which has no APF hook
+    dm = quiet(StaticGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=25,
+               predict_epsilon=True, compose=True, use_apf=True)
+    dm.eval(); dm.ddim = False
+    m2.reset_cache()
+    noise = synth.make_noise((26, B, H, S), seed=2345)
+    with NoiseInjector([torch.from_numpy(n) for n in noise]) as inj:
+        chain = dm.run_inference(None, hc, n_samples=B, **kw).detach().numpy()
+        assert inj.used == 26 and chain.shape == (26, B, H, S)
+    arrs.update(ddpm_noise=noise, ddpm_chain=chain)
+    # (3) DDIM-8 of T=100 with the APF hook (forward_t >= 2, three passes, union cloud of 6 + 4 obstacles)
+    dm = quiet(StaticGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=100,
+               predict_epsilon=True, compose=True, use_apf=True)
+    dm.eval()
+    assert dm.ddim and dm.ddim_num_inference_steps == 8
+    m2.reset_cache()
+    noise = synth.make_noise((1, B, H, S), seed=5432)
+    with NoiseInjector([torch.from_numpy(n) for n in noise]) as inj:
+        chain = dm.run_inference(None, hc, n_samples=B, **kw).detach().numpy()
+        assert inj.used == 1 and chain.shape == (9, B, H, S)
+    arrs.update(ddim_noise=noise, ddim_chain=chain)
+    m2.reset_cache()
+    save("compose_static.npz", **arrs)
+
+
+def gen_compose3d(m3, sp3):
+    """3-D compose (diffusion_model_3d.py:163-182, w1 = w2 = 5; rows [scene A, scene B, uncond], valid for one sample):
+    B independent n_samples=1 DDPM T=25 runs stacked."""
+    H, S, T, B = sp3.horizon, sp3.state_dim, 25, 2
+    clouds = np.stack([synth.make_cloud(5, 50, 3, seed=44), synth.make_cloud(5, 50, 3, seed=46)])
+    noise = synth.make_noise((T + 1, B, H, S), seed=779)
+    chains = []
+    for b in range(B):
+        dm = quiet(GaussianDiffusionModel3d, model=m3, variance_schedule="exponential", n_diffusion_steps=T,
+                   predict_epsilon=True, compose=True, use_apf=False)
+        dm.eval()
+        m3.reset_cache()
+        hc = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(S, H).items()}
+        with NoiseInjector([torch.from_numpy(noise[j, b:b + 1]) for j in range(T + 1)]) as inj:
+            chain = dm.run_inference(None, hc, n_samples=1, horizon=H, return_chain=True,
+                                     traj_normalized=torch.zeros(H, S), obstacle_pts=torch.from_numpy(clouds),
+                                     sample_fn=ddpm_sample_fn, guide=None, n_guide_steps=1, t_start_guide=7,
+                                     noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=0)
+            assert inj.used == T + 1
+        chains.append(chain.detach().numpy())
+    m3.reset_cache()
+    chain = np.concatenate(chains, axis=1)
+    lats = m3.scene_encoder(torch.from_numpy(clouds)).detach().numpy()
+    m3.reset_cache()
+    save("compose_3d.npz", chain=chain, noise=noise, clouds=clouds, latents=lats, T=T, w1=5.0, w2=5.0)
 
 
 def gen_apf():
@@ -522,6 +672,18 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "replan":
         m2, sp2, _ = build_unet(4, 48, False)
         gen_replan(m2, sp2); return
+    if len(sys.argv) > 1 and sys.argv[1] == "compose":
+        m2, sp2, _ = build_unet(4, 48, False)
+        gen_compose(m2, sp2)
+        m3, sp3, _ = build_unet(6, 48, True)
+        gen_compose3d(m3, sp3); return
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        m2, sp2, _ = build_unet(4, 48, False)
+        m3, sp3, _ = build_unet(6, 48, True)
+        gen_fullsize_seeds(m2, sp2, m3, sp3); return
+    if len(sys.argv) > 1 and sys.argv[1] == "config5":
+        m3b, sp3b, _ = build_unet(6, 64, True)
+        gen_chain3d_h64(m3b, sp3b); return
     if len(sys.argv) > 1 and sys.argv[1] == "cost":
         gen_cost(); return
     if len(sys.argv) > 1 and sys.argv[1] == "apf":
@@ -540,6 +702,9 @@ def main():
     print("cost"); gen_cost()
     print("chains 2-D"); gen_chains(m2, sp2)
     print("chain 3-D"); gen_chain3d(m3, sp3)
+    print("chain 3-D H=64 T=50"); gen_chain3d_h64(m3b, sp3b)
+    print("compose"); gen_compose(m2, sp2); gen_compose3d(m3, sp3)
+    print("full-size seeds"); gen_fullsize_seeds(m2, sp2, m3, sp3)
     print("dynamic"); gen_dynamic(m2, sp2)
     print("replan"); gen_replan(m2, sp2)
     print("metrics"); gen_metrics()

@@ -737,7 +737,7 @@ class SamplerOracle:
     """
 
     def __init__(self, unet: UNetOracle, T: int, cfg_w: float = 2.0, dtype=np.float32,
-                 sched: Optional[Dict[str, np.ndarray]] = None):
+                 sched: Optional[Dict[str, np.ndarray]] = None, compose_w=(2.0, 2.0)):
         """``sched``: the 12 schedule tables.  Several of them (1 - alphas_cumprod at small t)
         are cancellation-limited in float32, so two correct float32 evaluations differ by up to
         ~2e-4 relative; parity runs therefore pass the reference's own tables (fixtures
@@ -745,11 +745,26 @@ class SamplerOracle:
         self.unet = unet
         self.T = T
         self.w = cfg_w
+        self.compose_w = compose_w
         self.dt = dtype
         self.sched = {k: np.asarray(v).astype(dtype) for k, v in (sched or make_schedule(T, dtype)).items()}
 
+    def eps_compose(self, x: np.ndarray, t: int, latents: np.ndarray) -> np.ndarray:
+        """p_mean_variance_compose's combination (diffusion_model_static.py:188-214, diffusion_model_3d.py:163-174): three
+        rows per trajectory [scene A, scene B, unconditional (latent zeroed, UnetInference.py:190-191)],
+        e = u + w1 (cA - u) + w2 (cB - u) in that association order."""
+        B = x.shape[0]
+        x3 = np.repeat(x, 3, axis=0)
+        lat = np.zeros((3 * B, latents.shape[1]), self.dt)
+        lat[0::3] = latents[0]; lat[1::3] = latents[1]
+        out = self.unet.score(x3, np.full((3 * B,), t, np.int64), lat).reshape(B, 3, *x.shape[1:])
+        w1, w2 = self.dt(self.compose_w[0]), self.dt(self.compose_w[1])
+        return (out[:, 2] + w1 * (out[:, 0] - out[:, 2]) + w2 * (out[:, 1] - out[:, 2])).astype(self.dt)
+
     def eps_cfg(self, x: np.ndarray, t: int, latent: np.ndarray) -> np.ndarray:
-        """(1+w) eps(x|scene) - w eps(x|0) (diffusion_model_static.py:149-165)."""
+        """(1+w) eps(x|scene) - w eps(x|0) (diffusion_model_static.py:149-165); a (2, ctx) latent selects compose."""
+        if np.ndim(latent) == 2:
+            return self.eps_compose(x, t, latent)
         B = x.shape[0]
         x2 = np.repeat(x, 2, axis=0)
         lat = np.tile(latent[None, :], (2 * B, 1)).astype(self.dt)

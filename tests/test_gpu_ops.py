@@ -289,15 +289,26 @@ def test_fp16x3_dynamic_range_sweep(kind, wkind):
     _lib.op_gemm(dA, dW, None, None, o32, M, N, K, 1, 0, 0, 1, mode="fp32")
     amax = float(np.abs(A).max())
     _, flag = _lib.op_gemm(dA, dW, None, None, o16, M, N, K, 1, 0, 0, 1, mode="fp16x3", a_absmax_prev=amax)
-    assert flag == 0                                            # scaled from the true maximum: always inside the range
-    r32, r16 = o32.cpu().numpy(), o16.cpu().numpy()
+    r32 = o32.cpu().numpy()
+    absA, absW = np.abs(A).astype(np.float64), np.abs(W[0]).astype(np.float64)
+    rowscale = absA @ absW.T                                    # what fp32 summation noise of an element scales with
+    row32 = np.abs(r32 - ref).max(axis=1, keepdims=True)
+    if flag:
+        # The guard is evaluated per wave on the rows that wave staged: it fires as soon as ONE wave's rows all sit
+        # below 2^-8 of the tensor maximum (they would lose bits), not only when the whole tensor moved.  That is the
+        # "or the range guard fires" branch of the contract: the product then repeats the job on the bf16x6 kernels,
+        # which must meet the element-wise fp32 bar on these operands.
+        assert kind in ("tiny_rows", "outlier_elem", "outlier_cols", "loguniform"), "the guard must not fire on a Gaussian operand"
+        _lib.op_gemm(dA, dW, None, None, o16, M, N, K, 1, 0, 0, 1, mode="bf16x6")
+        e = np.abs(o16.cpu().numpy() - ref) / (2.0 * np.maximum(row32, 2.0 ** -24 * rowscale))
+        print(f"{kind}/{wkind}: guard fired (site flag {flag}); bf16x6 fallback element-wise err/bound {e.max():.3f}")
+        assert e.max() <= 1.0
+        return
+    r16 = o16.cpu().numpy()
     assert np.isfinite(r16).all()
     n32, n16 = rel(r32, ref), rel(r16, ref)
     assert n16 <= 2.0 * max(n32, 2.0 ** -24), (n16, n32)
-    absA, absW = np.abs(A).astype(np.float64), np.abs(W[0]).astype(np.float64)
-    row32 = np.abs(r32 - ref).max(axis=1, keepdims=True)
     floor = 2.0 ** -28 * amax * absW.sum(axis=1)[None, :] + 2.0 ** -33 * float(absW.max()) * absA.sum(axis=1)[:, None]
-    rowscale = absA @ absW.T                                    # what fp32 summation noise of an element scales with
     bound = 2.0 * np.maximum(row32, 2.0 ** -24 * rowscale) + floor
     excess = np.abs(r16 - ref) / bound
     print(f"{kind}/{wkind}: norm-wise fp32 {n32:.2e} fp16x3 {n16:.2e}; element-wise worst err/bound {excess.max():.3f}")

@@ -156,25 +156,105 @@ def test_chain3d_batched_equals_independent_reference_runs():
     assert e_gpu < 3 * e_ref
 
 
-def test_compose_three_way_vs_oracle():
-    """compose=True (3 rows per trajectory: scene A, scene B, unconditional; e = u + 2(cA-u) + 2(cB-u))."""
+def make_compose(T, use_apf, sampler=None, use_graph=True, gemm_mode="default"):
     from ramp_amd.models import StaticGaussianDiffusionModel
-    u = build_unet(4, 48, False, max_rows=12)
-    dm = StaticGaussianDiffusionModel(model=u, n_diffusion_steps=25, predict_epsilon=True, compose=True,
-                                      sampler="ddpm").eval().to("cuda")
-    clouds = np.stack([synth.make_cloud(6, 64, 2, seed=1), synth.make_cloud(6, 64, 2, seed=2)])
-    B = 3
-    x = synth.make_noise((B, 48, 4), seed=3)
-    t = torch.full((B,), 9, dtype=torch.long, device="cuda")
-    mean, _, _, x0, ec = None, None, None, None, None
-    dm.ddim = True   # return the 5-tuple
-    mean, pv, plv, x0, ec = dm.p_mean_variance(dev(x), None, None, t, obstacle_pts=dev(clouds), compose=True)
-    uo = O.UNetOracle(weights(4, 48, False), 4, 48, dtype=np.float64)
-    la, lb = uo.encode_scene(clouds[0]), uo.encode_scene(clouds[1])
-    lats = np.stack([la, lb, np.zeros_like(la)] * B)
-    out = uo.score(np.repeat(x, 3, axis=0), np.full(3 * B, 9), lats).reshape(B, 3, 48, 4)
-    e_ref = out[:, 2] + 2 * (out[:, 0] - out[:, 2]) + 2 * (out[:, 1] - out[:, 2])
-    assert rel(ec.cpu().numpy(), e_ref) < 5e-5
+    u = build_unet(4, 48, False, max_rows=12, gemm_mode=gemm_mode)
+    return StaticGaussianDiffusionModel(model=u, n_diffusion_steps=T, predict_epsilon=True, compose=True, use_apf=use_apf,
+                                        sampler=sampler, use_graph=use_graph).eval().to("cuda")
+
+
+def test_compose_static_against_reference_fixture():
+    """compose=True (3 rows per trajectory: scene A, scene B, unconditional; e = u + 2(cA-u) + 2(cB-u)) against outputs of
+    the reference's own p_mean_variance_compose and compose loops (diffusion_model_static.py:188-229, 259-333):
+    the single step, the free-running DDPM chain with use_apf=True (this path has no APF hook in the reference), and the
+    DDIM-8 of T=100 + APF chain on the 10-obstacle union cloud, teacher-forced from forward_t = 2 (APF chains are stiff)."""
+    g = np.load(f"{GOLDEN}/compose_static.npz")
+    clouds = dev(g["clouds"])
+    hcn = synth.default_hard_conds(4, 48)
+    hc = {k: torch.from_numpy(v) for k, v in hcn.items()}
+    # (1) one p_mean_variance_compose
+    dm = make_compose(25, False, sampler="ddim")
+    t = torch.full((3,), int(g["pmv_t"]), dtype=torch.long, device="cuda")
+    mean, _, _, x0, ec = dm.p_mean_variance(dev(g["pmv_x"]), None, None, t, obstacle_pts=clouds, compose=True)
+    assert rel(ec.cpu().numpy(), g["pmv_ecomb"]) < 5e-5
+    assert np.abs(x0.cpu().numpy() - g["pmv_x0"]).max() < 1e-4 and np.abs(mean.cpu().numpy() - g["pmv_mean"]).max() < 1e-4
+    # (2) DDPM T=25, use_apf=True: no hook on the compose path
+    dm = make_compose(25, True, sampler="ddpm")
+    with NoiseInjector(list(g["ddpm_noise"])) as inj:
+        chain = dm.run_inference(None, hc, n_samples=3, horizon=48, return_chain=True, obstacle_pts=clouds,
+                                 noise_std_extra_schedule_fn=lambda x: 0.5).cpu().numpy()
+        assert inj.used == 26
+    err = np.abs(chain - g["ddpm_chain"]).reshape(26, -1).max(1)
+    print(f"compose ddpm free-running: final {err[-1]:.2e} max {err.max():.2e}")
+    assert err.max() < 2e-4                       # w1 + w2 = 4 amplifies rounding ~2x the CFG chain (oracle32: same bar)
+    # (3) DDIM-8 + APF
+    dm = make_compose(100, True)
+    assert dm.ddim and dm.ddim_num_inference_steps == 8
+    with NoiseInjector(list(g["ddim_noise"])) as inj:
+        chain = dm.run_inference(None, hc, n_samples=3, horizon=48, return_chain=True, obstacle_pts=clouds).cpu().numpy()
+        assert inj.used == 1 and chain.shape == (9, 3, 48, 4)
+    assert np.abs(chain[:3] - g["ddim_chain"][:3]).max() < 1e-4          # free-running until the hook first fires
+    ref = g["ddim_chain"]
+    hcb = {k: torch.from_numpy(v).cuda().unsqueeze(0).expand(3, -1) for k, v in hcn.items()}
+    steps = [int(i) for i in dm.ddim_set_timesteps(8)]
+    worst = 0.0
+    for j, tt in enumerate(steps):
+        apf = [1 if j >= dm.apf_ddim["start"] else 0]
+        x, _ = dm._launch(3, dev(ref[j])[None], hcb, clouds, True, [tt], apf, None, dict(dm.apf_ddim) if apf[0] else None, False)
+        worst = max(worst, float(np.abs(x.cpu().numpy() - ref[j + 1]).max()))
+    print(f"compose ddim-8 + apf teacher-forced worst {worst:.2e}")
+    assert worst < 1e-4
+
+
+def test_compose_3d_against_reference_fixture():
+    """3-D compose (w1 = w2 = 5, diffusion_model_3d.py:163-182): one batched B=2 call vs two independent n_samples=1
+    reference runs, every step teacher-forced (w1 + w2 = 10 amplifies rounding ~20x per step)."""
+    from ramp_amd.models import GaussianDiffusionModel3d
+    g = np.load(f"{GOLDEN}/compose_3d.npz")
+    u = build_unet(6, 48, True, max_rows=12)
+    dm = GaussianDiffusionModel3d(model=u, n_diffusion_steps=25, predict_epsilon=True, compose=True,
+                                  use_graph=False).eval().to("cuda")
+    assert dm.compose_weights == (5.0, 5.0) and not dm.ddim
+    clouds = dev(g["clouds"])
+    assert rel(u.encode_scene(clouds).cpu().numpy(), g["latents"]) < 5e-6
+    ref = g["chain"]
+    hcb = {k: torch.from_numpy(v).cuda().unsqueeze(0).expand(2, -1) for k, v in synth.default_hard_conds(6, 48).items()}
+    worst = 0.0
+    for j, t in enumerate(reversed(range(25))):
+        noise = torch.stack([dev(ref[j]), dev(g["noise"][j + 1])])
+        x, _ = dm._launch(2, noise, hcb, clouds, False, [t], [0], [0.5], None, False)
+        worst = max(worst, float(np.abs(x.cpu().numpy() - ref[j + 1]).max()))
+    print(f"3d compose teacher-forced worst {worst:.2e}")
+    assert worst < 1e-4
+
+
+def test_config5_shape_chain_against_reference_fixture():
+    """BASELINE config 5's shape -- 3-D, H = 64, T = 50 DDPM, w = 5.75 -- against a run of the reference
+    (diffusion_model_3d.py:185-218): teacher-forced every step at 1e-4; free-running (hipGraph, default fp16x3 mode)
+    as close to the float64 truth as the reference's own fp32 chain is (within 3x) and within 1e-3 of the reference."""
+    from ramp_amd.models import GaussianDiffusionModel3d
+    g = np.load(f"{GOLDEN}/chain3d_h64_t50.npz")
+    u = build_unet(6, 64, True, max_rows=16)
+    dm = GaussianDiffusionModel3d(model=u, variance_schedule="exponential", n_diffusion_steps=50,
+                                  predict_epsilon=True, use_graph=False).eval().to("cuda")
+    worst = step_teacher_forced(dm, g, ddim=False)
+    print(f"config-5 shape teacher-forced worst {worst:.2e}")
+    assert worst < 1e-4
+    dm.use_graph = True
+    chain, used = run(dm, g, 2)
+    assert used == 51 and chain.shape == g["chain"].shape == (51, 2, 64, 6)
+    err = np.abs(chain - g["chain"]).max()
+    uo = O.UNetOracle(weights(6, 64, True), 6, 64, obstacle_3d=True, dtype=np.float64)
+    sm = O.SamplerOracle(uo, 50, 5.75, dtype=np.float64, sched=dict(np.load(f"{GOLDEN}/schedule_T50.npz")))
+    truth = sm.ddpm(g["noise"], synth.default_hard_conds(6, 64), g["latent"])
+    e_ref = np.abs(g["chain"] - truth).max(); e_gpu = np.abs(chain - truth).max()
+    print(f"config-5 shape free-running: vs reference {err:.2e}; vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e}")
+    assert err < 1e-3
+    assert e_gpu < 3 * e_ref
+    flag = C.c_int32(-1)
+    from ramp_amd import _lib as L
+    L.check(L.load().ramp_range_status(u.ctx(), C.byref(flag), L.current_stream()))
+    assert flag.value == 0
 
 
 def test_properties_at_scale():

@@ -158,6 +158,60 @@ def test_chain3d_ddpm():
     assert np.abs(ch - g["chain"]).max() < 2e-4
 
 
+def test_chain3d_h64_t50():
+    """BASELINE config 5's shape (3-D, H = 64, T = 50): w = 5.75 amplifies rounding ~12x per step and T = 50 doubles the
+    length, so the free-running fp32 restatement is compared at 5e-4 and every step teacher-forced at 1e-4."""
+    g = np.load(f"{G}/chain3d_h64_t50.npz")
+    sched = dict(np.load(f"{G}/schedule_T50.npz"))
+    u = O.UNetOracle(weights(6, 64, True), 6, 64, obstacle_3d=True)
+    assert rel(u.encode_scene(g["cloud"]), g["latent"]) < 5e-6
+    sm = O.SamplerOracle(u, 50, float(g["w"]), sched=sched)
+    hc = synth.default_hard_conds(6, 64)
+    ch = sm.ddpm(g["noise"], hc, g["latent"], teacher=g["chain"])
+    assert ch.shape == g["chain"].shape == (51, 2, 64, 6)
+    assert np.abs(ch - g["chain"]).max() < 1e-4
+    free = sm.ddpm(g["noise"], hc, g["latent"])
+    print("config-5 chain, free-running oracle32 vs reference:", np.abs(free - g["chain"]).max())
+    assert np.abs(free - g["chain"]).max() < 5e-4
+
+
+def test_compose_static():
+    """compose=True on the static wrapper: the single p_mean_variance_compose, the DDPM chain (no APF hook on that path
+    although use_apf=True) and the DDIM-8 + APF chain on the union cloud (diffusion_model_static.py:188-229, 298-319)."""
+    g = np.load(f"{G}/compose_static.npz")
+    u = O.UNetOracle(weights(4, 48, False), 4, 48)
+    lats = np.stack([u.encode_scene(g["clouds"][0]), u.encode_scene(g["clouds"][1])])
+    hc = synth.default_hard_conds(4, 48)
+    sm = O.SamplerOracle(u, 25, 2.0, sched=dict(np.load(f"{G}/schedule_T25.npz")), compose_w=(2.0, 2.0))
+    e = sm.eps_compose(g["pmv_x"], int(g["pmv_t"]), lats)
+    assert rel(e, g["pmv_ecomb"]) < 2e-5
+    x0, mean = sm.x0_mean(g["pmv_x"], g["pmv_ecomb"], int(g["pmv_t"]))
+    assert np.abs(x0 - g["pmv_x0"]).max() < 1e-6 and np.abs(mean - g["pmv_mean"]).max() < 1e-6
+    ch = sm.ddpm(g["ddpm_noise"], hc, lats, use_apf=False)
+    assert ch.shape == g["ddpm_chain"].shape == (26, 3, 48, 4)
+    assert np.abs(ch - g["ddpm_chain"]).max() < 2e-4                 # w1 + w2 = 4: ~2x the CFG chain's amplification
+    sm100 = O.SamplerOracle(u, 100, 2.0, sched=dict(np.load(f"{G}/schedule_T100.npz")), compose_w=(2.0, 2.0))
+    union = np.concatenate([g["clouds"][0], g["clouds"][1][:4]]).reshape(-1, 2)
+    ch = sm100.ddim(g["ddim_noise"][0], hc, lats, cloud=union, use_apf=True, K=8, teacher=g["ddim_chain"])
+    assert ch.shape == g["ddim_chain"].shape == (9, 3, 48, 4)
+    assert np.abs(ch - g["ddim_chain"]).max() < 1e-4
+    plain = sm100.ddim(g["ddim_noise"][0], hc, lats, use_apf=False, K=8, teacher=g["ddim_chain"])
+    assert np.abs(plain[3:] - g["ddim_chain"][3:]).max() > 1e-4      # the APF hook did fire in the fixture (forward_t >= 2)
+
+
+def test_compose_3d():
+    """3-D compose (w1 = w2 = 5; diffusion_model_3d.py:163-182), B independent n_samples=1 reference runs stacked."""
+    g = np.load(f"{G}/compose_3d.npz")
+    u = O.UNetOracle(weights(6, 48, True), 6, 48, obstacle_3d=True)
+    lats = np.stack([u.encode_scene(c) for c in g["clouds"]])
+    assert rel(lats, g["latents"]) < 5e-6
+    sm = O.SamplerOracle(u, 25, 5.75, sched=dict(np.load(f"{G}/schedule_T25.npz")), compose_w=(float(g["w1"]), float(g["w2"])))
+    hc = synth.default_hard_conds(6, 48)
+    ch = sm.ddpm(g["noise"], hc, g["latents"], teacher=g["chain"])
+    assert ch.shape == g["chain"].shape == (26, 2, 48, 6)
+    assert np.abs(ch - g["chain"]).max() < 1e-4
+
+
 def test_dynamic_cases():
     """Dynamic (pursuit-evasion) wrapper pieces: CFG with the reference's blocked row layout (quirk Q1) for even
     and odd batch sizes, the per-trajectory static / pursuer APF, and the velocity smoothing."""

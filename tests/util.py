@@ -42,7 +42,8 @@ class NoiseInjector:
     the reference), so the product's own loops consume exactly the golden noise."""
 
     def __init__(self, arrays, device="cuda"):
-        self.q = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in arrays]
+        self.q = [a.to(device) if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+                  for a in arrays]
         self.used = 0
 
     def __enter__(self):
