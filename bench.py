@@ -12,9 +12,13 @@ forward+backward evaluations, the sampler arithmetic, the final RCCL all-gather 
 (weights, scene latent, noise, hard conditions) are resident in HBM when the timed region starts.
 Weak scaling: every rank samples its own B trajectories; value = N*B*K / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event timing of
-the dominant kernel, the fp32-MFMA GEMM, on its launch stream) and `cpu_baseline` (the numpy oracle —
-a CPU port of the reference algorithm — timed on this host on a bounded sample).
+Without a torchrun environment `python bench.py --gpus N` (N > 1) starts its own N ranks (a parent that never touches the
+GPU spawns one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and exits non-zero unless all N ran.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event timing of the dominant kernel
+class, the split-precision MFMA GEMMs, on their launch stream, priced against the fp16 matrix pipe they execute on) and
+`cpu_baseline` (an eager PyTorch-CPU model of the same architecture, oracle/torch_cpu.py, pinned to the reference's
+outputs, timed on this host's cores on a bounded sample; the numpy oracle's rate is reported beside it).
 """
 from __future__ import annotations
 
@@ -33,6 +37,9 @@ sys.path.insert(0, ROOT)
 # reduced algorithmic FLOPs per sample-eval (fwd + bwd), 2-D S=4 H=48
 FLOP_PER_ROW_EVAL = 1.324e9
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_FP16_MFMA_TFLOPS = 2500.0         # same guide: Peak BF16/FP16 MFMA, dense
+PEAK_HBM_TBS = 8.0                     # same guide: HBM3E peak (6.3 achievable)
+FP16_PRODUCTS_PER_FP32 = 3             # fp16x3: h1h1' + h1h2' + h2h1' per fp32 product
 
 
 def parse():
@@ -43,7 +50,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="trajectories in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="trajectories in the PyTorch-CPU baseline sample (halved "
+                                                                  "until the projected chain time is <= 40 s)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE.json config (1-based): 2 = headline Maze2D B=4096 H=48 T=25 (default); "
                          "3 = Maze3D B=4096 H=48 T=25 4k-pt cloud; 5 = Maze3D B=8192/GPU H=64 T=50 8k-pt cloud")
@@ -107,38 +115,87 @@ def profile_gemm(dm, B, cloud, hard_conds):
     return {n: {"ms": ms[i], "flops": fl[i], "launches": int(cnt[i])} for i, n in enumerate(names)}
 
 
+PMC_FILE = "profiles/r02_pmc_traffic.json"
+
+
 def pmc_traffic(klass):
-    """Per-launch HBM traffic of a kernel class from the committed PMC summary (counters need their own passes)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    """Per-launch HBM traffic of a kernel class from the committed PMC summary: counters need rocprofv3's own passes
+    (FETCH_SIZE and WRITE_SIZE do not even fit one pass), so they cannot be collected inside this run.  Returns
+    (bytes per launch or None, provenance string)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)
     try:
         with open(path) as fh:
-            return float(json.load(fh)[klass]["hbm_bytes_per_launch"])
+            d = json.load(fh)
+        return float(d[klass]["hbm_bytes_per_launch"]), f"{PMC_FILE} ({d.get('collected', 'separate rocprofv3 --pmc passes')})"
     except Exception:
-        return None
+        return None, "no PMC summary committed for this round"
+
+
+def host_cores():
+    """Physical cores this process may use (the GPU box hands each GPU a share of the host)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or avail
+    except Exception:
+        phys = avail
+    return max(1, min(avail, phys))
 
 
 def cpu_baseline(sd, cloud_np, n_traj):
-    """The oracle (numpy restatement of the reference algorithm) on the host cores, bounded sample."""
+    """(1) PyTorch-CPU eager model of the same architecture (oracle/torch_cpu.py; same ATen kernels and autograd energy
+    gradient as the reference's CPU path, validated against the reference's outputs in tests/) on a bounded sample of
+    the headline workload; (2) the numpy oracle on a smaller sample, for continuity with round 1."""
+    import torch
     from oracle import ramp_oracle as O
+    from oracle.torch_cpu import TorchCpuSampler, TorchCpuScoreNet
     from ramp_amd import synth
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    net = TorchCpuScoreNet(sd, 4, 48)
     u = O.UNetOracle(sd, 4, 48, dtype=np.float32)
-    sm = O.SamplerOracle(u, 25, 2.0, dtype=np.float32)
     lat = u.encode_scene(cloud_np)
-    noise = synth.make_noise((26, n_traj, 48, 4), seed=1234)
+    sched = O.make_schedule(25, np.float32)
+    sm = TorchCpuSampler(net, sched, 2.0)
+    hc = synth.default_hard_conds(4, 48)
+    # size the sample: one score evaluation of 2 x n rows, then the whole chain if it projects to <= 40 s
+    n = n_traj
+    while True:
+        x = torch.from_numpy(synth.make_noise((2 * n, 48, 4), seed=5))
+        lt = torch.from_numpy(np.tile(lat[None], (2 * n, 1)).astype(np.float32))
+        tt = torch.full((2 * n,), 12, dtype=torch.long)
+        net.score(x[:8], tt[:8], lt[:8])                       # first-call overheads out of the estimate
+        t0 = time.time(); net.score(x, tt, lt); te = time.time() - t0
+        if te * 25 <= 40.0 or n <= 8:
+            break
+        n //= 2
+    noise = synth.make_noise((26, n, 48, 4), seed=1234)
     t0 = time.time()
-    sm.ddpm(noise, synth.default_hard_conds(4, 48), lat, cloud=cloud_np.reshape(-1, 2), use_apf=True)
+    sm.ddpm(noise, hc, lat, cloud=cloud_np.reshape(-1, 2), use_apf=True)
     dt = time.time() - t0
-    return {"value": n_traj / dt, "unit": "trajectories/s", "cores": int(threads), "kind": "port",
-            "sample": f"numpy oracle, B={n_traj} trajectories, full T=25 DDPM chain + APF, fp32, {dt:.1f} s"}
+    out = {"value": n / dt, "unit": "trajectories/s", "cores": int(cores), "kind": "port",
+           "sample": f"eager PyTorch-CPU model of the same architecture (oracle/torch_cpu.py, pinned to the reference's "
+                     f"outputs), torch.set_num_threads({cores}), B={n} trajectories x 2 CFG rows, full T=25 DDPM chain + APF, "
+                     f"fp32, {dt:.1f} s",
+           "torch_version": torch.__version__}
+    nn = 4
+    sm2 = O.SamplerOracle(u, 25, 2.0, dtype=np.float32)
+    t0 = time.time()
+    sm2.ddpm(synth.make_noise((26, nn, 48, 4), seed=1234), hc, lat, cloud=cloud_np.reshape(-1, 2), use_apf=True)
+    dn = time.time() - t0
+    out["numpy_oracle"] = {"value": nn / dn, "unit": "trajectories/s", "sample": f"numpy restatement (the parity oracle), B={nn}, {dn:.1f} s"}
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torchrun around us: this process becomes a GPU-free parent of args.gpus ranks (one per GPU, RCCL between them)
+        from ramp_amd.dist import launch_local_ranks
+        sys.exit(launch_local_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     import torch
     import torch.distributed as dist
     from ramp_amd import dist as rdist
@@ -149,10 +206,14 @@ def main():
     if args.config == 5 and args.batch == 4096:
         args.batch = 8192
     rank, world, local = rdist.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as "
+                         f"{args.gpus} GPUs")
     if world > 1:
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPU(s)")
         torch.cuda.set_device(local)
         rdist.init_process_group("nccl")
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the RAMP sampler has no CPU path")
     device = torch.device("cuda", local if world > 1 else 0)
@@ -193,7 +254,8 @@ def main():
     result = {
         "metric": f"sampled trajectories/sec (H={WL['H']}, T={WL['T']})", "value": value, "unit": "trajectories/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32-emulated (2 x fp16 planes per operand, fp32 accumulate)", "data": "synthetic",
         "gemm_mode": "fp16x3 (default): every fp32 operand is scaled by a power of two and split into 2 fp16 planes (22 "
                      "significand bits), 3 fp16 MFMA products accumulated in fp32; the first score evaluation of each job "
                      "runs bf16x6 and records the operand maxima the scales come from (fp32-level accuracy: the parity "
@@ -205,7 +267,9 @@ def main():
                    "trajectories_per_gpu": B, "horizon": WL["H"], "state_dim": WL["S"], "n_diffusion_steps": WL["T"],
                    "cloud_points": WL["cloud"][0] * WL["cloud"][1], "sharding": f"sample-batch x{world}, final all-gather only"},
         "e2e_algorithmic_tflops_per_gpu": e2e_tflops_per_gpu,
+        "e2e_frac_of_fp16x3_ceiling": e2e_tflops_per_gpu * FP16_PRODUCTS_PER_FP32 / PEAK_FP16_MFMA_TFLOPS,
         "e2e_frac_of_fp32_mfma_peak": e2e_tflops_per_gpu / PEAK_FP32_MFMA_TFLOPS,
+        "n_ranks_rccl": world,
         "workspace_gb": dm.model.workspace_bytes() / 2 ** 30,
     }
 
@@ -230,18 +294,21 @@ def main():
         g = prof["gemm_f32_mfma"]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
         total_ms = sum(v["ms"] for v in prof.values())
+        peak = PEAK_FP16_MFMA_TFLOPS / FP16_PRODUCTS_PER_FP32
+        traffic, traffic_src = pmc_traffic("gemm")
+        avg_us = g["ms"] * 1e3 / max(g["launches"], 1)
         result["roofline"] = {
-            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic("gemm_f32_mfma"),
-            "traffic_note": "HBM-side bytes per GEMM launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc "
-                            "passes over one score evaluation of this workload (profiles/r01_pmc_traffic.json, "
-                            "ramp_amd/tools/score_pmc.py + pmc_summary.py); not collected inside this run",
-            "kernel": "ramp::gemm_x6p_kernel<*> + gemm_kernel<*> (linears + k5/k1/stride-2 convs, fwd and dX)",
-            "peak_note": "achieved = ALGORITHMIC fp32 FLOPs / kernel time; peak = fp32 matrix peak (the arithmetic contract is "
-                         "fp32), which the split-precision kernel exceeds because it executes 3 fp16 MFMA products per fp32 "
-                         "product (6 bf16 ones in the calibration evaluation) on the 2500 TFLOP/s fp16/bf16 matrix pipes",
-            "executed_fp16_tflops": 3 * achieved, "frac_of_fp16_peak": 3 * achieved / 2500.0,
-            "launches_per_step": g["launches"], "avg_launch_us": g["ms"] * 1e3 / max(g["launches"], 1),
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "hbm_frac": (traffic / (avg_us * 1e-6) / 1e12 / PEAK_HBM_TBS) if traffic else None,
+            "kernel": "ramp::gemm_x6p_kernel<*, NP=2> (fp16x3; NP=3 = bf16x6 in the calibration evaluation) + gemm_kernel<*> "
+                      "(exact fp32, N = 32 layers): linears + k5/k1/stride-2 convs, forward and dX",
+            "peak_note": "achieved = ALGORITHMIC fp32 FLOPs of the GEMM launches / their summed HIP-event time; peak = the pipe "
+                         "the kernel executes on, fp16 dense MFMA 2500 TFLOP/s, divided by the 3 fp16 products it spends per "
+                         "fp32 product (833.3); frac = executed fp16 FLOP/s / 2500",
+            "executed_fp16_tflops": FP16_PRODUCTS_PER_FP32 * achieved,
+            "frac_vs_fp32_matrix_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "launches_per_step": g["launches"], "avg_launch_us": avg_us,
             "algorithmic_gflop_per_launch": g["flops"] / max(g["launches"], 1) / 1e9,
             "share_of_kernel_time": g["ms"] / total_ms,
             "kernel_time_ms_by_class": {k: round(v["ms"], 3) for k, v in prof.items()},
@@ -258,8 +325,9 @@ def main():
             torch.cuda.synchronize(); t1 = time.perf_counter()
             run_job(dm2, B, cloud, hard_conds, 1)
             torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
+            tf = B * 2 * 25 * FLOP_PER_ROW_EVAL / dt2 / 1e12
             result[key] = {"value": B / dt2, "unit": "trajectories/s", "ms_per_step": dt2 * 1e3,
-                           "e2e_frac_of_fp32_mfma_peak": B * 2 * 25 * FLOP_PER_ROW_EVAL / dt2 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+                           "e2e_frac_of_its_roofline": tf * 6 / PEAK_FP16_MFMA_TFLOPS if mode == "bf16x6" else tf / PEAK_FP32_MFMA_TFLOPS}
             del dm2
             torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:

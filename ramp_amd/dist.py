@@ -10,7 +10,10 @@ scripts/train/trainddp.py), so there is no reference call pattern to mirror here
 from __future__ import annotations
 
 import os
-from typing import Callable, List, Tuple
+import socket
+import subprocess
+import sys
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -71,3 +74,50 @@ def sample_sharded(sample_local: Callable[[int, int], torch.Tensor], n_total: in
     start, stop = shard_range(n_total, rank, world)
     local = sample_local(start, stop)
     return all_gather_trajectories(local, n_total) if gather else local
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_local_ranks(argv: List[str], world: int, extra_env: Optional[Dict[str, str]] = None,
+                       timeout: Optional[float] = None) -> int:
+    """Start ``world`` copies of ``python argv...`` on this node, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set the way torchrun sets them, and wait for all of them.  The caller is a parent that has
+    NOT initialised the GPU (it only spawns children and relays rank 0's stdout).  Returns 0 only if every rank exited
+    with 0; when one rank fails the others are terminated (a rank stuck in a collective would otherwise hang forever)."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    import time
+    t0 = time.time()
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    q.terminate()
+        if timeout is not None and time.time() - t0 > timeout and live:
+            for q in live:
+                q.kill()
+            return 124
+        time.sleep(0.05)
+    return rc

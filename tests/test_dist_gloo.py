@@ -60,3 +60,22 @@ def test_sharded_sampling_allgather_world2(n_total):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res) and all(r[2] == 2.0 for r in res)
+
+
+def test_launch_local_ranks(tmp_path):
+    """The launcher behind `python bench.py --gpus N` (no torchrun): N children with the torchrun environment, rank 0's
+    line relayed, non-zero exit when a rank fails (the others are terminated instead of hanging in a collective)."""
+    import json
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rank_probe.py")
+    code = ("import sys; sys.path.insert(0, %r); from ramp_amd import dist as d; "
+            "sys.exit(d.launch_local_ranks([%r] + sys.argv[1:], 2, timeout=240))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), probe))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    line = json.loads(ok.stdout.strip().splitlines()[-1])
+    assert line == {"n_gpus": 2, "max": 2.0, "gathered": [0.0, 0.0, 1.0, 1.0]}
+    bad = subprocess.run([sys.executable, "-c", code, "fail"], capture_output=True, text=True, env=env, timeout=300)
+    assert bad.returncode != 0

@@ -212,6 +212,27 @@ def test_compose_3d():
     assert np.abs(ch - g["chain"]).max() < 1e-4
 
 
+def test_torch_cpu_baseline_score_and_chain():
+    """bench.py's PyTorch-CPU eager baseline (oracle/torch_cpu.py: the same architecture and loop written in this repo,
+    ATen fp32 kernels, autograd energy gradient) against the reference's own outputs: forward / eps of unet2d_h48.npz and
+    the free-running T = 25 DDPM chain."""
+    import torch
+    from oracle.torch_cpu import TorchCpuSampler, TorchCpuScoreNet
+    g = np.load(f"{G}/unet2d_h48.npz")
+    net = TorchCpuScoreNet(weights(4, 48, False), 4, 48)
+    N = g["x"].shape[0]
+    lat = np.tile(g["latent"][None], (N, 1)).astype(np.float32); lat[1::2] = 0
+    x, t, lt = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(lat)
+    with torch.no_grad():
+        f = net.f(x, t, lt).numpy()
+    assert rel(f, g["f"]) < 2e-5
+    assert rel(net.score(x, t, lt).numpy(), g["eps"]) < 5e-5
+    c = np.load(f"{G}/chain_ddpm_plain.npz")
+    sm = TorchCpuSampler(net, dict(np.load(f"{G}/schedule_T25.npz")), 2.0)
+    ch = sm.ddpm(c["noise"], synth.default_hard_conds(4, 48), c["latent"])
+    assert ch.shape == c["chain"].shape and np.abs(ch - c["chain"]).max() < 1e-4
+
+
 def test_dynamic_cases():
     """Dynamic (pursuit-evasion) wrapper pieces: CFG with the reference's blocked row layout (quirk Q1) for even
     and odd batch sizes, the per-trajectory static / pursuer APF, and the velocity smoothing."""
