@@ -300,7 +300,7 @@ def test_fp16x3_dynamic_range_sweep(kind, wkind):
         # which must meet the element-wise fp32 bar on these operands (within 3x of the fp32 kernel's own row-wise error).
         assert kind in ("tiny_rows", "outlier_elem", "outlier_cols", "loguniform"), "the guard must not fire on a Gaussian operand"
         _lib.op_gemm(dA, dW, None, None, o16, M, N, K, 1, 0, 0, 1, mode="bf16x6")
-        e = np.abs(o16.cpu().numpy() - ref) / (2.0 * np.maximum(row32, 2.0 ** -24 * rowscale))
+        e = np.abs(o16.cpu().numpy() - ref) / (3.0 * np.maximum(row32, 2.0 ** -24 * rowscale))
         print(f"{kind}/{wkind}: guard fired (site flag {flag}); bf16x6 fallback element-wise err/bound {e.max():.3f}")
         assert e.max() <= 1.0
         return
