@@ -187,7 +187,8 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
 /* micro-benchmark (profiling tools only): one GEMM shape on the kernel `mode` names (as ramp_op_gemm_mode), operands
  * allocated and filled inside, weights packed once, `warmup` untimed then `iters` timed back-to-back launches on `stream`
  * between two HIP events; *avg_us = microseconds per launch.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue
- * (N = 2F), 8 A-multiplier operand (the FF1-dX loader; K = 2 x the operand width). */
+ * (N = 2F), 8 A-multiplier operand (the FF1-dX loader; K = 2 x the operand width), 16 force the 128 x 128 tile,
+ * 32 force 3 blocks per CU. */
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream);
 int ramp_op_groupnorm(const float* x, const float* gamma, const float* beta, const float* tbias,

@@ -598,15 +598,15 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 // work at once; the rows still leave as 16-byte stores (a store instruction covers 4 rows x 256 contiguous bytes).
 // GEGLU forward expects the weights tiled [32 a-rows | 32 g-rows] so that a wave's two 32-column halves hold matching
 // (a, g) pairs.  Same fused math as `epilogue` (bias, per-row-variant bias, residuals, GEGLU forward / backward).
-template <int EPI, bool GEN, bool OSC>
+template <int EPI, bool GEN, bool OSC, int BM = 128, int BN = 128>
 __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x16 (&acc)[2][2], float* Sw, int tile, int tiles_n,
                                               int lane, int wm, int wn, int r, int h, const float oscale) {
   constexpr int SLD = 68;                                  // floats per scratch row (64 + pad: conflict-free b128 reads)
   const int tile_m = tile / tiles_n;
-  const int n0 = (tile - tile_m * tiles_n) * 128;
+  const int n0 = (tile - tile_m * tiles_n) * BN;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    const int m0 = tile_m * 128 + wm * 64 + mi * 32;
+    const int m0 = tile_m * BM + wm * 64 + mi * 32;
     if (EPI == EPI_GEGLU_FWD) {
       const int rl0 = lane >> 3, c = (lane & 7) * 4;       // 4 passes of 8 rows; 8 lanes per row
       const int nb = n0 + wn * 64;
@@ -757,7 +757,7 @@ __device__ __forceinline__ u32x2 peel4(f32x4& v, bool subtract) {
 // 22 bits and smaller ones an absolute error of 2^-30 of the maximum); a launch whose scaled operand reaches 60000,
 // or whose largest scaled element falls below 2^-3, raises a.range_flag.  All scales are powers of two and are undone exactly in the epilogue.
 // Two blocks per CU (bf16x6, and the fp16x3 A-multiplier variant whose extra operand registers do not fit three) ...
-template <int EPI, bool GEN, bool AMUL = false, int NP = 3, bool REC = false>
+template <int EPI, bool GEN, bool AMUL = false, int NP = 3, bool REC = false, bool WIDE = false>
 __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #define X6P_THREE 0
@@ -767,7 +767,7 @@ void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 // ... or three (fp16x3: 168 VGPRs, 51 KB of LDS): a third resident block covers the epilogue-store stalls of the others;
 // the compiler spills registers around the epilogue (once per tile), none inside the slab loop.  Used where it
 // measured faster (launch_x6).
-template <int EPI, bool GEN, bool AMUL = false, int NP = 2, bool REC = true>
+template <int EPI, bool GEN, bool AMUL = false, int NP = 2, bool REC = true, bool WIDE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #define X6P_THREE 1
@@ -814,22 +814,35 @@ constexpr size_t X6_LDS = std::max<size_t>(6 * (size_t)128 * XLD * 2, (size_t)12
 constexpr size_t X6P_LDS3 = 2 * (9216 + 3 * (size_t)128 * XLD * 2);    // pipelined, 3 planes: 67584 B (2 blocks / CU)
 constexpr size_t X6P_LDS2 = 2 * (9728 + 2 * (size_t)128 * XLD * 2);    // pipelined, 2 planes, 3 blocks / CU: 52224 B
 constexpr size_t X6P_LDS2R = 2 * (17408 + 2 * (size_t)128 * XLD * 2);  // pipelined, 2 planes, 2 blocks / CU (roomy): 67584 B
+constexpr size_t X6P_LDS2W = 2 * (17408 + 2 * (size_t)64 * XLD * 2);   // 64 x 256 tile, 2 planes (roomy): 51200 B (up to 3 blocks / CU)
 static_assert(X6P_LDS3 <= X6_LDS, "bf16x6 pipelined layout");
 
 template <int EPI, bool GEN>
 static int launch_x6(const GemmArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + 127) / 128, tiles_n = (a.N + 127) / 128;
+  // 64 x 256 tiles (fp16x3 linears whose N is a multiple of 256: every transformer projection): see gemm_x6p_body.inc
+  const bool wide = !GEN && a.wx_packed == 2 && a.N % 256 == 0 && a.tile_pref != 1;
+  const int BMt = wide ? 64 : 128, BNt = wide ? 256 : 128;
+  const int tiles_m = (a.M + BMt - 1) / BMt, tiles_n = (a.N + BNt - 1) / BNt;
   const int n_tiles = tiles_m * tiles_n;
   // fp16x3 GEGLU forward (the kernel with the longest epilogue): 3 blocks per CU.  The plain shapes measured slower that
   // way (the ~60 registers spilled around every tile's epilogue cost more than the third block hides: 228 -> 172 TFLOP/s
   // at 393216 x 256 x 256), GEGLU forward faster (189 -> 201).
-  const bool three = a.wx_packed == 2 && !a.Amul && EPI == EPI_GEGLU_FWD;
+  const bool three = a.wx_packed == 2 && !a.Amul && (EPI == EPI_GEGLU_FWD || a.tile_pref == 3);
   const int slots = three ? 768 : 512;
   const int rounds = (n_tiles + slots - 1) / slots;
   const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
 #define X6P_LAUNCH(...) hipLaunchKernelGGL((gemm_x6p_kernel<__VA_ARGS__>), dim3(nb), dim3(256), X6P_LDS3, s, a, tiles_n, n_tiles)
   const bool rec = a.a_absmax_out != nullptr;
-  if (a.wx_packed && a.Amul) {
+  if (wide) {
+    if constexpr (!GEN) {
+      if (a.Amul) {
+        RAMP_REQUIRE(EPI == EPI_LINEAR && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
+        if constexpr (EPI == EPI_LINEAR)
+          hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
+      } else if (three) hipLaunchKernelGGL((gemm_x6p3_kernel<EPI, false, false, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
+      else hipLaunchKernelGGL((gemm_x6p_kernel<EPI, false, false, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
+    }
+  } else if (a.wx_packed && a.Amul) {
     RAMP_REQUIRE(EPI == EPI_LINEAR && !GEN && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
     if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true>), dim3(nb), dim3(256), X6P_LDS2R, s, a, tiles_n, n_tiles);
     else if (rec) X6P_LAUNCH(EPI_LINEAR, false, true, 3, true);
@@ -854,6 +867,12 @@ static int set_attr_x6() {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2));
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI, GEN, false, 2, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2R));
+  if constexpr (!GEN) {
+    RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI, false, false, 2, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2W));
+    RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p3_kernel<EPI, false, false, 2, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2W));
+  }
   return 0;
 }
 template <int WM, int WN, int MI, int NI> struct Cfg {
@@ -892,6 +911,8 @@ int init_gemm_attributes() {
   X6P_ATTR(EPI_LINEAR, false, true, 3, true);
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2R));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2W));
   if (int e = set_attr_x6<EPI_LINEAR, false>()) return e;
   if (int e = set_attr_x6<EPI_LINEAR, true>()) return e;
   if (int e = set_attr_x6<EPI_GEGLU_FWD, false>()) return e;
