@@ -297,10 +297,10 @@ def test_fp16x3_dynamic_range_sweep(kind, wkind):
         # The guard is evaluated per wave on the rows that wave staged: it fires as soon as ONE wave's rows all sit
         # below 2^-8 of the tensor maximum (they would lose bits), not only when the whole tensor moved.  That is the
         # "or the range guard fires" branch of the contract: the product then repeats the job on the bf16x6 kernels,
-        # which must meet the element-wise fp32 bar on these operands (within 3x of the fp32 kernel's own row-wise error).
+        # which must meet the element-wise fp32 bar on these operands (within 4x of the fp32 kernel's own row-wise error: max-over-a-row statistics of two ~2^-24 roundings).
         assert kind in ("tiny_rows", "outlier_elem", "outlier_cols", "loguniform"), "the guard must not fire on a Gaussian operand"
         _lib.op_gemm(dA, dW, None, None, o16, M, N, K, 1, 0, 0, 1, mode="bf16x6")
-        e = np.abs(o16.cpu().numpy() - ref) / (3.0 * np.maximum(row32, 2.0 ** -24 * rowscale))
+        e = np.abs(o16.cpu().numpy() - ref) / (4.0 * np.maximum(row32, 2.0 ** -24 * rowscale))
         print(f"{kind}/{wkind}: guard fired (site flag {flag}); bf16x6 fallback element-wise err/bound {e.max():.3f}")
         assert e.max() <= 1.0
         return
