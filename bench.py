@@ -52,9 +52,11 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="trajectories in the PyTorch-CPU baseline sample (halved "
                                                                   "until the projected chain time is <= 40 s)")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based): 2 = headline Maze2D B=4096 H=48 T=25 (default); "
-                         "3 = Maze3D B=4096 H=48 T=25 4k-pt cloud; 5 = Maze3D B=8192/GPU H=64 T=50 8k-pt cloud")
+                         "3 = Maze3D B=4096 H=48 T=25 4k-pt cloud; 4 = Maze2D dynamic replanning B=8192 (10 high-level DDIM steps "
+                         "+ 3 replans x 5, moving 1024-pt pursuer cloud, one hipGraph per replan); "
+                         "5 = Maze3D B=8192/GPU H=64 T=50 8k-pt cloud")
     return ap.parse_args()
 
 
@@ -62,6 +64,8 @@ WORKLOADS = {   # S, H, T, 3-D?, cloud (n_obstacles, n_points), use_apf
     2: dict(S=4, H=48, T=25, o3=False, cloud=(16, 64), apf=True),
     3: dict(S=6, H=48, T=25, o3=True, cloud=(20, 200), apf=False),
     5: dict(S=6, H=64, T=50, o3=True, cloud=(40, 200), apf=False),
+    # dynamic planner: T = 100 schedule, 10 + 3 x 5 = 25 score-network steps per job
+    4: dict(S=4, H=48, T=100, o3=False, cloud=(16, 64), apf=False, dynamic=True, evals=25, replans=3),
 }
 WL = WORKLOADS[2]
 
@@ -77,6 +81,12 @@ def build_model(B, device, gemm_mode="default"):
     unet = TemporalUnetInference(n_support_points=WL["H"], state_dim=WL["S"], unet_input_dim=32, dim_mults=(1, 2, 4, 8),
                                  obstacle_3d=WL["o3"], max_rows=2 * B, gemm_mode=gemm_mode)
     load_numpy_state_dict(unet, sd)
+    if WL.get("dynamic"):
+        from ramp_amd.models import DynamicGaussianDiffusionModel
+        dm = DynamicGaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=WL["T"],
+                                           predict_epsilon=True, use_graph=True)
+        dm.apf_dynamic = dict(dm.apf_dynamic, points_per_obstacle=1024)      # pursuer cloud re-sampled to 1024 points per replan
+        return dm.eval().to(device), sd
     cls = GaussianDiffusionModel3d if WL["o3"] else StaticGaussianDiffusionModel
     dm = cls(model=unet, variance_schedule="exponential", n_diffusion_steps=WL["T"], predict_epsilon=True,
              compose=False, use_apf=WL["apf"], sampler="ddpm", use_graph=True)
@@ -88,6 +98,18 @@ def run_job(dm, B, cloud, hard_conds, world, x_all=None):
     """One step = one run_inference of B trajectories + the final all-gather."""
     import torch
     from ramp_amd import dist as rdist
+    if WL.get("dynamic"):
+        # one job = the high-level plan (10 DDIM steps, one graph) + selection + WL["replans"] replans (5 DDIM steps each,
+        # one graph per replan) against a freshly reset pursuit environment; the executed plan (H, S) is the product
+        from ramp_amd import compat, synth
+        import numpy as np
+        np.random.seed(0)
+        boxes = synth.make_boxes(WL["cloud"][0], 2, seed=42)
+        ctx = {"dataset": compat.make_pursuit_env(boxes, np.full((len(boxes), 2), 0.26), [0.6, 0.55])}
+        hc = {k: v.unsqueeze(0).expand(B, -1).contiguous() for k, v in hard_conds.items()}
+        x, _chain, _obs, _start = dm.ddim_p_sample_loop((B, WL["H"], WL["S"]), hc, context=ctx, return_chain=False,
+                                                        obstacle_pts=cloud, max_iteration=WL["replans"])
+        return x
     x = dm.run_inference(None, hard_conds, n_samples=B, horizon=WL["H"], return_chain=False, traj_normalized=None,
                          obstacle_pts=cloud, sample_fn=None, guide=None, n_guide_steps=1, t_start_guide=7,
                          noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=0)
@@ -234,7 +256,7 @@ def main():
 
     global WL
     WL = WORKLOADS[args.config]
-    if args.config == 5 and args.batch == 4096:
+    if args.config in (4, 5) and args.batch == 4096:
         args.batch = 8192
     rank, world, local = rdist.env_rank()
     if world != args.gpus:
@@ -275,12 +297,15 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert out.shape == (B * world, WL["H"], WL["S"]) and bool(torch.isfinite(out).all())
+    if WL.get("dynamic"):
+        assert out.shape == (WL["H"], WL["S"]) and bool(torch.isfinite(out).all())
+    else:
+        assert out.shape == (B * world, WL["H"], WL["S"]) and bool(torch.isfinite(out).all())
 
     value = world * B * args.steps / dt
     ms_per_step = dt / args.steps * 1e3
-    flop_row = {2: 1.324e9, 3: 1.323e9, 5: 1.773e9}[args.config]          # SURVEY.md §8(d), reduced count
-    e2e_tflops_per_gpu = B * 2 * WL["T"] * flop_row / (dt / args.steps) / 1e12
+    flop_row = {2: 1.324e9, 3: 1.323e9, 4: 1.324e9, 5: 1.773e9}[args.config]          # SURVEY.md §8(d), reduced count
+    e2e_tflops_per_gpu = B * 2 * WL.get("evals", WL["T"]) * flop_row / (dt / args.steps) / 1e12
 
     result = {
         "metric": f"sampled trajectories/sec (H={WL['H']}, T={WL['T']})", "value": value, "unit": "trajectories/s",
@@ -294,6 +319,9 @@ def main():
         "config": {"workload": {2: "BASELINE configs[1]: Maze2D static DDPM, B=4096 trajectories/GPU x 2 CFG rows, "
                                    "H=48, S=4, T=25, 1024-pt cloud, APF forward_t>20, hipGraph replay",
                                 3: "BASELINE configs[2]: Maze3D DDPM (w=5.75), B=4096/GPU x 2 CFG rows, H=48, S=6, T=25, 4000-pt cloud",
+                                4: "BASELINE configs[3]: Maze2D dynamic replanning, B=8192 candidates x 2 CFG rows, H=48, 25 score steps "
+                                   "(10 high-level DDIM + 3 replans x 5), 1024-pt static + 1024-pt moving pursuer cloud, one hipGraph "
+                                   "per replan, device-side APF / costs / selection",
                                 5: "BASELINE configs[4]: Maze3D DDPM, B=8192/GPU x 2 CFG rows, H=64, S=6, T=50, 8000-pt cloud"}[args.config],
                    "trajectories_per_gpu": B, "horizon": WL["H"], "state_dim": WL["S"], "n_diffusion_steps": WL["T"],
                    "cloud_points": WL["cloud"][0] * WL["cloud"][1], "sharding": f"sample-batch x{world}, final all-gather only"},
@@ -304,7 +332,7 @@ def main():
         "workspace_gb": dm.model.workspace_bytes() / 2 ** 30,
     }
 
-    if rank == 0 and not WL["o3"]:
+    if rank == 0 and not WL["o3"] and not WL.get("dynamic"):
         # solution quality of the last timed batch, outside the timed region (on-device metrics);
         # the weights are random, so this only shows that the metric path runs at the benchmark's batch size
         from ramp_amd.metrics import Metrics
@@ -320,7 +348,7 @@ def main():
         result["solution_quality"]["metrics_ms"] = (time.perf_counter() - tq) * 1e3
         result["solution_quality"]["note"] = "random-init weights: not a planning-quality claim"
 
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline and not WL.get("dynamic"):
         prof = profile_gemm(dm, B, cloud, hard_conds)
         g = prof["gemm_f32_mfma"]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12

@@ -137,6 +137,81 @@ typedef struct ramp_sample_params {
 int ramp_sample(ramp_ctx* ctx, const ramp_sample_params* p, const float* noise, float* chain_out,
                 float* x_out, void* stream);
 
+/* ---- receding-horizon replanning: DynamicGaussianDiffusionModel.ddim_p_sample_loop, STAGE II
+ *      (diffusion_model_dynamic.py:533-612) ----
+ * One call = one replan iteration, run as ONE captured hipGraph: q_sample of the current best plan for all B candidates
+ * (:671-680), the executed history / goal / zero start velocity pinned (:540-546, :563-568), n_steps DDIM steps of the
+ * score network with CFG (:338-447), on the last one (t == 0) the velocity smoothing `sm` (:192-214, :551-553) and the
+ * per-trajectory static + pursuer APF (:375-435, APFhelper_dynamic.py:107-142), the final smoothing (:570-571), the
+ * collision mask / path length / smoothness against the cost cloud and the min-max-normalised argmin
+ * (cost.py:25-88, :572-590) with `x[0, 2:] = 0` on the winner (:607).  What differs between two replans -- executed
+ * history, current waypoint, noise, the pursuer's cloud and position -- is copied into fixed device buffers first, so the
+ * graph is captured once (twice in fp16x3 mode: the first replan after a scene change calibrates the delayed operand
+ * scales on its first evaluation, later ones continue from their predecessor's maxima).  The single device-to-host
+ * transfer of a replan is the 16-byte result record.  The environment callback of the reference (the pursuer's dynamics,
+ * fed x[:, stepp, :2], which is the pinned executed state and therefore known beforehand) runs in the caller BEFORE this
+ * call; the "no collision-free candidate" restart (:591-605) is left to the caller too (result.n_free == 0). */
+typedef struct ramp_replan_params {
+  int32_t B;               /* candidate trajectories                                       */
+  int32_t n_rp;            /* 2 (CFG)                                                      */
+  int32_t n_steps;         /* DDIM steps of one replan (ddim_num_inference_steps_low = 5)  */
+  int32_t clip_denoised;
+  double w;                /* CFG weight (2.5)                                             */
+  /* per-step HOST arrays of length n_steps, as in ramp_sample_params */
+  const int32_t* t;
+  const float* sqrt_recip; const float* sqrt_recipm1;
+  const float* sqrt_a_t; const float* sqrt_1m_a_t; const float* sqrt_a_prev; const float* dir_coef;
+  float q_sqrt_a, q_sqrt_1m_a;     /* q_sample at t[0]: sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod */
+  int32_t n_hard; int32_t reserved0;
+  const int32_t* hard_idx_host;    /* host (n_hard)                                        */
+  const float* hard_val;           /* device (n_hard, B, S)                                */
+  int32_t sm_window_last;          /* 3: smoothing before the last DDIM step               */
+  int32_t sm_window_final;         /* 2: smoothing before the selection                    */
+  float sm_dt, sm_max_vel;         /* 0.1, 0.8                                             */
+  const double* static_pts;        /* device (n_static, 2) float64: APF cloud of the static boxes */
+  int32_t n_static;
+  int32_t n_dyn;                   /* points of the pursuer's sphere cloud                 */
+  double thr_static, thr_pred, strength_static, strength_pred;   /* 0.2, 0.5, 0.15, 0.15    */
+  int32_t window_static;           /* 8                                                    */
+  int32_t n_cost;                  /* points of the static cost cloud                      */
+  const float* cost_cloud;         /* device (n_cost, 2)                                   */
+  int32_t n_extra;                 /* pursuer points appended to the cost cloud when it is near (64); 0 = never */
+  float cost_thr;                  /* collision threshold of the selection (0.05)          */
+  float w_smooth, w_len;           /* 0.1, 0.9                                             */
+  int32_t use_graph;
+} ramp_replan_params;
+
+typedef struct ramp_replan_state {
+  const float* noise;              /* device (B, H, S): the randn_like of q_sample         */
+  const float* x_clean;            /* device (H, S) current best plan, or NULL = the previous replan's winner */
+  const float* history;            /* device (n_hist, S): executed states, pinned at waypoints 0 .. n_hist-1 */
+  int32_t n_hist;
+  int32_t stepp;                   /* current waypoint (= n_hist - 1 in the reference loop) */
+  const double* dyn_pts_host;      /* host (n_dyn, 2) float64: pursuer sphere cloud after its update */
+  float pursuer[2];                /* its centre                                            */
+  int32_t near;                    /* 1: append extra_pts_host to the cost cloud            */
+  int32_t reserved;
+  const float* extra_pts_host;     /* host (n_extra, 2) or NULL                             */
+} ramp_replan_state;
+
+typedef struct ramp_replan_result {
+  int32_t n_free;                  /* collision-free candidates                             */
+  int32_t best_rank;               /* winner's index among the free ones (what the reference's argmin returns) */
+  int32_t best_row;                /* its row in the batch                                  */
+  int32_t fell_back;               /* != 0: fp16x3 range guard fired (1 + call site) and the replan was repeated in bf16x6 */
+} ramp_replan_result;
+
+/* best_out device (H,S) or NULL; batch_out device (B,H,S) or NULL (the batch handed to the selection); mask_out device
+ * (B) int32 or NULL (1 = in collision).  Synchronises `stream` (the result record is in host memory on return). */
+int ramp_replan(ramp_ctx* ctx, const ramp_replan_params* p, const ramp_replan_state* st, float* best_out, float* batch_out,
+                int32_t* mask_out, ramp_replan_result* result_host, void* stream);
+/* the selection alone (compute_trajectory_costs + winner with x[0, 2:] = 0) for a finished batch, e.g. the high-level plan
+ * (diffusion_model_dynamic.py:524-530): mask / path_len / smooth device (B), best_out device (H,S), result_dev device
+ * int32[4] = {n_free, best_rank, best_row, 0}.  Asynchronous. */
+int ramp_select_best(const float* traj, int32_t B, int32_t H, int32_t S, const float* cloud, int32_t n_points, float threshold,
+                     float w_smooth, float w_len, int32_t* mask, float* path_len, float* smooth, float* best_out,
+                     int32_t* result_dev, void* stream);
+
 /* ---- kernel-level entry points (same kernels the loops use; exported for parity tests) ---- */
 /* avoidance(trajectories, ObstacleField(cloud, thr), window, strength) in place (APFhelper.py:37-104) */
 int ramp_apf(float* traj, int32_t B, int32_t H, int32_t S, const ramp_apf_params* p, void* stream);

@@ -39,6 +39,29 @@ class RampSampleParams(C.Structure):
                 ("apf", RampApfParams), ("use_graph", C.c_int32), ("reserved", C.c_int32)]
 
 
+class RampReplanParams(C.Structure):
+    _fields_ = [("B", C.c_int32), ("n_rp", C.c_int32), ("n_steps", C.c_int32), ("clip_denoised", C.c_int32),
+                ("w", C.c_double), ("t", c_i32p), ("sqrt_recip", c_f32p), ("sqrt_recipm1", c_f32p), ("sqrt_a_t", c_f32p),
+                ("sqrt_1m_a_t", c_f32p), ("sqrt_a_prev", c_f32p), ("dir_coef", c_f32p), ("q_sqrt_a", C.c_float),
+                ("q_sqrt_1m_a", C.c_float), ("n_hard", C.c_int32), ("reserved0", C.c_int32), ("hard_idx_host", c_i32p),
+                ("hard_val", C.c_void_p), ("sm_window_last", C.c_int32), ("sm_window_final", C.c_int32),
+                ("sm_dt", C.c_float), ("sm_max_vel", C.c_float), ("static_pts", C.c_void_p), ("n_static", C.c_int32),
+                ("n_dyn", C.c_int32), ("thr_static", C.c_double), ("thr_pred", C.c_double), ("strength_static", C.c_double),
+                ("strength_pred", C.c_double), ("window_static", C.c_int32), ("n_cost", C.c_int32),
+                ("cost_cloud", C.c_void_p), ("n_extra", C.c_int32), ("cost_thr", C.c_float), ("w_smooth", C.c_float),
+                ("w_len", C.c_float), ("use_graph", C.c_int32)]
+
+
+class RampReplanState(C.Structure):
+    _fields_ = [("noise", C.c_void_p), ("x_clean", C.c_void_p), ("history", C.c_void_p), ("n_hist", C.c_int32),
+                ("stepp", C.c_int32), ("dyn_pts_host", C.c_void_p), ("pursuer", C.c_float * 2), ("near", C.c_int32),
+                ("reserved", C.c_int32), ("extra_pts_host", C.c_void_p)]
+
+
+class RampReplanResult(C.Structure):
+    _fields_ = [("n_free", C.c_int32), ("best_rank", C.c_int32), ("best_row", C.c_int32), ("fell_back", C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/ramp_hip.h
 PROTOTYPES = {
     "ramp_last_error": (C.c_char_p, []),
@@ -55,6 +78,10 @@ PROTOTYPES = {
     "ramp_score_mode": (C.c_int, [C.c_void_p, c_i32p]),
     "ramp_sample": (C.c_int, [C.c_void_p, C.POINTER(RampSampleParams), C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p]),
+    "ramp_replan": (C.c_int, [C.c_void_p, C.POINTER(RampReplanParams), C.POINTER(RampReplanState), C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.POINTER(RampReplanResult), C.c_void_p]),
+    "ramp_select_best": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ramp_apf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RampApfParams), C.c_void_p]),
     "ramp_apf_dynamic": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
                                    C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -175,6 +175,17 @@ struct ApfDynArgs {
   double thr_query = 0, thr_force = 0, strength = 0;
 };
 int launch_apf_dynamic(const ApfDynArgs& a, hipStream_t s);
+// receding-horizon replanning (sampler.hip): what changes from replan to replan, resident on the device
+struct ReplanState { int n_hist; int stepp; int pad0; int pad1; float pursuer[2]; float pad2[2]; };
+int launch_replan_init(float* x, const float* x_clean, const float* noise, float sa, float s1a, const float* hist,
+                       const ReplanState* st, int B, int H, int S, hipStream_t s);
+int launch_replan_pin(float* x, HardConds hc, const float* hist, const float* x_clean, const ReplanState* st, int B, int H,
+                      int S, hipStream_t s);
+int launch_replan_sm(float* x, const ReplanState* st, int window, float dt, float max_vel, int B, int H, int S, hipStream_t s);
+int launch_replan_near(const float* x, const ReplanState* st, float thr, int* en, int B, int H, int S, hipStream_t s);
+int launch_replan_goal(float* x0, const float* x, int B, int H, int S, hipStream_t s);
+int launch_replan_select(const float* traj, const int* mask, const float* plen, const float* smooth, float w_s, float w_l,
+                         float* best, int* result, int B, int H, int S, hipStream_t s);
 // mask[b] = any_{h,p} ||xy - p|| < thr ; plen[b], smooth[b]
 int launch_traj_costs(const float* traj, const float* cloud, int B, int H, int S, int P, float thr,
                       int* mask, float* plen, float* smooth, hipStream_t s);

@@ -154,6 +154,16 @@ struct ramp_ctx {
   float* s_cloud = nullptr; size_t s_cloud_cap = 0;
   // graph cache
   hipGraphExec_t graph_exec = nullptr; std::string graph_key;
+  // receding-horizon replanning (ramp_replan): fixed device buffers the captured graphs read, the graph of a replan whose
+  // first evaluation calibrates ([0]) and of one that continues from the previous replan's operand maxima ([1])
+  float *r_noise = nullptr, *r_hist = nullptr, *r_xclean = nullptr, *r_best = nullptr, *r_plen = nullptr, *r_smooth = nullptr,
+        *r_cost = nullptr, *r_hard_val = nullptr;
+  double *r_static = nullptr, *r_dyn = nullptr;
+  int *r_mask = nullptr, *r_en = nullptr, *r_result = nullptr, *r_hard_idx = nullptr;
+  ReplanState* r_state = nullptr;
+  size_t r_cap_B = 0, r_cap_static = 0, r_cap_dyn = 0, r_cap_cost = 0;
+  hipGraphExec_t r_graph[2] = {nullptr, nullptr}; std::string r_key;
+  bool r_calibrated = false;
   // scene-encoder scratch
   float* scene_ws = nullptr; size_t scene_ws_cap = 0;
   // bf16x6 weight planes: fp32 weight base pointer -> (planes, element count)
@@ -165,7 +175,7 @@ struct ramp_ctx {
   // fp16x3 (gemm_mode 2): delayed operand scaling.  phase 0 = bf16x6; 1 = bf16x6 that records max|A| per GEMM call site
   // (the calibration evaluation: the first score evaluation of every ramp_sample); 2 = fp16x3 scaled from the
   // previous evaluation's maxima, recording its own.  obs[2][MAX_SITES] floats, ping-pong by evaluation.
-  static constexpr int MAX_SITES = 1024;
+  static constexpr int MAX_SITES = 1024, N_OBS_TABLES = 3;
   int phase = 0, site = 0;
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
@@ -776,7 +786,7 @@ int ensure_sampler_buffers(ramp_ctx* c, int B, int n_rp, int n_steps, bool chain
   const size_t nn = (size_t)(n_steps + 1) * B * HS;
   if (nn > c->s_noise_cap) { CK(dev_alloc(c, &c->s_noise, nn)); c->s_noise_cap = nn; moved = true; }
   if (chain && nn > c->s_chain_cap) { CK(dev_alloc(c, &c->s_chain, nn)); c->s_chain_cap = nn; moved = true; }
-  if (moved) c->graph_key.clear();      // captured nodes hold the old pointers
+  if (moved) { c->graph_key.clear(); c->r_key.clear(); }      // captured nodes hold the old pointers
   return 0;
 }
 
@@ -831,6 +841,7 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
 int ramp_destroy(ramp_ctx* c) {
   if (!c) return 0;
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  for (auto& g : c->r_graph) if (g) (void)hipGraphExecDestroy(g);
   if (c->d_ptr_tables) (void)hipFree(c->d_ptr_tables);
   delete c;
   return 0;
@@ -981,9 +992,10 @@ int ramp_finalize_weights(ramp_ctx* c) {
       return 0;
     };
     if (c->gemm_mode == 2) {
-      float* o; CK(dev_alloc(c, &o, 2 * ramp_ctx::MAX_SITES + 4));
-      c->obs = o; c->range_flag = reinterpret_cast<int*>(o + 2 * ramp_ctx::MAX_SITES);
-      RAMP_HIP_CHECK(hipMemset(o, 0, (2 * ramp_ctx::MAX_SITES + 4) * sizeof(float)));
+      const size_t nt = (size_t)ramp_ctx::N_OBS_TABLES * ramp_ctx::MAX_SITES;
+      float* o; CK(dev_alloc(c, &o, nt + 4));
+      c->obs = o; c->range_flag = reinterpret_cast<int*>(o + nt);
+      RAMP_HIP_CHECK(hipMemset(o, 0, (nt + 4) * sizeof(float)));
     }
     for (auto& r : c->rtbs) {
       if (!r.first) { CK(reg(r.c1.fwd, 5ul * r.cin * r.cout, r.cin)); CK(reg(r.c1.bwd, 5ul * r.cin * r.cout, r.cout)); }
@@ -1081,7 +1093,8 @@ int ramp_set_scene(ramp_ctx* c, const float* latents, int32_t n_variants, const 
   RAMP_HIP_CHECK(hipStreamSynchronize(s));
   RAMP_HIP_CHECK(hipFree(d));
   c->graph_key.clear();     // scene changed: cross_bias pointer may have moved
-  c->score_calibrated = false;
+  c->r_key.clear();
+  c->score_calibrated = false; c->r_calibrated = false;
   return rc;
 }
 
@@ -1125,6 +1138,7 @@ int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, 
     int flag = 0;
     RAMP_HIP_CHECK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     RAMP_HIP_CHECK(hipStreamSynchronize(s));
+    c->r_calibrated = false;
     if (!flag) { c->score_parity ^= 1; c->score_last_mode = 2; return 0; }
   }
   tables(c->score_parity);
@@ -1134,6 +1148,7 @@ int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, 
   c->phase = 0;
   CK(rc);
   c->score_calibrated = true; c->score_parity ^= 1; c->score_last_mode = 1;
+  c->r_calibrated = false;
   return 0;
 }
 
@@ -1223,7 +1238,7 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
   }
   RAMP_HIP_CHECK(hipMemcpyAsync(c->s_noise, noise, n_noise * 4, hipMemcpyDeviceToDevice, s));
   c->launches = 0;
-  c->score_calibrated = false;      // the loop below overwrites the delayed-scaling tables
+  c->score_calibrated = false; c->r_calibrated = false;      // the loop below overwrites the delayed-scaling tables
   if (!p->use_graph) {
     CK(sample_body(c, p, s, chain));
   } else {
@@ -1261,6 +1276,204 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
   if (chain_out) RAMP_HIP_CHECK(hipMemcpyAsync(chain_out, c->s_chain, (size_t)(p->n_steps + 1) * n * 4, hipMemcpyDeviceToDevice, s));
   if (x_out) RAMP_HIP_CHECK(hipMemcpyAsync(x_out, c->s_x, n * 4, hipMemcpyDeviceToDevice, s));
   return 0;
+}
+
+// ---- receding-horizon replanning --------------------------------------------------------------------
+// One replan of DynamicGaussianDiffusionModel.ddim_p_sample_loop (diffusion_model_dynamic.py:533-612) as ONE captured
+// graph: q_sample of the current plan -> n_steps x [score, CFG + x0, (last step: static + pursuer APF), DDIM update,
+// pinned waypoints] -> smoothing -> collision mask / costs -> selection.  The pursuer's new position is computed by the
+// caller BEFORE the replan: the reference hands the environment x[:, stepp, :2], which is the pinned executed state.
+static int replan_body(ramp_ctx* c, const ramp_replan_params* p, hipStream_t s, bool calibrate) {
+  const int B = p->B, H = c->cfg.horizon, S = c->cfg.state_dim;
+  const size_t HS = (size_t)H * S;
+  HardConds hc; hc.idx = c->r_hard_idx; hc.val = c->r_hard_val; hc.n = p->n_hard;
+  HardConds none;
+  CK(launch_replan_init(c->s_x, c->r_xclean, c->r_noise, p->q_sqrt_a, p->q_sqrt_1m_a, c->r_hist, c->r_state, B, H, S, s));
+  const bool h3 = c->gemm_mode == 2 && !c->force_x6;
+  if (h3) {
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<unsigned*>(c->range_flag), 1);
+    RAMP_HIP_CHECK(hipGetLastError());
+  }
+  for (int j = 0; j < p->n_steps; ++j) {
+    const bool last = p->t[j] == 0;                       // the reference's `i == 0`: smoothing + APF on the final step
+    if (last) CK(launch_replan_sm(c->s_x, c->r_state, p->sm_window_last, p->sm_dt, p->sm_max_vel, B, H, S, s));
+    if (h3) {
+      // delayed-scaling tables: evaluation j writes table j & 1, the last one table 2, which the first evaluation of the
+      // NEXT replan reads: every steady-state replan sees the same pointers, so its graph is captured once
+      const int t_out = j + 1 == p->n_steps ? 2 : (j & 1);
+      const int t_in = j == 0 ? 2 : ((j - 1) & 1);
+      c->phase = (calibrate && j == 0) ? 1 : 2;
+      c->obs_out = c->obs + t_out * ramp_ctx::MAX_SITES;
+      c->obs_in = c->obs + t_in * ramp_ctx::MAX_SITES;
+      hipLaunchKernelGGL(zero_words_kernel, dim3(ramp_ctx::MAX_SITES / 256), dim3(256), 0, s,
+                         reinterpret_cast<unsigned*>(c->obs_out), ramp_ctx::MAX_SITES);
+      RAMP_HIP_CHECK(hipGetLastError());
+    }
+    const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s);
+    c->phase = 0;
+    CK(rc_score);
+    CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = p->n_rp;
+    m.w0 = (float)p->w; m.w1 = 0.f; m.w0p1 = (float)(1.0 + p->w);
+    m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised;
+    m.mean = nullptr; m.x0 = c->s_x0;
+    CK(launch_cfg_mean(m, s));
+    if (last) {
+      CK(launch_replan_near(c->s_x, c->r_state, (float)p->thr_pred, c->r_en, B, H, S, s));
+      ApfDynArgs a; a.traj = c->s_x0; a.B = B; a.H = H; a.S = S;
+      a.points = c->r_static; a.P = p->n_static; a.window = p->window_static; a.affected = H;
+      a.thr_query = p->thr_static; a.thr_force = p->thr_static; a.strength = p->strength_static;
+      CK(launch_apf_dynamic(a, s));
+      a.points = c->r_dyn; a.P = p->n_dyn; a.window = -1; a.affected = H; a.thr_query = p->thr_pred;
+      a.strength = p->strength_pred; a.goal = c->s_x + (size_t)(H - 1) * S; a.enable = c->r_en;
+      CK(launch_apf_dynamic(a, s));
+      CK(launch_replan_goal(c->s_x0, c->s_x, B, H, S, s));
+    }
+    CK(launch_ddim_finish(c->s_x, c->s_x0, p->sqrt_a_t[j], p->sqrt_1m_a_t[j], p->sqrt_a_prev[j], p->dir_coef[j], none,
+                          c->s_x, nullptr, B, H, S, s));
+    CK(launch_replan_pin(c->s_x, hc, c->r_hist, c->r_xclean, c->r_state, B, H, S, s));
+  }
+  CK(launch_replan_sm(c->s_x, c->r_state, p->sm_window_final, p->sm_dt, p->sm_max_vel, B, H, S, s));
+  CK(launch_traj_costs(c->s_x, c->r_cost, B, H, S, p->n_cost + p->n_extra, p->cost_thr, c->r_mask, c->r_plen, c->r_smooth, s));
+  CK(launch_replan_select(c->s_x, c->r_mask, c->r_plen, c->r_smooth, p->w_smooth, p->w_len, c->r_best, c->r_result, B, H, S, s));
+  return 0;
+}
+
+int ramp_replan(ramp_ctx* c, const ramp_replan_params* p, const ramp_replan_state* st, float* best_out, float* batch_out,
+                int32_t* mask_out, ramp_replan_result* result_host, void* stream) {
+  RAMP_REQUIRE(c && p && st && result_host, "null argument");
+  RAMP_REQUIRE(c->finalized && c->cross_bias, "context not ready (weights / scene)");
+  const int B = p->B, H = c->cfg.horizon, S = c->cfg.state_dim;
+  RAMP_REQUIRE(B > 0 && p->n_rp == 2 && p->n_steps >= 1 && p->n_steps <= 64, "bad replan dims");
+  RAMP_REQUIRE(p->t && p->sqrt_recip && p->sqrt_recipm1 && p->sqrt_a_t && p->sqrt_1m_a_t && p->sqrt_a_prev && p->dir_coef, "missing schedule arrays");
+  RAMP_REQUIRE(p->n_hard >= 0 && p->n_hard <= 16 && (p->n_hard == 0 || (p->hard_idx_host && p->hard_val)), "bad hard conditions");
+  RAMP_REQUIRE(p->static_pts && p->n_static > 0 && p->n_dyn > 0 && p->cost_cloud && p->n_cost > 0 && p->n_extra >= 0, "bad clouds");
+  RAMP_REQUIRE(st->noise && st->history && st->n_hist >= 1 && st->n_hist <= H && st->stepp >= 0 && st->stepp < H, "bad replan state");
+  RAMP_REQUIRE(st->dyn_pts_host && (st->near == 0 || p->n_extra == 0 || st->extra_pts_host), "missing pursuer points");
+  RAMP_REQUIRE(st->x_clean || c->r_best, "no current plan: pass x_clean on the first replan");
+  for (int j = 0; j < p->n_hard; ++j) RAMP_REQUIRE(p->hard_idx_host[j] >= 0 && p->hard_idx_host[j] < H, "hard index out of range");
+  hipStream_t s = as_stream(stream);
+  const size_t HS = (size_t)H * S, n = (size_t)B * HS;
+  // ---- fixed buffers the graphs read
+  CK(ensure_sampler_buffers(c, B, p->n_rp, 0, false));
+  bool moved = false;
+  if (!c->r_state) {
+    float* q; CK(dev_alloc(c, &q, 16)); c->r_state = reinterpret_cast<ReplanState*>(q);
+    CK(dev_alloc(c, &q, 8)); c->r_result = reinterpret_cast<int*>(q);
+    CK(dev_alloc(c, &q, 16)); c->r_hard_idx = reinterpret_cast<int*>(q);
+    CK(dev_alloc(c, &c->r_hist, HS)); CK(dev_alloc(c, &c->r_xclean, HS)); CK(dev_alloc(c, &c->r_best, HS));
+    moved = true;
+  }
+  if ((size_t)B > c->r_cap_B) {
+    float* q;
+    CK(dev_alloc(c, &c->r_noise, n)); CK(dev_alloc(c, &c->r_plen, B)); CK(dev_alloc(c, &c->r_smooth, B));
+    CK(dev_alloc(c, &q, B)); c->r_mask = reinterpret_cast<int*>(q);
+    CK(dev_alloc(c, &q, B)); c->r_en = reinterpret_cast<int*>(q);
+    CK(dev_alloc(c, &c->r_hard_val, (size_t)16 * B * S));
+    c->r_cap_B = B; moved = true;
+  }
+  if ((size_t)p->n_static > c->r_cap_static) {
+    float* q; CK(dev_alloc(c, &q, (size_t)p->n_static * 4)); c->r_static = reinterpret_cast<double*>(q);
+    c->r_cap_static = p->n_static; moved = true;
+  }
+  if ((size_t)p->n_dyn > c->r_cap_dyn) {
+    float* q; CK(dev_alloc(c, &q, (size_t)p->n_dyn * 4)); c->r_dyn = reinterpret_cast<double*>(q);
+    c->r_cap_dyn = p->n_dyn; moved = true;
+  }
+  if ((size_t)(p->n_cost + p->n_extra) > c->r_cap_cost) {
+    CK(dev_alloc(c, &c->r_cost, (size_t)(p->n_cost + p->n_extra) * 2)); c->r_cap_cost = p->n_cost + p->n_extra; moved = true;
+  }
+  if (moved) c->r_key.clear();
+  // ---- this replan's inputs
+  RAMP_HIP_CHECK(hipMemcpyAsync(c->r_noise, st->noise, n * 4, hipMemcpyDeviceToDevice, s));
+  RAMP_HIP_CHECK(hipMemcpyAsync(c->r_hist, st->history, (size_t)st->n_hist * S * 4, hipMemcpyDeviceToDevice, s));
+  RAMP_HIP_CHECK(hipMemcpyAsync(c->r_xclean, st->x_clean ? st->x_clean : c->r_best, HS * 4, hipMemcpyDeviceToDevice, s));
+  RAMP_HIP_CHECK(hipMemcpyAsync(c->r_static, p->static_pts, (size_t)p->n_static * 16, hipMemcpyDeviceToDevice, s));
+  RAMP_HIP_CHECK(hipMemcpyAsync(c->r_cost, p->cost_cloud, (size_t)p->n_cost * 8, hipMemcpyDeviceToDevice, s));
+  RAMP_HIP_CHECK(hipMemcpyAsync(c->r_dyn, st->dyn_pts_host, (size_t)p->n_dyn * 16, hipMemcpyHostToDevice, s));
+  std::vector<float> far((size_t)p->n_extra * 2, 1.0e9f);     // (alive until the synchronisation below)
+  if (p->n_extra) {
+    // the pursuer's sphere points join the cost cloud only when it is near the evader; otherwise far-away fillers
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->r_cost + (size_t)p->n_cost * 2, st->near ? st->extra_pts_host : far.data(),
+                                  (size_t)p->n_extra * 8, hipMemcpyHostToDevice, s));
+  }
+  if (p->n_hard) {
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->r_hard_idx, p->hard_idx_host, p->n_hard * 4, hipMemcpyHostToDevice, s));
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->r_hard_val, p->hard_val, (size_t)p->n_hard * B * S * 4, hipMemcpyDeviceToDevice, s));
+  }
+  ReplanState hs{}; hs.n_hist = st->n_hist; hs.stepp = st->stepp; hs.pursuer[0] = st->pursuer[0]; hs.pursuer[1] = st->pursuer[1];
+  RAMP_HIP_CHECK(hipMemcpyAsync(c->r_state, &hs, sizeof(hs), hipMemcpyHostToDevice, s));
+  c->launches = 0;
+  c->score_calibrated = false;
+  const bool h3 = c->gemm_mode == 2 && !c->force_x6;
+  auto run = [&](bool calibrate) -> int {
+    if (!p->use_graph) return replan_body(c, p, s, calibrate);
+    std::string key;
+    auto put = [&](const void* q, size_t b) { key.append(static_cast<const char*>(q), b); };
+    put(&p->B, 4); put(&p->n_steps, 4); put(&p->w, 8); put(p->t, 4 * p->n_steps); put(p->sqrt_recip, 4 * p->n_steps);
+    put(p->sqrt_recipm1, 4 * p->n_steps); put(p->sqrt_a_t, 4 * p->n_steps); put(p->sqrt_1m_a_t, 4 * p->n_steps);
+    put(p->sqrt_a_prev, 4 * p->n_steps); put(p->dir_coef, 4 * p->n_steps); put(&p->q_sqrt_a, 4); put(&p->q_sqrt_1m_a, 4);
+    put(&p->clip_denoised, 4); put(&p->n_hard, 4); put(&p->sm_window_last, 4); put(&p->sm_window_final, 4); put(&p->sm_dt, 4);
+    put(&p->sm_max_vel, 4); put(&p->n_static, 4); put(&p->n_dyn, 4); put(&p->thr_static, 8); put(&p->thr_pred, 8);
+    put(&p->strength_static, 8); put(&p->strength_pred, 8); put(&p->window_static, 4); put(&p->n_cost, 4); put(&p->n_extra, 4);
+    put(&p->cost_thr, 4); put(&p->w_smooth, 4); put(&p->w_len, 4); put(&c->force_x6, 4);
+    if (key != c->r_key) {
+      for (auto& g : c->r_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+      c->r_key = key;
+    }
+    const int which = (h3 && !calibrate) ? 1 : 0;
+    if (!c->r_graph[which]) {
+      hipStream_t cs;
+      RAMP_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      RAMP_HIP_CHECK(hipStreamSynchronize(s));
+      RAMP_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+      int rc = replan_body(c, p, cs, calibrate);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(cs, &g);
+      if (rc != 0) { if (g) (void)hipGraphDestroy(g); (void)hipStreamDestroy(cs); return rc; }
+      if (e != hipSuccess) { (void)hipStreamDestroy(cs); RAMP_HIP_CHECK(e); }
+      e = hipGraphInstantiate(&c->r_graph[which], g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g); (void)hipStreamDestroy(cs);
+      RAMP_HIP_CHECK(e);
+    }
+    RAMP_HIP_CHECK(hipGraphLaunch(c->r_graph[which], s));
+    return 0;
+  };
+  CK(run(h3 && !c->r_calibrated));
+  // ---- the one read-back of a replan: {n_free, rank, row} + the range flag
+  int back[4] = {0, 0, 0, 0};
+  RAMP_HIP_CHECK(hipMemcpyAsync(back, c->r_result, 12, hipMemcpyDeviceToHost, s));
+  if (h3) RAMP_HIP_CHECK(hipMemcpyAsync(back + 3, c->range_flag, 4, hipMemcpyDeviceToHost, s));
+  RAMP_HIP_CHECK(hipStreamSynchronize(s));
+  result_host->fell_back = 0;
+  if (h3 && back[3]) {
+    // an operand left the range the delayed scaling assumed: repeat THIS replan (same inputs) on the bf16x6 kernels and
+    // start the next one with a calibration evaluation
+    c->force_x6 = 1;
+    int rc = replan_body(c, p, s, false);
+    c->force_x6 = 0;
+    CK(rc);
+    RAMP_HIP_CHECK(hipMemcpyAsync(back, c->r_result, 12, hipMemcpyDeviceToHost, s));
+    RAMP_HIP_CHECK(hipStreamSynchronize(s));
+    c->r_calibrated = false;
+    result_host->fell_back = back[3];
+  } else if (h3) {
+    c->r_calibrated = true;
+  }
+  result_host->n_free = back[0]; result_host->best_rank = back[1]; result_host->best_row = back[2];
+  if (best_out) RAMP_HIP_CHECK(hipMemcpyAsync(best_out, c->r_best, HS * 4, hipMemcpyDeviceToDevice, s));
+  if (batch_out) RAMP_HIP_CHECK(hipMemcpyAsync(batch_out, c->s_x, n * 4, hipMemcpyDeviceToDevice, s));
+  if (mask_out) RAMP_HIP_CHECK(hipMemcpyAsync(mask_out, c->r_mask, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+/* compute_trajectory_costs + the winner (cost.py:56-88) for a finished batch, e.g. the high-level plan */
+int ramp_select_best(const float* traj, int32_t B, int32_t H, int32_t S, const float* cloud, int32_t n_points, float threshold,
+                     float w_smooth, float w_len, int32_t* mask, float* path_len, float* smooth, float* best_out,
+                     int32_t* result_dev, void* stream) {
+  RAMP_REQUIRE(traj && cloud && mask && path_len && smooth && best_out && result_dev, "null argument");
+  hipStream_t s = as_stream(stream);
+  CK(launch_traj_costs(traj, cloud, B, H, S, n_points, threshold, mask, path_len, smooth, s));
+  return launch_replan_select(traj, mask, path_len, smooth, w_smooth, w_len, best_out, result_dev, B, H, S, s);
 }
 
 // ---- kernel-level entry points ---------------------------------------------------------------------
@@ -1569,7 +1782,7 @@ int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
 int ramp_set_fallback(ramp_ctx* c, int32_t bf16x6_only) {
   RAMP_REQUIRE(c, "null argument");
   c->force_x6 = bf16x6_only ? 1 : 0;
-  c->score_calibrated = false;
+  c->score_calibrated = false; c->r_calibrated = false;
   return 0;
 }
 int ramp_score_mode(ramp_ctx* c, int32_t* mode) {

@@ -218,6 +218,191 @@ int launch_apf(const ApfArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Receding-horizon replanning (diffusion_model_dynamic.py:495-624): the elementwise pieces between the score
+// evaluations of one replan.  What changes from replan to replan (how many waypoints have been executed, the current
+// waypoint, the pursuer's position) lives in a small device record, so the captured graph of one replan never changes.
+// ------------------------------------------------------------------------------------------
+// x = q_sample(repeat(x_clean), t) = sqrt_ac[t] * x_clean + sqrt_1m_ac[t] * noise (diffusion_model_dynamic.py:671-680),
+// then x[:, 0, 2:] = 0, the executed history, and the goal waypoint of the clean plan (:540-546)
+__global__ __launch_bounds__(256) void replan_init_kernel(float* __restrict__ x, const float* __restrict__ x_clean,
+                                                           const float* __restrict__ noise, float sa, float s1a,
+                                                           const float* __restrict__ hist, const ReplanState* __restrict__ st,
+                                                           int B, int H, int S) {
+  const int n_hist = st->n_hist;
+  const long n = (long)B * H * S;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int si = (int)(idx % S); const int h = (int)((idx / S) % H);
+    float v = add(mul(sa, x_clean[h * S + si]), mul(s1a, noise[idx]));
+    if (h == 0 && si >= 2) v = 0.f;
+    if (h < n_hist) v = hist[h * S + si];
+    if (h == H - 1) v = x_clean[h * S + si];
+    x[idx] = v;
+  }
+}
+// after every DDIM step: apply_hard_conditioning, then the executed history, the goal of the clean plan, x[:, 0, 2:] = 0
+// (diffusion_model_dynamic.py:563-568); one thread per (trajectory, state component), the pinned waypoints in order
+__global__ __launch_bounds__(256) void replan_pin_kernel(float* __restrict__ x, HardConds hc, const float* __restrict__ hist,
+                                                          const float* __restrict__ x_clean, const ReplanState* __restrict__ st,
+                                                          int B, int H, int S) {
+  const int n_hist = st->n_hist;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * S) return;
+  const int b = idx / S, si = idx - b * S;
+  float* xb = x + (long)b * H * S;
+  for (int k = 0; k < hc.n; ++k) xb[hc.idx[k] * S + si] = hc.val[((long)k * B + b) * S + si];
+  for (int h = 0; h < n_hist; ++h) xb[h * S + si] = hist[h * S + si];
+  xb[(H - 1) * S + si] = x_clean[(H - 1) * S + si];
+  if (si >= 2) xb[si] = 0.f;
+}
+// sm(): velocity-limited straight-line states between waypoints stepp and stepp + window, written to
+// stepp + 1 .. stepp + window (diffusion_model_dynamic.py:192-214), torch's fp32 evaluation order
+__global__ __launch_bounds__(256) void replan_sm_kernel(float* __restrict__ x, const ReplanState* __restrict__ st, int window,
+                                                         float dt, float max_vel, int B, int H, int S) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const int stepp = st->stepp;
+  if (stepp + window >= H) return;                        // the reference would index past the horizon here
+  float* xb = x + (long)b * H * S;
+  const float* s1 = xb + stepp * S; const float* s2 = xb + (stepp + window) * S;
+  const float dx = sub(s2[0], s1[0]), dy = sub(s2[1], s1[1]);
+  const float dist = sqrtf(add(mul(dx, dx), mul(dy, dy)));
+  const float ux = dist > 1e-6f ? __fdiv_rn(dx, dist) : 0.f, uy = dist > 1e-6f ? __fdiv_rn(dy, dist) : 0.f;
+  const float span = (float)((double)window * (double)dt);          // python: num_steps * dt, then one fp32 division
+  const float vx0 = __fdiv_rn(dx, span), vy0 = __fdiv_rn(dy, span);
+  const bool fast = sqrtf(add(mul(vx0, vx0), mul(vy0, vy0))) > max_vel;
+  const float vx = fast ? mul(ux, max_vel) : vx0, vy = fast ? mul(uy, max_vel) : vy0;
+  for (int j = 1; j <= window; ++j) {
+    const float tt = mul((float)j, dt);
+    float* o = xb + (stepp + j) * S;
+    o[0] = add(s1[0], mul(tt, vx)); o[1] = add(s1[1], mul(tt, vy));
+    o[2] = vx; o[3] = vy;
+  }
+}
+// en[b] = || x[b, stepp, :2] - pursuer || < thr   (diffusion_model_dynamic.py:414-420: which trajectories get the
+// pursuer pass); x0[:, -1] = x[:, -1] afterwards is replan_goal_kernel
+__global__ __launch_bounds__(256) void replan_near_kernel(const float* __restrict__ x, const ReplanState* __restrict__ st,
+                                                           float thr, int* __restrict__ en, int B, int H, int S) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float* q = x + ((long)b * H + st->stepp) * S;
+  const float dx = sub(q[0], st->pursuer[0]), dy = sub(q[1], st->pursuer[1]);
+  en[b] = sqrtf(add(mul(dx, dx), mul(dy, dy))) < thr;
+}
+__global__ __launch_bounds__(256) void replan_goal_kernel(float* __restrict__ x0, const float* __restrict__ x, int B, int H, int S) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * S) return;
+  const int b = idx / S, si = idx - b * S;
+  x0[((long)b * H + H - 1) * S + si] = x[((long)b * H + H - 1) * S + si];
+}
+// compute_trajectory_costs (cost.py:56-88) over the B per-trajectory scalars: min-max normalisation over the
+// collision-free ones, total = w_s * smooth + w_l * length, first minimum; the winner is gathered with x[0, 2:] = 0
+// (diffusion_model_dynamic.py:607).  One block.  result: {n_free, rank of the winner among the free ones, its row, 0}
+__global__ __launch_bounds__(1024) void replan_select_kernel(const float* __restrict__ traj, const int* __restrict__ mask,
+                                                              const float* __restrict__ plen, const float* __restrict__ smooth,
+                                                              float w_s, float w_l, float* __restrict__ best,
+                                                              int* __restrict__ result, int B, int H, int S) {
+  __shared__ float r_min[2][16], r_max[2][16];
+  __shared__ float r_tot[16]; __shared__ int r_idx[16], r_cnt[16];
+  __shared__ float s_lo[2], s_hi[2]; __shared__ int s_best, s_free;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float lo0 = INFINITY, hi0 = -INFINITY, lo1 = INFINITY, hi1 = -INFINITY; int cnt = 0;
+  for (int b = tid; b < B; b += 1024)
+    if (!mask[b]) { lo0 = fminf(lo0, plen[b]); hi0 = fmaxf(hi0, plen[b]); lo1 = fminf(lo1, smooth[b]); hi1 = fmaxf(hi1, smooth[b]); ++cnt; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    lo0 = fminf(lo0, __shfl_xor(lo0, m)); hi0 = fmaxf(hi0, __shfl_xor(hi0, m));
+    lo1 = fminf(lo1, __shfl_xor(lo1, m)); hi1 = fmaxf(hi1, __shfl_xor(hi1, m)); cnt += __shfl_xor(cnt, m);
+  }
+  if (lane == 0) { r_min[0][wave] = lo0; r_max[0][wave] = hi0; r_min[1][wave] = lo1; r_max[1][wave] = hi1; r_cnt[wave] = cnt; }
+  __syncthreads();
+  if (tid == 0) {
+    float a0 = INFINITY, b0 = -INFINITY, a1 = INFINITY, b1 = -INFINITY; int c = 0;
+    for (int w = 0; w < 16; ++w) { a0 = fminf(a0, r_min[0][w]); b0 = fmaxf(b0, r_max[0][w]); a1 = fminf(a1, r_min[1][w]); b1 = fmaxf(b1, r_max[1][w]); c += r_cnt[w]; }
+    s_lo[0] = a0; s_hi[0] = b0; s_lo[1] = a1; s_hi[1] = b1; s_free = c;
+  }
+  __syncthreads();
+  const float pl_lo = s_lo[0], pl_rng = sub(s_hi[0], s_lo[0]), sm_lo = s_lo[1], sm_rng = sub(s_hi[1], s_lo[1]);
+  float bt = INFINITY; int bi = 0x7fffffff;
+  for (int b = tid; b < B; b += 1024) {
+    if (mask[b]) continue;
+    const float pl = __fdiv_rn(sub(plen[b], pl_lo), pl_rng), sm = __fdiv_rn(sub(smooth[b], sm_lo), sm_rng);
+    const float tot = add(mul(w_s, sm), mul(w_l, pl));
+    // a NaN total (0 / 0 when every free trajectory ties) ranks first, as in torch.argmin
+    const bool better = (tot != tot) ? !(bt != bt) || b < bi : (!(bt != bt) && (tot < bt || (tot == bt && b < bi)));
+    if (bi == 0x7fffffff || better) { bt = tot; bi = b; }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float ot = __shfl_xor(bt, m); const int oi = __shfl_xor(bi, m);
+    if (oi == 0x7fffffff) continue;
+    const bool better = (ot != ot) ? (!(bt != bt) || oi < bi) : (!(bt != bt) && (ot < bt || (ot == bt && oi < bi)));
+    if (bi == 0x7fffffff || better) { bt = ot; bi = oi; }
+  }
+  if (lane == 0) { r_tot[wave] = bt; r_idx[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    float t = INFINITY; int i = 0x7fffffff;
+    for (int w = 0; w < 16; ++w) {
+      const float ot = r_tot[w]; const int oi = r_idx[w];
+      if (oi == 0x7fffffff) continue;
+      const bool better = (ot != ot) ? (!(t != t) || oi < i) : (!(t != t) && (ot < t || (ot == t && oi < i)));
+      if (i == 0x7fffffff || better) { t = ot; i = oi; }
+    }
+    s_best = i;
+  }
+  __syncthreads();
+  const int bb = s_best;
+  if (bb == 0x7fffffff) { if (tid == 0) { result[0] = 0; result[1] = -1; result[2] = -1; } return; }
+  int rank = 0;
+  for (int b = tid; b < bb; b += 1024) rank += !mask[b];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) rank += __shfl_xor(rank, m);
+  if (lane == 0) r_cnt[wave] = rank;
+  __syncthreads();
+  if (tid == 0) { int r = 0; for (int w = 0; w < 16; ++w) r += r_cnt[w]; result[0] = s_free; result[1] = r; result[2] = bb; }
+  for (int e = tid; e < H * S; e += 1024) {
+    float v = traj[(long)bb * H * S + e];
+    if (e < S && e >= 2) v = 0.f;
+    best[e] = v;
+  }
+}
+
+int launch_replan_init(float* x, const float* x_clean, const float* noise, float sa, float s1a, const float* hist,
+                       const ReplanState* st, int B, int H, int S, hipStream_t s) {
+  hipLaunchKernelGGL(replan_init_kernel, dim3(ew_grid((long)B * H * S)), dim3(256), 0, s, x, x_clean, noise, sa, s1a, hist, st, B, H, S);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_replan_pin(float* x, HardConds hc, const float* hist, const float* x_clean, const ReplanState* st, int B, int H,
+                      int S, hipStream_t s) {
+  hipLaunchKernelGGL(replan_pin_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, x, hc, hist, x_clean, st, B, H, S);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_replan_sm(float* x, const ReplanState* st, int window, float dt, float max_vel, int B, int H, int S, hipStream_t s) {
+  RAMP_REQUIRE(S >= 4 && window >= 1, "sm needs (x, y, vx, vy) states");
+  hipLaunchKernelGGL(replan_sm_kernel, dim3((B + 255) / 256), dim3(256), 0, s, x, st, window, dt, max_vel, B, H, S);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_replan_near(const float* x, const ReplanState* st, float thr, int* en, int B, int H, int S, hipStream_t s) {
+  hipLaunchKernelGGL(replan_near_kernel, dim3((B + 255) / 256), dim3(256), 0, s, x, st, thr, en, B, H, S);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_replan_goal(float* x0, const float* x, int B, int H, int S, hipStream_t s) {
+  hipLaunchKernelGGL(replan_goal_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, x0, x, B, H, S);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_replan_select(const float* traj, const int* mask, const float* plen, const float* smooth, float w_s, float w_l,
+                         float* best, int* result, int B, int H, int S, hipStream_t s) {
+  hipLaunchKernelGGL(replan_select_kernel, dim3(1), dim3(1024), 0, s, traj, mask, plen, smooth, w_s, w_l, best, result, B, H, S);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Dynamic-planner APF (APFhelper_dynamic.py:107-142), one block per trajectory, points in float64 like the
 // reference's numpy clouds.  window >= 0: static pass, pushes only waypoints [ci - w, min(H-1, ci + w)) around the
 // waypoint ci nearest to the cloud; window < 0: pursuer pass over waypoints [0, affected) with the 0.9 / 0.1

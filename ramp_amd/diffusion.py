@@ -178,7 +178,7 @@ class _GaussianDiffusionBase(nn.Module):
         return idx, val
 
     def _launch(self, B, noise, hard_conds, obstacle_pts, ddim: bool, steps, apply_apf, noise_scale, apf_cfg,
-                return_chain: bool):
+                return_chain: bool, ddim_K: Optional[int] = None):
         """Fill ramp_sample_params from the schedule buffers exactly as the reference's extract() would."""
         m = self.model
         dev = self._device()
@@ -215,7 +215,7 @@ class _GaussianDiffusionBase(nn.Module):
             p.noise_scale = arr_f(noise_scale)
         else:
             ac = buf['alphas_cumprod']
-            K = self.ddim_num_inference_steps
+            K = ddim_K or self.ddim_num_inference_steps
             sa, s1, sp, dc = [], [], [], []
             for t in steps:
                 prev = t - self.n_diffusion_steps // K
@@ -580,15 +580,172 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
                 x[:, h] = st
         return x
 
+    # ------------------------------------------------------------------ receding-horizon planner, one graph per replan
+    def _ddim_arrays(self, steps, K):
+        ac = self.alphas_cumprod.detach().cpu()
+        sr, srm, sa, s1, sp, dc = [], [], [], [], [], []
+        for t in steps:
+            prev = t - self.n_diffusion_steps // K
+            a_t = ac[t]
+            a_prev = ac[prev] if prev >= 0 else self.final_alpha_cumprod[0]
+            sr.append(self.sqrt_recip_alphas_cumprod[t]); srm.append(self.sqrt_recipm1_alphas_cumprod[t])
+            sa.append(a_t ** 0.5); s1.append((1 - a_t) ** 0.5); sp.append(a_prev ** 0.5); dc.append((1 - a_prev) ** 0.5)
+        return sr, srm, sa, s1, sp, dc
+
     @torch.no_grad()
     def ddim_p_sample_loop(self, shape, hard_conds, context=None, return_chain=False, traj_normalized=None,
                            obstacle_pts=None, t_start_guide=float('inf'), guide=None, n_guide_steps=1,
                            max_iteration=60, **sample_kwargs):
-        """Pursuit-evasion receding-horizon planner (diffusion_model_dynamic.py:495-624): a 10-step DDIM high-level
-        plan, best-trajectory selection, then up to ``max_iteration`` replans of 5 DDIM steps each from a re-noised
-        copy of the current plan with the executed history and the goal inpainted, velocity smoothing, the
-        per-trajectory static / pursuer APF on the last step, and collision / cost selection.  Host control flow as
-        in the reference; every tensor operation on the trajectories runs on the HIP kernels."""
+        """Pursuit-evasion receding-horizon planner (diffusion_model_dynamic.py:495-624), MI355X-shaped: the 10-step
+        high-level plan is ONE ``ramp_sample`` job and every replan ONE ``ramp_replan`` graph replay (q_sample of the
+        current plan, 5 DDIM steps with the executed history / goal pinned, smoothing, static + pursuer APF on the last
+        step, collision mask, costs, selection -- all on the device), with a 16-byte result record and the winning
+        trajectory as the only read-backs.  Host work per replan is what the reference leaves to the environment: the
+        pursuer's dynamics callback (fed x[:, stepp, :2], i.e. the pinned executed state, known before the replan starts),
+        its re-sampled sphere cloud (numpy RNG, same call order as the reference) and the termination test.
+        ``self.replan_log`` (a list, optional) receives every batch handed to a selection, for the parity tests."""
+        from .apf_dynamic import generate_sphere_points
+        device = self._device()
+        B, H, S = shape
+        lib = _lib.load()
+        m = self.model
+        log = getattr(self, 'replan_log', None)
+        env = context['dataset'].env
+        fixed = env.obj_fixed_list[0].fields[0]
+        context['static_obstacle_centers'] = fixed.centers.cpu().numpy()[:4]
+        context['static_obstacle_sizes'] = fixed.sizes.cpu().numpy()[:4]
+        sphere = env.obj_extra_list[0].fields[0]
+        cloud = obstacle_pts.to(device).contiguous()
+        cost_cloud = cloud.reshape(-1, 2).to(torch.float32).contiguous()
+        chain_obs = []
+        chain_start = [hard_conds[0][0].unsqueeze(0)]
+        safe_threshold, distance_threshold_pred = 0.2, 0.4
+        thr_high, thr_low = 0.02, 0.05
+        chain = [] if return_chain else None
+        # STAGE I: high-level plan (10 DDIM steps, hard conditioning after each: one captured job), then the selection
+        x = torch.randn(shape, device=device)
+        ts = [int(i) for i in self.ddim_set_timesteps(self.ddim_num_inference_steps_high)]
+        xb, _ = self._launch(B, x.unsqueeze(0), hard_conds, cloud, True, ts, [0] * len(ts), None, None, False,
+                             ddim_K=self.ddim_num_inference_steps_high)
+        mask = torch.empty(B, dtype=torch.int32, device=device)
+        plen = torch.empty(B, device=device); smooth = torch.empty(B, device=device)
+        best = torch.empty((H, S), device=device)
+        res_dev = torch.zeros(4, dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(lib.ramp_select_best(_lib.ptr(xb), B, H, S, _lib.ptr(cost_cloud), cost_cloud.shape[0], thr_high, 0.1, 0.9,
+                                            _lib.ptr(mask), _lib.ptr(plen), _lib.ptr(smooth), _lib.ptr(best), _lib.ptr(res_dev),
+                                            _lib.current_stream()), "ramp_select_best")
+        n_free, rank, _row, _ = (int(v) for v in res_dev.cpu())
+        if log is not None:
+            log.append(dict(batch=xb.clone(), npts=cost_cloud.shape[0], idx=rank if n_free else -1, free=(mask == 0).clone()))
+        if n_free == 0:
+            raise RuntimeError("no collision-free high-level plan (the reference dereferences None here)")
+        x_plan = xb[_row].clone()       # (the selection kernel zeroes x[0, 2:] as the replans need; the high-level winner stays as is)
+        high_plan = x_plan.clone()
+        hist_dev = torch.zeros((H, S), device=device)
+        hist_dev[0] = x_plan[0]
+        executed_history = [x_plan[0].clone().unsqueeze(0)]
+        best_host = x_plan.cpu().numpy()
+        # STAGE II
+        low = ts[-self.ddim_num_inference_steps_low:]
+        sr, srm, sa, s1, sp, dc = self._ddim_arrays(low, self.ddim_num_inference_steps_high)
+        keep = []
+
+        def arr_f(vals):
+            a = _f32(vals); keep.append(a); return C.cast(a, _lib.c_f32p)
+
+        def arr_i(vals):
+            a = _i32(vals); keep.append(a); return C.cast(a, _lib.c_i32p)
+
+        c = self.apf_dynamic
+        p = _lib.RampReplanParams()
+        p.B, p.n_rp, p.n_steps, p.clip_denoised, p.w = B, 2, len(low), int(bool(self.clip_denoised)), float(self.cfg_weight)
+        p.t = arr_i(low)
+        p.sqrt_recip, p.sqrt_recipm1 = arr_f(sr), arr_f(srm)
+        p.sqrt_a_t, p.sqrt_1m_a_t, p.sqrt_a_prev, p.dir_coef = arr_f(sa), arr_f(s1), arr_f(sp), arr_f(dc)
+        p.q_sqrt_a = float(self.sqrt_alphas_cumprod[low[0]]); p.q_sqrt_1m_a = float(self.sqrt_one_minus_alphas_cumprod[low[0]])
+        idx, hval = self._hard_arrays(hard_conds, B)
+        p.n_hard = len(idx); p.hard_idx_host = arr_i(idx) if idx else None; p.hard_val = _lib.ptr(hval) if idx else None
+        p.sm_window_last, p.sm_window_final, p.sm_dt, p.sm_max_vel = 3, 2, 0.1, 0.8
+        p.thr_static, p.thr_pred = float(c['threshold_static']), float(c['threshold_pred'])
+        p.strength_static, p.strength_pred, p.window_static = float(c['strength_static']), float(c['strength_pred']), int(c['window_static'])
+        p.n_dyn = int(c['points_per_obstacle'])
+        p.cost_cloud, p.n_cost, p.n_extra = _lib.ptr(cost_cloud), cost_cloud.shape[0], 64
+        p.cost_thr, p.w_smooth, p.w_len = thr_low, 0.1, 0.9
+        p.use_graph = int(self.use_graph)
+        x_clean = x_plan.contiguous()
+        stepp = 0
+        batch = torch.empty((B, H, S), device=device) if log is not None else None
+        for k in range(max_iteration):
+            noise = torch.randn_like(xb)                           # q_sample's randn_like(x_start)
+            field = self._obstacle_field(context)
+            p.static_pts, p.n_static = _lib.ptr(field._static_dev), field._static_dev.shape[0]
+            # the environment step of the reference's last DDIM step (diffusion_model_dynamic.py:396-411): the pursuer sees
+            # x[:, stepp, :2], which is the pinned executed state of every candidate
+            field.update_dynamic(k, executed_history[-1][:, :2].expand(B, 2).clone(), replan_guide=True)
+            centre = np.asarray(field.dynamic_center, np.float64)
+            dyn = np.ascontiguousarray(field.dynamic_points, np.float64)
+            assert dyn.shape == (p.n_dyn, 2)
+            near = bool(np.linalg.norm(best_host[stepp, :2] - sphere.centers[0].cpu().numpy()) < distance_threshold_pred)
+            extra = None
+            if near:
+                extra = np.ascontiguousarray(generate_sphere_points(sphere.centers[0].cpu().numpy(),
+                                                                    sphere.radii[0].cpu().numpy(), 64), np.float32)
+            st = _lib.RampReplanState()
+            st.noise, st.x_clean, st.history = _lib.ptr(noise), _lib.ptr(x_clean), _lib.ptr(hist_dev)
+            st.n_hist, st.stepp = len(executed_history), stepp
+            st.dyn_pts_host = dyn.ctypes.data
+            st.pursuer[0], st.pursuer[1] = float(np.float32(centre[0])), float(np.float32(centre[1]))
+            st.near = int(near)
+            st.extra_pts_host = extra.ctypes.data if near else None
+            res = _lib.RampReplanResult()
+            with torch.cuda.device(device):
+                _lib.check(lib.ramp_replan(m.ctx(), C.byref(p), C.byref(st), _lib.ptr(best), _lib.ptr(batch),
+                                           _lib.ptr(mask) if log is not None else None, C.byref(res), _lib.current_stream()),
+                           "ramp_replan")
+            if res.fell_back:
+                warnings.warn(f"fp16x3 range guard tripped at GEMM call site {res.fell_back - 1}: replan repeated in bf16x6")
+            if log is not None:
+                log.append(dict(batch=batch.clone(), npts=cost_cloud.shape[0] + (64 if near else 0),
+                                idx=res.best_rank if res.n_free else -1, free=(mask == 0).clone()))
+            if res.n_free == 0:
+                # no candidate survived: the reference re-plans from scratch until one does (:591-605), eager path
+                from .cost import compute_trajectory_costs
+                xs = None
+                while xs is None:
+                    nb = min(30, B)
+                    new_hc = {kk: v[:nb].clone() for kk, v in hard_conds.items()}
+                    xs = self.ddim_replan_scratch((nb, H, S), new_hc, context, traj_normalized, forward_t=k,
+                                                  obstacle_pts=cloud, use_apf=False, executed_history=executed_history)
+                    xs[:, stepp + 1:stepp + 3] = self.sm(xs[:, stepp], xs[:, stepp + 2], num_steps=2)
+                    xs, _, _, _, _ = compute_trajectory_costs(xs, cost_cloud, collision_threshold=thr_low)
+                xs = xs.clone(); xs[0, 2:] = 0.0
+                best.copy_(xs)
+            x_cur = best.clone()
+            best_host = x_cur.cpu().numpy()
+            x_clean = x_cur
+            executed_history.append(x_cur[stepp + 1].clone().unsqueeze(0))
+            hist_dev[stepp + 1] = x_cur[stepp + 1]
+            updated_start_state = x_cur[stepp].clone()
+            stepp += 1
+            if return_chain:
+                if stepp == 1:
+                    chain.append(high_plan.unsqueeze(0).clone())
+                chain.append(x_cur.unsqueeze(0).clone())
+            chain_obs.append(sphere.centers.clone())
+            chain_start.append(updated_start_state.unsqueeze(0).clone())
+            if float(np.linalg.norm(best_host[stepp - 1, :2] - best_host[-1, :2])) < safe_threshold:
+                break
+        if return_chain:
+            chain = torch.stack(chain, dim=1)
+        return x_cur, chain, chain_obs, chain_start
+
+    @torch.no_grad()
+    def ddim_p_sample_loop_eager(self, shape, hard_conds, context=None, return_chain=False, traj_normalized=None,
+                                 obstacle_pts=None, t_start_guide=float('inf'), guide=None, n_guide_steps=1,
+                                 max_iteration=60, **sample_kwargs):
+        """The same planner as a host loop over the step-at-a-time entry points (one launch sequence and several syncs
+        per DDIM step): kept as the readable restatement the graph path is tested against."""
         from .apf_dynamic import generate_sphere_points
         from .cost import compute_trajectory_costs
         device = self._device()

@@ -343,37 +343,49 @@ def test_warmup_consumes_one_randn_and_compose_loop_runs():
     assert torch.equal(out[-1][:, 0], hc[0].cuda().expand(5, -1)) and torch.equal(out[-1][:, 47], hc[47].cuda().expand(5, -1))
 
 
-def test_dynamic_replanning_loop_against_reference_run():
+@pytest.mark.parametrize("impl", ["graph", "eager-loop", "graph-fp16x3-eager-launch"])
+def test_dynamic_replanning_loop_against_reference_run(impl):
     """The receding-horizon planner (diffusion_model_dynamic.py:495-624) against a run of the reference planner with
     the same fake env, numpy seed and torch noise: every batch handed to the cost selection, every selected index,
-    every evader state handed to the pursuer dynamics."""
+    every collision mask, every evader state handed to the pursuer dynamics.  'graph': one ramp_sample job for the
+    high-level plan + one captured ramp_replan graph per replan (device-side smoothing / APF / costs / selection);
+    'eager-loop': the step-at-a-time host loop over the same kernels; the third runs ramp_replan without graph capture."""
     import ramp_amd.cost as cost_mod
     from ramp_amd.models import DynamicGaussianDiffusionModel
     from util import NoiseInjector, StopReplan, make_fake_pursuit_env
     g = np.load(f"{GOLDEN}/replan_chain.npz")
     K = int(g["n_iter"]); B, H, S = g["noise"].shape[1:]
     u = build_unet(4, 48, False, max_rows=16)
-    dm = DynamicGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True).eval().to("cuda")
+    dm = DynamicGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True,
+                                       use_graph=(impl == "graph")).eval().to("cuda")
     log_env, log_cost = [], []
     dataset, sphere = make_fake_pursuit_env(stop_at=K, log=log_env)
-    orig = cost_mod.compute_trajectory_costs
-
-    def logged(trajs, pts, **kw):
-        out = orig(trajs, pts, **kw)
-        log_cost.append((trajs.cpu().numpy().copy(), pts.reshape(-1, 2).shape[0], -1 if out[4] is None else int(out[4]),
-                         out[3].cpu().numpy().copy()))
-        return out
-
-    cost_mod.compute_trajectory_costs = logged
     hard = {0: dev(g["hard0"]).repeat(B, 1), H - 1: dev(g["hardN"]).repeat(B, 1)}
     np.random.seed(23)
-    try:
+    if impl == "eager-loop":
+        orig = cost_mod.compute_trajectory_costs
+
+        def logged(trajs, pts, **kw):
+            out = orig(trajs, pts, **kw)
+            log_cost.append((trajs.cpu().numpy().copy(), pts.reshape(-1, 2).shape[0], -1 if out[4] is None else int(out[4]),
+                             out[3].cpu().numpy().copy()))
+            return out
+
+        cost_mod.compute_trajectory_costs = logged
+        try:
+            with NoiseInjector(list(g["noise"])):
+                with pytest.raises(StopReplan):
+                    dm.ddim_p_sample_loop_eager((B, H, S), hard, context={'dataset': dataset}, return_chain=True,
+                                                obstacle_pts=dev(g["cloud"]))
+        finally:
+            cost_mod.compute_trajectory_costs = orig
+    else:
+        dm.replan_log = []
         with NoiseInjector(list(g["noise"])):
             with pytest.raises(StopReplan):
                 dm.ddim_p_sample_loop((B, H, S), hard, context={'dataset': dataset}, return_chain=True,
                                       obstacle_pts=dev(g["cloud"]))
-    finally:
-        cost_mod.compute_trajectory_costs = orig
+        log_cost = [(e["batch"].cpu().numpy(), e["npts"], e["idx"], e["free"].cpu().numpy()) for e in dm.replan_log]
     assert len(log_cost) == int(g["n_cost"]) and len(log_env) == int(g["n_env"])
     errs = []
     for j, (tr, npts, idx, free) in enumerate(log_cost):

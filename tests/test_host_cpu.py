@@ -42,14 +42,26 @@ def test_no_cpu_fallback():
 
 
 def test_struct_layout_matches_header():
-    """ctypes mirrors of the C structs have the sizes the C compiler gives them."""
+    """ctypes mirrors of the C structs have the sizes AND field offsets the C compiler gives them."""
     import subprocess, tempfile
-    src = '#include "ramp_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n", sizeof(ramp_config), sizeof(ramp_apf_params), sizeof(ramp_sample_params));return 0;}\n'
+    pairs = [("ramp_config", _lib.RampConfig), ("ramp_apf_params", _lib.RampApfParams), ("ramp_sample_params", _lib.RampSampleParams),
+             ("ramp_replan_params", _lib.RampReplanParams), ("ramp_replan_state", _lib.RampReplanState),
+             ("ramp_replan_result", _lib.RampReplanResult)]
+    body = []
+    for cname, cls in pairs:
+        body.append(f'printf("%zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            body.append(f'printf(" %zu", offsetof({cname}, {fname}));')
+        body.append('printf("\\n");')
+    src = '#include "ramp_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){' + "".join(body) + 'return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
-        out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
-    assert [int(v) for v in out] == [C.sizeof(_lib.RampConfig), C.sizeof(_lib.RampApfParams), C.sizeof(_lib.RampSampleParams)]
+        lines = subprocess.check_output([os.path.join(d, "s")]).decode().strip().splitlines()
+    for (cname, cls), line in zip(pairs, lines):
+        got = [int(v) for v in line.split()]
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert got == want, (cname, got, want)
 
 
 @pytest.mark.parametrize("S,o3,n", [(4, False, 684), (6, True, 608)])
