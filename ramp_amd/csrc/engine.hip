@@ -179,7 +179,7 @@ struct ramp_ctx {
   int phase = 0, site = 0;
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
-  bool score_calibrated = false; int score_parity = 0; int score_last_mode = 0;
+  bool score_calibrated = false; bool score_calibrated_bwd = false; int score_parity = 0; int score_last_mode = 0;
   float* obs = nullptr; float *obs_in = nullptr, *obs_out = nullptr;
   int* range_flag = nullptr;
   // debug
@@ -1127,7 +1127,8 @@ int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, 
                        reinterpret_cast<unsigned*>(c->obs_out), ramp_ctx::MAX_SITES);
   };
   int rc = 0;
-  if (c->score_calibrated) {
+  // (a forward-only evaluation leaves the call sites of the input-gradient pass without maxima)
+  if (c->score_calibrated && (c->score_calibrated_bwd || eps_out == nullptr)) {
     hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<unsigned*>(c->range_flag), 1);
     tables(c->score_parity);
     RAMP_HIP_CHECK(hipGetLastError());
@@ -1139,7 +1140,7 @@ int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, 
     RAMP_HIP_CHECK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     RAMP_HIP_CHECK(hipStreamSynchronize(s));
     c->r_calibrated = false;
-    if (!flag) { c->score_parity ^= 1; c->score_last_mode = 2; return 0; }
+    if (!flag) { c->score_parity ^= 1; c->score_last_mode = 2; c->score_calibrated_bwd = eps_out != nullptr; return 0; }
   }
   tables(c->score_parity);
   RAMP_HIP_CHECK(hipGetLastError());
@@ -1147,7 +1148,7 @@ int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, 
   rc = score_all(c, x, B, n_rp, t, f_out, eps_out, s);
   c->phase = 0;
   CK(rc);
-  c->score_calibrated = true; c->score_parity ^= 1; c->score_last_mode = 1;
+  c->score_calibrated = true; c->score_calibrated_bwd = eps_out != nullptr; c->score_parity ^= 1; c->score_last_mode = 1;
   c->r_calibrated = false;
   return 0;
 }
