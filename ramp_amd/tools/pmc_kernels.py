@@ -30,8 +30,8 @@ for k, cs in agg.items():
                 e[c + "_frac_of_wave"] = e[c] / e["SQ_WAVE_CYCLES"]
     out[k] = e
 out["_note"] = ("one score evaluation (forward + dX backward) of the headline workload under rocprofv3 --pmc; the collection "
-                "runs hold the shader clock near 1.4 GHz, so times are longer than in the timed runs; the evaluation is a "
-                "single ramp_score call, i.e. the bf16x6 kernels (NP = 3)")
+                "runs hold the shader clock near 1.4 GHz, so times are longer than in the timed runs; the evaluation is the last "
+                "(third) ramp_score call of score_pmc.py, i.e. the fp16x3 kernels bench.py times (NP = 2)")
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k, e in sorted(out.items(), key=lambda kv: -kv[1].get("time_us_under_pmc", 0) if isinstance(kv[1], dict) else 0)[:10]:
     if isinstance(e, dict):

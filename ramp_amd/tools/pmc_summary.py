@@ -12,7 +12,7 @@ import sys
 
 def klass(name):
     if "gemm_x6" in name or "gemm_kernel" in name:
-        return "gemm_f32_mfma"
+        return "gemm"
     if "attn2" in name:
         return "attention"
     if "gn_" in name or "ln_" in name:
@@ -45,18 +45,23 @@ def main():
             e = res.setdefault(k, {"launches": {}, "read_bytes": 0.0, "write_bytes": 0.0})
             e["launches"][counter] = e["launches"].get(counter, 0) + 1
             e["read_bytes" if counter == "FETCH_SIZE" else "write_bytes"] += v * 1024.0 * scale
-    for k, e in res.items():
+    for k, e in list(res.items()):
         n = max(e["launches"].values())
         assert len(set(e["launches"].values())) == 1, e["launches"]
         e["launches"] = n
         e["hbm_bytes"] = e["read_bytes"] + e["write_bytes"]
         e["hbm_bytes_per_launch"] = e["hbm_bytes"] / n
-    res["_note"] = ("one score evaluation (forward + dX backward) of the headline workload, B=4096 trajectories = 8192 "
-                    "network rows; read bytes = 2 x FETCH_SIZE KiB (gfx950 correction), write bytes = WRITE_SIZE KiB; "
-                    "counters collected in separate --pmc passes")
+    res["_note"] = ("one fp16x3 score evaluation (forward + dX backward; the kernels bench.py times) of the headline workload, "
+                    "B=4096 trajectories = 8192 network rows; read bytes = 2 x FETCH_SIZE KiB (gfx950 correction), write bytes "
+                    "= WRITE_SIZE KiB; counters collected in separate --pmc passes")
+    res["collected"] = sys.argv[4] if len(sys.argv) > 4 else "separate rocprofv3 --pmc passes"
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
-    print(json.dumps({k: (v if isinstance(v, str) else {kk: round(vv) for kk, vv in v.items()}) for k, v in res.items()}, indent=1))
+    tot = sum(v["hbm_bytes"] for v in res.values() if isinstance(v, dict))
+    res["total_hbm_bytes_per_evaluation"] = tot
+    print(json.dumps({k: (v if not isinstance(v, dict) else {kk: round(vv) for kk, vv in v.items()}) for k, v in res.items()}, indent=1))
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
 
 
 if __name__ == "__main__":
