@@ -48,6 +48,7 @@ struct GemmArgs {
   int site_id = 0;
   int geglu_group = 64;                                     // EPI_GEGLU_FWD weight tiling: [group a-rows | group g-rows]
   const float* Amul = nullptr; int lda_mul = 0; int a_period = 0;   // optional: A_eff[m][k] = A[m][k % a_period] * Amul[m][k]
+  int ablate = 0;                                           // diagnostic kernel variant (ramp_bench_gemm only)
   int tile_pref = 0;                                        // tuning override (micro-benchmarks): 0 auto, 1 force the 128 x 128 tile, 3 force 3 blocks / CU
   int wx_packed = 0;                                        // 1: Wx is fragment-packed [taps*N/32][K/16][3][64][8] bf16 (launch_pack_x6); 2: [..][2][64][8] fp16 (launch_pack_h3)
   const float* bias = nullptr;                              // [N]

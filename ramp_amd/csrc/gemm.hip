@@ -761,7 +761,21 @@ template <int EPI, bool GEN, bool AMUL = false, int NP = 3, bool REC = false, bo
 __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #define X6P_THREE 0
+#define X6P_ABL 0
 #include "gemm_x6p_body.inc"
+#undef X6P_ABL
+#undef X6P_THREE
+}
+// diagnostic twin of the plain fp16x3 kernel with parts of the loop switched off (ramp_bench_gemm, flags bits 8..11):
+// where a tile's time goes.  Results are meaningless; never launched by the product.
+template <int ABLV, bool WIDE>
+__global__ __launch_bounds__(256)
+void gemm_x6p_abl_kernel(GemmArgs a, int tiles_n, int n_tiles) {
+  constexpr int EPI = EPI_LINEAR; constexpr bool GEN = false, AMUL = false, REC = true; constexpr int NP = 2;
+#define X6P_THREE 0
+#define X6P_ABL ABLV
+#include "gemm_x6p_body.inc"
+#undef X6P_ABL
 #undef X6P_THREE
 }
 // ... or three (fp16x3: 168 VGPRs, 51 KB of LDS): a third resident block covers the epilogue-store stalls of the others;
@@ -771,7 +785,9 @@ template <int EPI, bool GEN, bool AMUL = false, int NP = 2, bool REC = true, boo
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #define X6P_THREE 1
+#define X6P_ABL 0
 #include "gemm_x6p_body.inc"
+#undef X6P_ABL
 #undef X6P_THREE
 }
 
@@ -833,7 +849,15 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
   const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
 #define X6P_LAUNCH(...) hipLaunchKernelGGL((gemm_x6p_kernel<__VA_ARGS__>), dim3(nb), dim3(256), X6P_LDS3, s, a, tiles_n, n_tiles)
   const bool rec = a.a_absmax_out != nullptr;
-  if (wide) {
+  if (a.ablate && a.wx_packed == 2) {
+    if constexpr (!GEN && EPI == EPI_LINEAR) {
+      const size_t lds = wide ? X6P_LDS2W : X6P_LDS2R;
+#define ABL_CASE(V) case V: if (wide) hipLaunchKernelGGL((gemm_x6p_abl_kernel<V, true>), dim3(nb), dim3(256), lds, s, a, tiles_n, n_tiles); \
+                            else hipLaunchKernelGGL((gemm_x6p_abl_kernel<V, false>), dim3(nb), dim3(256), lds, s, a, tiles_n, n_tiles); break;
+      switch (a.ablate) { ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(15) default: RAMP_REQUIRE(false, "ablation variant not built"); }
+#undef ABL_CASE
+    }
+  } else if (wide) {
     if constexpr (!GEN) {
       if (a.Amul) {
         RAMP_REQUIRE(EPI == EPI_LINEAR && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
@@ -913,6 +937,10 @@ int init_gemm_attributes() {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2R));
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2W));
+#define ABL_ATTR(V) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_abl_kernel<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2W)); \
+                    RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_abl_kernel<V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2R));
+  ABL_ATTR(1) ABL_ATTR(2) ABL_ATTR(3) ABL_ATTR(4) ABL_ATTR(7) ABL_ATTR(8) ABL_ATTR(15)
+#undef ABL_ATTR
   if (int e = set_attr_x6<EPI_LINEAR, false>()) return e;
   if (int e = set_attr_x6<EPI_LINEAR, true>()) return e;
   if (int e = set_attr_x6<EPI_GEGLU_FWD, false>()) return e;
