@@ -152,7 +152,7 @@ def check(rc: int, what: str = "") -> None:
         raise RampHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
-GEMM_MODES = {"fp32": 0, "bf16x6": 1, "bf16x6-lds": 2, "fp16x3": 3}       # ramp_op_gemm_mode
+GEMM_MODES = {"fp32": 0, "bf16x6": 1, "bf16x6-lds": 2, "fp16x3": 3, "fp16x3-dma": 4}       # ramp_op_gemm_mode
 
 
 def op_gemm(A, W, bias, resid, out, M, N, K, taps, shift0, step, L, mode="fp32", a_absmax_prev=0.0):

@@ -48,6 +48,7 @@ struct GemmArgs {
   int site_id = 0;
   int geglu_group = 64;                                     // EPI_GEGLU_FWD weight tiling: [group a-rows | group g-rows]
   const float* Amul = nullptr; int lda_mul = 0; int a_period = 0;   // optional: A_eff[m][k] = A[m][k % a_period] * Amul[m][k]
+  const unsigned short* Ap = nullptr; long ap_plane = 0;    // optional: A already split into two scaled fp16 planes, row-major [2][M][K] (gemm_q.hip)
   int ablate = 0;                                           // diagnostic kernel variant (ramp_bench_gemm only)
   int tile_pref = 0;                                        // tuning override (micro-benchmarks): 0 auto, 1 force the 128 x 128 tile, 3 force 3 blocks / CU
   int wx_packed = 0;                                        // 1: Wx is fragment-packed [taps*N/32][K/16][3][64][8] bf16 (launch_pack_x6); 2: [..][2][64][8] fp16 (launch_pack_h3)
@@ -78,6 +79,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_split3(const float* in, unsigned short* out, long n, hipStream_t s);   // fp32 -> 3 bf16 planes
 int launch_pack_x6(const float* W, unsigned short* out, long rows, int K, hipStream_t s);   // fp32 [rows][K] -> MFMA-fragment-packed planes
 int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, float scale, hipStream_t s);   // same, two fp16 planes
+int launch_split_planes(const float* A, int lda, unsigned short* out, long plane, int M, int K, const float* absmax_in,
+                        float* absmax_out, int* range_flag, int site_id, hipStream_t s);   // fp32 -> the Ap format
+bool gemm_h3q_applicable(const GemmArgs& a);
+int launch_gemm_h3q(const GemmArgs& a, hipStream_t s);   // fp16x3, both operands through an LDS-DMA ring (gemm_q.hip)
+int init_gemm_q_attributes();
 int init_gemm_attributes();        // raise the dynamic-LDS limit of every GEMM instantiation (once)
 int init_attention_attributes();   // same for the attention kernels
 

@@ -1016,6 +1016,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
     for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C, u.C)); CK(reg(u.w_b, 4ul * u.C * u.C, u.C)); }
   }
   RAMP_HIP_CHECK(hipDeviceSynchronize());
+  CK(init_gemm_q_attributes());
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
   CK(init_attention_attributes());
   c->finalized = true;
@@ -1575,15 +1576,15 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
                       int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step, int32_t L, int32_t mode,
                       float a_absmax_prev, float* a_absmax_out_host, int32_t* range_flag_out_host, void* stream) {
   RAMP_REQUIRE(A && W && C, "null argument");
-  RAMP_REQUIRE(mode >= 0 && mode <= 3, "mode: 0 fp32, 1 bf16x6, 2 bf16x6 (LDS-staged weights), 3 fp16x3");
+  RAMP_REQUIRE(mode >= 0 && mode <= 4, "mode: 0 fp32, 1 bf16x6, 2 bf16x6 (LDS-staged weights), 3 fp16x3, 4 fp16x3 through the LDS-DMA ring");
   hipStream_t s = as_stream(stream);
   GemmArgs a; a.A = A; a.lda = K; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.C = C; a.ldc = N;
   a.M = M; a.N = N; a.K = K; a.taps = taps; a.shift0 = shift0; a.shift_step = shift_step; a.L = L;
   const long n = (long)taps * N * K;
   const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
-  unsigned short* planes = nullptr; float* slots = nullptr;
+  unsigned short* planes = nullptr; float* slots = nullptr; unsigned short* aplanes = nullptr;
   int rc = 0;
-  if (mode == 3 && frag_ok) {
+  if ((mode == 3 || mode == 4) && frag_ok) {
     // the product's static weight scale: max |w| -> [2^10, 2^11)  (ramp_finalize_weights)
     std::vector<float> hw(n);
     RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -1598,6 +1599,12 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
     a.Wx = planes; a.wx_packed = 2; a.w_scale_inv = 1.f / sc;
     a.a_absmax_in = a_absmax_prev > 0.f ? slots : nullptr; a.a_absmax_out = slots + 1;
     a.range_flag = reinterpret_cast<int*>(slots + 2);
+    if (mode == 4 && rc == 0) {
+      RAMP_HIP_CHECK(hipMalloc(&aplanes, (size_t)2 * M * K * sizeof(unsigned short)));
+      rc = launch_split_planes(A, K, aplanes, (long)M * K, M, K, a.a_absmax_in, slots + 1, reinterpret_cast<int*>(slots + 2), 0, s);
+      a.Ap = aplanes; a.ap_plane = (long)M * K;
+      if (!gemm_h3q_applicable(a)) { a.Ap = nullptr; }      // shapes it does not cover run the register-staged kernel
+    }
   } else if (mode == 1 && frag_ok) {
     RAMP_HIP_CHECK(hipMalloc(&planes, 3 * n * sizeof(unsigned short)));
     rc = launch_pack_x6(W, planes, (long)taps * N, K, s);
@@ -1607,7 +1614,7 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
     rc = launch_split3(W, planes, n, s);
     a.Wx = planes; a.wx_plane = n;
   }
-  if (rc == 0) rc = launch_gemm(a, s);
+  if (rc == 0) rc = a.Ap ? launch_gemm_h3q(a, s) : launch_gemm(a, s);
   hipError_t e = hipStreamSynchronize(s);
   if (rc == 0 && e == hipSuccess && slots) {
     float back[4] = {0, 0, 0, 0};
@@ -1620,6 +1627,7 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
     if (range_flag_out_host) *range_flag_out_host = 0;
   }
   if (planes) (void)hipFree(planes);
+  if (aplanes) (void)hipFree(aplanes);
   if (slots) (void)hipFree(slots);
   RAMP_HIP_CHECK(e);
   return rc;
@@ -1635,7 +1643,7 @@ __global__ void fill_uniform_kernel(float* p, long n, unsigned seed, float scale
 }
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 3, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 4, "bad arguments");
   hipStream_t s = as_stream(stream);
   DevArena ar;
   auto fill = [&](float* p, size_t n, unsigned seed, float sc) {
@@ -1660,11 +1668,11 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
   if (geglu) { a.epi = EPI_GEGLU_FWD; a.aux_out = aux; a.ld_aux = N / 2; a.geglu_group = (mode == 1 || mode == 3) ? 32 : 64; }
   if (amul) { a.Amul = mul; a.lda_mul = K; a.a_period = Ka; }
   a.tile_pref = (flags & 16) ? 1 : (flags & 32) ? 3 : 0;
-  a.ablate = (flags >> 8) & 15;
+  a.ablate = (flags >> 8) & 31;
   const long n = (long)taps * N * K;
   const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
   unsigned short* planes = nullptr;
-  if (mode == 3 && frag_ok) {
+  if ((mode == 3 || mode == 4) && frag_ok) {
     planes = reinterpret_cast<unsigned short*>(ar.alloc((size_t)n + 4));
     RAMP_REQUIRE(planes, "hipMalloc failed");
     const float sc = std::ldexp(1.f, 10) * std::sqrt((float)K * taps);      // max |w| ~ 1 / sqrt(K taps)
@@ -1672,6 +1680,13 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     CK(launch_pack_h3(W, planes, (long)taps * N, K, scp, s));
     a.Wx = planes; a.wx_packed = 2; a.w_scale_inv = 1.f / scp;
     a.a_absmax_in = slots; a.a_absmax_out = slots + 1; a.range_flag = reinterpret_cast<int*>(slots + 2);
+    if (mode == 4) {                                   // operands pre-split once; the timed launches are the LDS-DMA GEMM alone
+      unsigned short* ap = reinterpret_cast<unsigned short*>(ar.alloc((size_t)M * K + 4));
+      RAMP_REQUIRE(ap, "hipMalloc failed");
+      CK(launch_split_planes(A, Ka, ap, (long)M * K, M, K, slots, slots + 1, reinterpret_cast<int*>(slots + 2), 0, s));
+      a.Ap = ap; a.ap_plane = (long)M * K;
+      RAMP_REQUIRE(gemm_h3q_applicable(a), "shape not covered by the LDS-DMA GEMM");
+    }
   } else if (mode == 1 && frag_ok) {
     planes = reinterpret_cast<unsigned short*>(ar.alloc((3 * (size_t)n + 1) / 2 + 4));
     RAMP_REQUIRE(planes, "hipMalloc failed");
@@ -1683,12 +1698,13 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     CK(launch_split3(W, planes, n, s));
     a.Wx = planes; a.wx_plane = n;
   }
-  for (int i = 0; i < warmup; ++i) CK(launch_gemm(a, s));
+  auto go = [&]() { return a.Ap ? launch_gemm_h3q(a, s) : launch_gemm(a, s); };
+  for (int i = 0; i < warmup; ++i) CK(go());
   hipEvent_t e0, e1;
   RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
   RAMP_HIP_CHECK(hipEventRecord(e0, s));
   int rc = 0;
-  for (int i = 0; i < iters && rc == 0; ++i) rc = launch_gemm(a, s);
+  for (int i = 0; i < iters && rc == 0; ++i) rc = go();
   RAMP_HIP_CHECK(hipEventRecord(e1, s));
   RAMP_HIP_CHECK(hipEventSynchronize(e1));
   float ms = 0.f;

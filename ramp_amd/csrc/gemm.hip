@@ -762,7 +762,9 @@ __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #define X6P_THREE 0
 #define X6P_ABL 0
+#define X6P_DEEP 1
 #include "gemm_x6p_body.inc"
+#undef X6P_DEEP
 #undef X6P_ABL
 #undef X6P_THREE
 }
@@ -773,8 +775,10 @@ __global__ __launch_bounds__(256)
 void gemm_x6p_abl_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   constexpr int EPI = EPI_LINEAR; constexpr bool GEN = false, AMUL = false, REC = true; constexpr int NP = 2;
 #define X6P_THREE 0
-#define X6P_ABL ABLV
+#define X6P_ABL (ABLV & 15)
+#define X6P_DEEP (ABLV < 16)
 #include "gemm_x6p_body.inc"
+#undef X6P_DEEP
 #undef X6P_ABL
 #undef X6P_THREE
 }
@@ -786,7 +790,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #define X6P_THREE 1
 #define X6P_ABL 0
+#define X6P_DEEP 0
 #include "gemm_x6p_body.inc"
+#undef X6P_DEEP
 #undef X6P_ABL
 #undef X6P_THREE
 }
@@ -854,7 +860,7 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
       const size_t lds = wide ? X6P_LDS2W : X6P_LDS2R;
 #define ABL_CASE(V) case V: if (wide) hipLaunchKernelGGL((gemm_x6p_abl_kernel<V, true>), dim3(nb), dim3(256), lds, s, a, tiles_n, n_tiles); \
                             else hipLaunchKernelGGL((gemm_x6p_abl_kernel<V, false>), dim3(nb), dim3(256), lds, s, a, tiles_n, n_tiles); break;
-      switch (a.ablate) { ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(15) default: RAMP_REQUIRE(false, "ablation variant not built"); }
+      switch (a.ablate) { ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(15) ABL_CASE(16) default: RAMP_REQUIRE(false, "ablation variant not built"); }
 #undef ABL_CASE
     }
   } else if (wide) {
@@ -939,7 +945,7 @@ int init_gemm_attributes() {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2W));
 #define ABL_ATTR(V) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_abl_kernel<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2W)); \
                     RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_abl_kernel<V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2R));
-  ABL_ATTR(1) ABL_ATTR(2) ABL_ATTR(3) ABL_ATTR(4) ABL_ATTR(7) ABL_ATTR(8) ABL_ATTR(15)
+  ABL_ATTR(1) ABL_ATTR(2) ABL_ATTR(3) ABL_ATTR(4) ABL_ATTR(7) ABL_ATTR(8) ABL_ATTR(15) ABL_ATTR(16)
 #undef ABL_ATTR
   if (int e = set_attr_x6<EPI_LINEAR, false>()) return e;
   if (int e = set_attr_x6<EPI_LINEAR, true>()) return e;

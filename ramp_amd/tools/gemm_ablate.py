@@ -17,9 +17,9 @@ def t(N, K, flags, iters=6):
     return us.value
 
 
-names = {0: "full", 1: "-A", 2: "-B", 3: "-A-B", 4: "-bar", 7: "-A-B-bar", 8: "-epi", 15: "mfma only"}
-for (N, K) in [(256, 256), (1024, 256), (256, 2048), (2048, 2048)]:
-    for tile, tf in (("wide", 0), ("narrow", 16)):
+names = {0: "full", 16: "2-slab prefetch", 1: "-A", 2: "-B", 3: "-A-B", 8: "-epi", 15: "mfma only"}
+for (N, K) in [(256, 256), (1024, 256), (256, 1024), (256, 2048), (2048, 2048)]:
+    for tile, tf in (("wide", 0),):
         best = {}
         for rnd in range(2):
             for ab in names:

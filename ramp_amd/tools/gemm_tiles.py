@@ -10,15 +10,15 @@ lib = _lib.load()
 M = 393216
 
 
-def t(N, K, flags, iters=6):
+def t(N, K, flags, iters=6, mode=3):
     us = C.c_float()
-    _lib.check(lib.ramp_bench_gemm(M, N, K, 1, 1, 3, flags, 2, iters, C.byref(us), None))
+    _lib.check(lib.ramp_bench_gemm(M, N, K, 1, 1, mode, flags, 2, iters, C.byref(us), None))
     return us.value
 
 
 shapes = [("qkv", 768, 256, 0), ("out+res", 256, 256, 3), ("ff1 geglu", 2048, 256, 1 | 4), ("ff2+res", 256, 1024, 3),
           ("dhg", 1024, 256, 0), ("ff1 dX amul", 256, 2048, 8), ("d(o)", 256, 256, 0), ("dln1", 256, 768, 0)]
-variants = [("wide", 0), ("narrow", 16), ("wide x3", 32), ("narrow x3", 16 | 32)]
+variants = [("wide", 0), ("narrow", 16)]
 for name, N, K, fl in shapes:
     best = {}
     for rnd in range(3):
@@ -27,5 +27,7 @@ for name, N, K, fl in shapes:
                 continue
             us = t(N, K, fl | vf)
             best[vn] = min(best.get(vn, 1e30), us)
+        if not (fl & (4 | 8)):
+            best["lds-dma"] = min(best.get("lds-dma", 1e30), t(N, K, fl, mode=4))
     fl_tf = 2.0 * M * N * K / 1e12
     print(f"{name:12s} N={N:5d} K={K:5d}: " + "  ".join(f"{vn} {us:7.1f} us ({fl_tf / (us * 1e-6):5.1f} TF)" for vn, us in best.items()), flush=True)

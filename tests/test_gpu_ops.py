@@ -57,6 +57,35 @@ def test_gemm_taps(M, N, K, taps, L, backward, mode):
     assert rel(out.cpu().numpy(), ref) < 3e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 256, 256), (384, 768, 256), (1024, 256, 1024), (256, 512, 2048), (2048, 2048, 256),
+                                   (128 * 37, 1024, 512)])
+@pytest.mark.parametrize("extras", [False, True])
+def test_gemm_lds_dma_kernel(M, N, K, extras):
+    """The fp16x3 GEMM whose operands both arrive through the LDS-DMA ring (gemm_q.hip: pre-split activation planes,
+    128 x 256 tiles, eight waves) against float64, with and without bias + residual, scaled from a recorded maximum;
+    tile streams of 1 .. 37 x 4 tiles per launch exercise the cross-tile prefetch and its vmcnt bookkeeping."""
+    g = rng(M + N + K)
+    A = (g.standard_normal((M, K)) * 1.7).astype(np.float32)
+    W = (g.standard_normal((1, N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = g.standard_normal(N).astype(np.float32) if extras else None
+    resid = g.standard_normal((M, N)).astype(np.float32) if extras else None
+    ref = A.astype(np.float64) @ W[0].astype(np.float64).T
+    if extras:
+        ref = ref + bias + resid
+    out = torch.full((M, N), float("nan"), device="cuda")
+    amax = float(np.abs(A).max())
+    rec, flag = _lib.op_gemm(dev(A), dev(W), None if bias is None else dev(bias), None if resid is None else dev(resid), out,
+                             M, N, K, 1, 0, 0, 1, mode="fp16x3-dma", a_absmax_prev=amax * 0.7)
+    assert flag == 0 and rec == amax
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel(got, ref) < 3e-6
+    out2 = torch.empty((M, N), device="cuda")                       # repeatable bit for bit (no race in the ring)
+    _lib.op_gemm(dev(A), dev(W), None if bias is None else dev(bias), None if resid is None else dev(resid), out2,
+                 M, N, K, 1, 0, 0, 1, mode="fp16x3-dma", a_absmax_prev=amax * 0.7)
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("R,L,C", [(3, 48, 32), (5, 24, 64), (2, 12, 128), (7, 6, 256), (2, 64, 32), (3, 8, 256), (2, 24, 32)])
 @pytest.mark.parametrize("mish", [0, 1])
 def test_groupnorm_fwd_bwd(R, L, C, mish):
