@@ -598,21 +598,33 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 // work at once; the rows still leave as 16-byte stores (a store instruction covers 4 rows x 256 contiguous bytes).
 // GEGLU forward expects the weights tiled [32 a-rows | 32 g-rows] so that a wave's two 32-column halves hold matching
 // (a, g) pairs.  Same fused math as `epilogue` (bias, per-row-variant bias, residuals, GEGLU forward / backward).
-template <int EPI, bool GEN, bool OSC, int BM = 128, int BN = 128>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x16 (&acc)[2][2], float* Sw, int tile, int tiles_n,
-                                              int lane, int wm, int wn, int r, int h, const float oscale) {
+// AUX (EPI_LINEAR): 0 = no addends besides the bias, 1 = one residual, 2 = residual(s) and / or the per-row-variant bias.
+// A template parameter rather than run-time `if (a.resid)` tests inside the passes: hipcc places the s_waitcnt of a
+// conditional load AFTER the join, where it executes on both paths -- a plain GEMM then waited vmcnt(0) in its second
+// pass for loads it never issued, i.e. for the first pass's eight stores to be acknowledged (once per tile).
+template <int EPI, bool GEN, bool OSC, int BM, int BN, int AUX>
+__device__ __forceinline__ void epilogue_wave_aux(const GemmArgs& a, f32x16 (&acc)[2][2], float* Sw, int tile, int tiles_n,
+                                                  int lane, int wm, int wn, int r, int h, const float oscale) {
   constexpr int SLD = 68;                                  // floats per scratch row (64 + pad: conflict-free b128 reads)
   const int tile_m = tile / tiles_n;
   const int n0 = (tile - tile_m * tiles_n) * BN;
+  // Every global LOAD of the epilogue is issued before its first STORE: vmcnt retires in order, so a load behind a store
+  // cannot be waited for before that store is acknowledged (and hipcc places the wait after the `if (a.bias)` join, where
+  // it executes whether or not anything was loaded).  The biases are therefore fetched once, ahead of both passes.
+  f32x4 ba = {0, 0, 0, 0}, bg = {0, 0, 0, 0}, b4 = {0, 0, 0, 0};
+  if (EPI == EPI_GEGLU_FWD) {
+    const int cg = (lane & 7) * 4, nbg = n0 + wn * 64;
+    if (a.bias) { ba = *reinterpret_cast<const f32x4*>(a.bias + nbg + cg); bg = *reinterpret_cast<const f32x4*>(a.bias + nbg + 32 + cg); }
+  } else {
+    const int nl = n0 + wn * 64 + (lane & 15) * 4;
+    if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + (nl < a.N ? nl : 0));
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     const int m0 = tile_m * BM + wm * 64 + mi * 32;
     if (EPI == EPI_GEGLU_FWD) {
       const int rl0 = lane >> 3, c = (lane & 7) * 4;       // 4 passes of 8 rows; 8 lanes per row
-      const int nb = n0 + wn * 64;
       const int half = a.N >> 1, j = (n0 >> 1) + wn * 32 + c;
-      f32x4 ba = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-      if (a.bias) { ba = *reinterpret_cast<const f32x4*>(a.bias + nb + c); bg = *reinterpret_cast<const f32x4*>(a.bias + nb + 32 + c); }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -649,14 +661,25 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x16 (&acc)[2
       const int nc = nok ? n : 0;
       // the global operands of the fused math are requested before the transpose (their latency hides behind it)
       f32x4 pre0[8], pre1[EPI == EPI_GEGLU_BWD ? 8 : 1];
+      f32x4 rbv[AUX == 2 && !GEN ? 8 : 1];          // (no conv layer has a per-row-variant bias)
       if (EPI == EPI_LINEAR) {
-        if (a.resid) {
+        if (AUX >= 1 && a.resid) {
 #pragma unroll
           for (int p = 0; p < 8; ++p) {
             const int m = m0 + p * 4 + rl0, mc = m < a.M ? m : 0;
             const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
             pre0[p] = *reinterpret_cast<const f32x4*>(a.resid + orow * a.ldr + nc);
           }
+        }
+        if (AUX == 2 && !GEN && a.rowbias) {              // index, then row: both ahead of this pass's stores
+          int rvi[8];
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            const int m = m0 + p * 4 + rl0, mc = m < a.M ? m : 0;
+            rvi[p] = a.rowvar[a.row0 + mc / a.L];
+          }
+#pragma unroll
+          for (int p = 0; p < 8; ++p) rbv[p] = *reinterpret_cast<const f32x4*>(a.rowbias + (long)rvi[p] * a.rb_stride + nc);
         }
       } else {
 #pragma unroll
@@ -673,8 +696,6 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x16 (&acc)[2
           Sw[((reg & 3) + 8 * (reg >> 2) + 4 * h) * SLD + ni * 32 + r] = acc[mi][ni][reg];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      f32x4 b4 = {0, 0, 0, 0};
-      if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + nc);
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int rl = p * 4 + rl0, m = m0 + rl;
@@ -685,9 +706,9 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x16 (&acc)[2
         if (OSC) v *= oscale;                            // undo the operand scales (powers of two: exact)
         v += b4;
         if (EPI == EPI_LINEAR) {
-          if (a.rowbias) v += *reinterpret_cast<const f32x4*>(a.rowbias + (long)a.rowvar[a.row0 + mc / a.L] * a.rb_stride + nc);
-          if (a.resid) v += pre0[p];
-          if (GEN && a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + orow * a.ldr2 + nc);
+          if (AUX == 2 && !GEN && a.rowbias) v += rbv[p];
+          if (AUX >= 1 && a.resid) v += pre0[p];
+          if (AUX == 2 && GEN && a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + orow * a.ldr2 + nc);
           if (ok) {
             if (!GEN || n < a.N1) *reinterpret_cast<f32x4*>(a.C + orow * a.ldc + n) = v;
             else *reinterpret_cast<f32x4*>(a.C2 + orow * a.ldc2 + (n - a.N1)) = v;
@@ -704,6 +725,15 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x16 (&acc)[2
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch is rewritten by the next pass
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <int EPI, bool GEN, bool OSC, int BM = 128, int BN = 128, bool NOAUX = false>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x16 (&acc)[2][2], float* Sw, int tile, int tiles_n,
+                                              int lane, int wm, int wn, int r, int h, const float oscale) {
+  if (EPI != EPI_LINEAR || NOAUX) { epilogue_wave_aux<EPI, GEN, OSC, BM, BN, 0>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale); return; }
+  if (a.rowbias || (GEN && a.resid2)) epilogue_wave_aux<EPI, GEN, OSC, BM, BN, 2>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale);
+  else if (a.resid) epilogue_wave_aux<EPI, GEN, OSC, BM, BN, 1>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale);
+  else epilogue_wave_aux<EPI, GEN, OSC, BM, BN, 0>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale);
 }
 
 // AMUL: A_eff[m][k] = A[m][k % a_period] * Amul[m][k] (the GEGLU VJP d(ag) = [d(hg) s1 | d(hg) s2] formed while the

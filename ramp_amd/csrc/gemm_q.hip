@@ -51,6 +51,11 @@ __device__ __forceinline__ void glds16(const void* src, char* dst) {
 // EPI_LINEAR only: C = acc * oscale + bias + rowbias + resid.  M must be a multiple of 128 and N of 256 (the caller
 // falls back to the register-staged kernel otherwise), so every store is unconditional and the per-tile store count the
 // vmcnt bookkeeping relies on is a constant.
+// STAG: the two waves of every SIMD (waves w and w + 4 of the block) alternate -- one reads its next fragments and issues
+// LDS-DMA while the other owns the matrix pipe -- by running waves 4..7 one barrier phase behind waves 0..3 (two phases
+// per stage).  A wave then confirms its own LDS-DMA one stage earlier (stage g + 2 at phase L(g)), because the other
+// half reads a stage half a phase before / after it does.
+template <bool STAG>
 __global__ __launch_bounds__(512)
 void gemm_h3q_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,12 +129,14 @@ void gemm_h3q_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   setup_tile(ld_tile);
 #pragma unroll 1
   for (int i = 0; i < QR; ++i) issue_stage();
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (QR - 1)) : "memory");
+  if (STAG) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (QR - 2)) : "memory");      // own shares of stages 0 and 1
+  else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (QR - 1)) : "memory");
   __builtin_amdgcn_s_barrier();
   u32x4 fa[2][2][2], fb[2][2][2];                     // [buffer][plane][mi / ni]
   read_frags(fa[0], fb[0], 0);
   int rd_slot = 1;                                     // slot of the stage whose fragments are read next
   bool after_epi = false;
+  if (STAG && wm == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // half a stage behind
 
   for (int tile = t_begin; tile < t_end; tile += t_step) {
     f32x16 acc[2][2];
@@ -145,13 +152,19 @@ void gemm_h3q_kernel(GemmArgs a, int tiles_n, int n_tiles) {
       // two stages per trip so that the fragment double buffer is indexed statically
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        // stage g+1 landed (this wave's share; the barrier makes it everyone's) and this wave's reads of stage g retired
-        if (after_epi && ks + u < QR - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (QR - 2) + Q_EPI_STORES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (QR - 2)) : "memory");
+        // stage g+1 (STAG: g+2) landed (this wave's share; the barrier makes it everyone's), reads of stage g retired
+        constexpr int LEAD = STAG ? QR - 3 : QR - 2;
+        if (after_epi && ks + u <= LEAD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * LEAD + Q_EPI_STORES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * LEAD) : "memory");
         __builtin_amdgcn_s_barrier();
         issue_stage();                                 // stage g + QR -> the slot stage g has just left
         read_frags(fa[u ^ 1], fb[u ^ 1], rd_slot);
         rd_slot = rd_slot + 1 == QR ? 0 : rd_slot + 1;
+        if (STAG) {                                    // second phase of the stage: this half computes, the other loads
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_s_setprio(1);
+        }
         // small terms first: h2 h1', h1 h2', h1 h1'
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
@@ -162,6 +175,7 @@ void gemm_h3q_kernel(GemmArgs a, int tiles_n, int n_tiles) {
             for (int ni = 0; ni < 2; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[u][PA[t3]][mi]),
                                                                    __builtin_bit_cast(half8, fb[u][PB[t3]][ni]), acc[mi][ni], 0, 0, 0);
+        if (STAG) __builtin_amdgcn_s_setprio(0);
       }
     }
 
@@ -208,6 +222,7 @@ void gemm_h3q_kernel(GemmArgs a, int tiles_n, int n_tiles) {
       }
     after_epi = true;
   }
+  if (STAG && wm == 0) __builtin_amdgcn_s_barrier();     // the phase waves 4..7 still owe
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the loader ran ahead: no LDS-DMA may outlive the block
 }
 
@@ -274,13 +289,16 @@ int launch_gemm_h3q(const GemmArgs& a, hipStream_t s) {
   const int slots = 256;                                   // one 8-wave block per CU
   const int rounds = (n_tiles + slots - 1) / slots;
   const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
-  hipLaunchKernelGGL(gemm_h3q_kernel, dim3(nb), dim3(512), Q_LDS, s, a, tiles_n, n_tiles);
+  if (a.tile_pref == 1) hipLaunchKernelGGL(gemm_h3q_kernel<false>, dim3(nb), dim3(512), Q_LDS, s, a, tiles_n, n_tiles);
+  else hipLaunchKernelGGL(gemm_h3q_kernel<true>, dim3(nb), dim3(512), Q_LDS, s, a, tiles_n, n_tiles);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int init_gemm_q_attributes() {
-  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3q_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)Q_LDS));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3q_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)Q_LDS));
   return 0;
 }

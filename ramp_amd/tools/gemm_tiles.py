@@ -28,6 +28,7 @@ for name, N, K, fl in shapes:
             us = t(N, K, fl | vf)
             best[vn] = min(best.get(vn, 1e30), us)
         if not (fl & (4 | 8)):
-            best["lds-dma"] = min(best.get("lds-dma", 1e30), t(N, K, fl, mode=4))
+            best["dma stag"] = min(best.get("dma stag", 1e30), t(N, K, fl, mode=4))
+            best["dma flat"] = min(best.get("dma flat", 1e30), t(N, K, fl | 16, mode=4))
     fl_tf = 2.0 * M * N * K / 1e12
     print(f"{name:12s} N={N:5d} K={K:5d}: " + "  ".join(f"{vn} {us:7.1f} us ({fl_tf / (us * 1e-6):5.1f} TF)" for vn, us in best.items()), flush=True)
