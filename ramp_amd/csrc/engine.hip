@@ -1668,7 +1668,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
   if (geglu) { a.epi = EPI_GEGLU_FWD; a.aux_out = aux; a.ld_aux = N / 2; a.geglu_group = (mode == 1 || mode == 3) ? 32 : 64; }
   if (amul) { a.Amul = mul; a.lda_mul = K; a.a_period = Ka; }
   a.tile_pref = (flags & 16) ? 1 : (flags & 32) ? 3 : 0;
-  a.ablate = (flags >> 8) & 31;
+  a.ablate = (flags >> 8) & 127;
   const long n = (long)taps * N * K;
   const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
   unsigned short* planes = nullptr;

@@ -602,7 +602,7 @@ void gemm_x6_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 // A template parameter rather than run-time `if (a.resid)` tests inside the passes: hipcc places the s_waitcnt of a
 // conditional load AFTER the join, where it executes on both paths -- a plain GEMM then waited vmcnt(0) in its second
 // pass for loads it never issued, i.e. for the first pass's eight stores to be acknowledged (once per tile).
-template <int EPI, bool GEN, bool OSC, int BM, int BN, int AUX>
+template <int EPI, bool GEN, bool OSC, int BM, int BN, int AUX, int EABL = 0>   // EABL (diagnostic twin only): 1 no stores, 2 no LDS transpose
 __device__ __forceinline__ void epilogue_wave_aux(const GemmArgs& a, f32x16 (&acc)[2][2], float* Sw, int tile, int tiles_n,
                                                   int lane, int wm, int wn, int r, int h, const float oscale) {
   constexpr int SLD = 68;                                  // floats per scratch row (64 + pad: conflict-free b128 reads)
@@ -689,6 +689,7 @@ __device__ __forceinline__ void epilogue_wave_aux(const GemmArgs& a, f32x16 (&ac
           pre1[p] = *reinterpret_cast<const f32x4*>(a.aux_in + (long)mc * a.ld_aux + a.N + nc);
         }
       }
+      if (EABL != 2) {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -696,13 +697,17 @@ __device__ __forceinline__ void epilogue_wave_aux(const GemmArgs& a, f32x16 (&ac
           Sw[((reg & 3) + 8 * (reg >> 2) + 4 * h) * SLD + ni * 32 + r] = acc[mi][ni][reg];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      }
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int rl = p * 4 + rl0, m = m0 + rl;
-        const bool ok = nok && m < a.M;
+        const bool ok = EABL != 1 && nok && m < a.M;
         const int mc = m < a.M ? m : 0;
         const long orow = GEN ? (long)mc * a.c_rstride + a.c_roff : (long)mc;
-        f32x4 v = *reinterpret_cast<const f32x4*>(Sw + rl * SLD + c);
+        f32x4 v;
+        if (EABL == 2) v = f32x4{acc[mi][p & 1][(p >> 1) * 4], acc[mi][p & 1][(p >> 1) * 4 + 1], acc[mi][p & 1][(p >> 1) * 4 + 2], acc[mi][p & 1][(p >> 1) * 4 + 3]};
+        else v = *reinterpret_cast<const f32x4*>(Sw + rl * SLD + c);
+        if (EABL == 1) asm volatile("" :: "v"(v));
         if (OSC) v *= oscale;                            // undo the operand scales (powers of two: exact)
         v += b4;
         if (EPI == EPI_LINEAR) {
@@ -727,9 +732,10 @@ __device__ __forceinline__ void epilogue_wave_aux(const GemmArgs& a, f32x16 (&ac
   }
 }
 
-template <int EPI, bool GEN, bool OSC, int BM = 128, int BN = 128, bool NOAUX = false>
+template <int EPI, bool GEN, bool OSC, int BM = 128, int BN = 128, bool NOAUX = false, int EABL = 0>
 __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x16 (&acc)[2][2], float* Sw, int tile, int tiles_n,
                                               int lane, int wm, int wn, int r, int h, const float oscale) {
+  if (EABL) { epilogue_wave_aux<EPI, GEN, OSC, BM, BN, 0, EABL>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale); return; }
   if (EPI != EPI_LINEAR || NOAUX) { epilogue_wave_aux<EPI, GEN, OSC, BM, BN, 0>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale); return; }
   if (a.rowbias || (GEN && a.resid2)) epilogue_wave_aux<EPI, GEN, OSC, BM, BN, 2>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale);
   else if (a.resid) epilogue_wave_aux<EPI, GEN, OSC, BM, BN, 1>(a, acc, Sw, tile, tiles_n, lane, wm, wn, r, h, oscale);
@@ -792,8 +798,10 @@ __global__ __launch_bounds__(256)
 void gemm_x6p_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #define X6P_THREE 0
 #define X6P_ABL 0
+#define X6P_EABL 0
 #define X6P_DEEP 1
 #include "gemm_x6p_body.inc"
+#undef X6P_EABL
 #undef X6P_DEEP
 #undef X6P_ABL
 #undef X6P_THREE
@@ -806,8 +814,10 @@ void gemm_x6p_abl_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   constexpr int EPI = EPI_LINEAR; constexpr bool GEN = false, AMUL = false, REC = true; constexpr int NP = 2;
 #define X6P_THREE 0
 #define X6P_ABL (ABLV & 15)
-#define X6P_DEEP (ABLV < 16)
+#define X6P_EABL (ABLV >> 5)
+#define X6P_DEEP (!(ABLV & 16))
 #include "gemm_x6p_body.inc"
+#undef X6P_EABL
 #undef X6P_DEEP
 #undef X6P_ABL
 #undef X6P_THREE
@@ -820,8 +830,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #define X6P_THREE 1
 #define X6P_ABL 0
+#define X6P_EABL 0
 #define X6P_DEEP 0
 #include "gemm_x6p_body.inc"
+#undef X6P_EABL
 #undef X6P_DEEP
 #undef X6P_ABL
 #undef X6P_THREE
@@ -890,7 +902,7 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
       const size_t lds = wide ? X6P_LDS2W : X6P_LDS2R;
 #define ABL_CASE(V) case V: if (wide) hipLaunchKernelGGL((gemm_x6p_abl_kernel<V, true>), dim3(nb), dim3(256), lds, s, a, tiles_n, n_tiles); \
                             else hipLaunchKernelGGL((gemm_x6p_abl_kernel<V, false>), dim3(nb), dim3(256), lds, s, a, tiles_n, n_tiles); break;
-      switch (a.ablate) { ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(15) ABL_CASE(16) default: RAMP_REQUIRE(false, "ablation variant not built"); }
+      switch (a.ablate) { ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(15) ABL_CASE(16) ABL_CASE(32) ABL_CASE(64) default: RAMP_REQUIRE(false, "ablation variant not built"); }
 #undef ABL_CASE
     }
   } else if (wide) {
@@ -975,7 +987,7 @@ int init_gemm_attributes() {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2W));
 #define ABL_ATTR(V) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_abl_kernel<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2W)); \
                     RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6p_abl_kernel<V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6P_LDS2R));
-  ABL_ATTR(1) ABL_ATTR(2) ABL_ATTR(3) ABL_ATTR(4) ABL_ATTR(7) ABL_ATTR(8) ABL_ATTR(15) ABL_ATTR(16)
+  ABL_ATTR(1) ABL_ATTR(2) ABL_ATTR(3) ABL_ATTR(4) ABL_ATTR(7) ABL_ATTR(8) ABL_ATTR(15) ABL_ATTR(16) ABL_ATTR(32) ABL_ATTR(64)
 #undef ABL_ATTR
   if (int e = set_attr_x6<EPI_LINEAR, false>()) return e;
   if (int e = set_attr_x6<EPI_LINEAR, true>()) return e;

@@ -17,8 +17,8 @@ def t(N, K, flags, iters=6):
     return us.value
 
 
-names = {0: "full", 16: "2-slab prefetch", 1: "-A", 2: "-B", 3: "-A-B", 8: "-epi", 15: "mfma only"}
-for (N, K) in [(256, 256), (1024, 256), (256, 1024), (256, 2048), (2048, 2048)]:
+names = {0: "full", 1: "-A", 2: "-B", 8: "-epi", 32: "-stores", 64: "-transpose", 15: "mfma only"}
+for (N, K) in [(256, 256), (768, 256), (1024, 256), (256, 1024)]:
     for tile, tf in (("wide", 0),):
         best = {}
         for rnd in range(2):
