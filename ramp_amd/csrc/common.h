@@ -84,6 +84,7 @@ int launch_split_planes(const float* A, int lda, unsigned short* out, long plane
 bool gemm_h3q_applicable(const GemmArgs& a);
 int launch_gemm_h3q(const GemmArgs& a, hipStream_t s);   // fp16x3, both operands through an LDS-DMA ring (gemm_q.hip)
 int init_gemm_q_attributes();
+int launch_ff_fwd(const GemmArgs& ff1, const GemmArgs& ff2, hipStream_t s);   // fused FF1 -> GEGLU -> FF2 (gemm.hip)
 int init_gemm_attributes();        // raise the dynamic-LDS limit of every GEMM instantiation (once)
 int init_attention_attributes();   // same for the attention kernels
 

@@ -177,6 +177,7 @@ struct ramp_ctx {
   // previous evaluation's maxima, recording its own.  obs[2][MAX_SITES] floats, ping-pong by evaluation.
   static constexpr int MAX_SITES = 1024, N_OBS_TABLES = 3;
   int phase = 0, site = 0;
+  int ff_fused = 1;                  // fp16x3 evaluations: FF1 -> GEGLU -> FF2 as one launch (RAMP_FF_FUSED=0: two launches)
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
   bool score_calibrated = false; bool score_calibrated_bwd = false; int score_parity = 0; int score_last_mode = 0;
@@ -345,38 +346,59 @@ int build_st(ramp_ctx* c, ST& s) {
 // ---- op wrappers that count launches -----------------------------------------------------------
 struct Run {
   ramp_ctx* c; hipStream_t s; int R; int row0;
+  // attach the split-precision weight planes and the delayed-scaling slots of the next call site; returns 2 when the launch
+  // will run the fp16x3 fragment kernels, 1 for bf16x6 fragments, 0 otherwise (< 0: error)
+  int prep(GemmArgs& b) {
+    if (!(c->gemm_mode >= 1 && (b.N >= 128 || (c->x6_pipe && b.N >= 64)))) return 0;
+    auto it = c->x6.upper_bound(b.W);
+    if (it == c->x6.begin()) return 0;
+    --it;
+    const auto& e = it->second;
+    if (!(b.W >= it->first && b.W < it->first + e.n)) return 0;
+    const size_t off = b.W - it->first;
+    const bool frag = c->x6_pipe && e.packed && e.K == b.K && off % (32ul * b.K) == 0 && b.N % 32 == 0;
+    if (!frag) { b.Wx = e.planes + off; b.wx_plane = (long)e.n; return 0; }
+    RAMP_REQUIRE(c->site < ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
+    int kind = 1;
+    if (c->phase == 2 && e.packed3) {
+      b.Wx = e.packed3 + 2 * off; b.wx_packed = 2; b.w_scale_inv = e.w_scale_inv;
+      b.a_absmax_in = c->obs_in + c->site; b.a_absmax_out = c->obs_out + c->site; b.range_flag = c->range_flag;
+      b.site_id = c->site;
+      kind = 2;
+    } else {
+      b.Wx = e.packed + 3 * off; b.wx_packed = 1;
+      if (c->phase >= 1) b.a_absmax_out = c->obs_out + c->site;
+    }
+    c->site++;
+    return kind;
+  }
   int gemm(const GemmArgs& a) {
     prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, a.taps});
     GemmArgs b = a;
-    if (c->gemm_mode >= 1 && (b.N >= 128 || (c->x6_pipe && b.N >= 64))) {
-      auto it = c->x6.upper_bound(b.W);
-      if (it != c->x6.begin()) {
-        --it;
-        const auto& e = it->second;
-        if (b.W >= it->first && b.W < it->first + e.n) {
-          const size_t off = b.W - it->first;
-          const bool frag = c->x6_pipe && e.packed && e.K == b.K && off % (32ul * b.K) == 0 && b.N % 32 == 0;
-          if (frag) {
-            RAMP_REQUIRE(c->site < ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
-            if (c->phase == 2 && e.packed3) {
-              b.Wx = e.packed3 + 2 * off; b.wx_packed = 2; b.w_scale_inv = e.w_scale_inv;
-              b.a_absmax_in = c->obs_in + c->site; b.a_absmax_out = c->obs_out + c->site; b.range_flag = c->range_flag;
-              b.site_id = c->site;
-            } else {
-              b.Wx = e.packed + 3 * off; b.wx_packed = 1;
-              if (c->phase >= 1) b.a_absmax_out = c->obs_out + c->site;
-            }
-            c->site++;
-          } else {
-            b.Wx = e.planes + off; b.wx_plane = (long)e.n;
-          }
-        }
-      }
-    }
+    const int kind = prep(b);
+    if (kind < 0) return kind;
     int rc = launch_gemm(b, s);
     prof_post(c, s);
     c->launches++;
     return rc;
+  }
+  // FF1 -> GEGLU -> FF2 of one transformer block (layers_attention_mini.py:38-45, 147): one fused launch in the fp16x3
+  // evaluations (the 1024-wide hidden stays in LDS), two launches otherwise.  Either way the two call sites are
+  // numbered in the same order, so calibration and fused evaluations read each other's maxima.
+  int ff_forward(const GemmArgs& u, const GemmArgs& f2) {
+    GemmArgs b1 = u, b2 = f2;
+    if (c->ff_fused && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe) {
+      prof_pre(c, s, CAT_GEMM, 2.0 * u.M * u.N * u.K + 2.0 * f2.M * f2.N * f2.K, {u.M, -1, u.K, 2});
+      const int k1 = prep(b1); if (k1 < 0) return k1;
+      const int k2 = prep(b2); if (k2 < 0) return k2;
+      RAMP_REQUIRE(k1 == 2 && k2 == 2, "fused feed-forward: weights without fp16 planes");
+      int rc = launch_ff_fwd(b1, b2, s);
+      prof_post(c, s);
+      c->launches++;
+      return rc;
+    }
+    if (int rc = gemm(u)) return rc;
+    return gemm(f2);
   }
 };
 
@@ -490,10 +512,9 @@ int st_forward(Run& r, ST& m, const float* x) {
     GemmArgs u = lin(c->t_ln, D, k.w1_pk, k.b1_pk, k.a_ag, 2048, M, 2048, D);
     u.epi = EPI_GEGLU_FWD; u.aux_out = c->t_hg; u.ld_aux = 1024;        // writes ag (stash) and hg = a * gelu(g)
     u.geglu_group = c->geglu_group;
-    CK(r.gemm(u));
     GemmArgs f = lin(c->t_hg, 1024, k.w2_f, k.b2, k.a_z2, D, M, D, 1024);
     f.resid = k.a_z1; f.ldr = D;
-    CK(r.gemm(f));
+    CK(r.ff_forward(u, f));
     zin = k.a_z2;
   }
   GemmArgs o = lin(zin, D, m.wpo_f, m.bpo, m.a_y, m.C, M, m.C, D);
@@ -868,6 +889,8 @@ int ramp_finalize_weights(ramp_ctx* c) {
                  : (env && std::string(env) == "fp32") ? 0 : RAMP_DEFAULT_GEMM_MODE;
     const char* pe = getenv("RAMP_X6_PIPE");
     c->x6_pipe = !(pe && pe[0] == '0');
+    const char* fe = getenv("RAMP_FF_FUSED");
+    c->ff_fused = !(fe && fe[0] == '0');
     c->geglu_group = (c->gemm_mode >= 1 && c->x6_pipe) ? 32 : 64;
   }
   const int nl = c->cfg.n_levels, S = c->cfg.state_dim, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim;

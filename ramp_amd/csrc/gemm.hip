@@ -839,6 +839,384 @@ void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #undef X6P_THREE
 }
 
+// =================================================================================================================
+// Fused feed-forward, forward direction (layers_attention_mini.py:38-45, 130-149):
+//     z2 = z1 + W2 (a * gelu(g)) + b2 ,   [a | g] = W1 LN3(z1) + b1
+// as ONE kernel that never writes the 1024-wide hidden hg = a * gelu(g) to HBM (it is 2048 of the 4864 floats per token
+// the FF1 / FF2 pair moves; both layers are K = 256-ish, output-store-bound shapes, profiles/r02_gemm_ablation.txt).
+//
+// Eight waves per block, one block per CU, an M-tile of 64 tokens at a time, TWO ROLES:
+//   G1 = waves 0..3: the register-staged fp16x3 loop of gemm_x6p_body.inc (64 x 256 tile: each wave 64 rows x [32 a | 32 g]
+//        packed columns) over one 256-column chunk of W1 at a time (8 chunks per M-tile); its epilogue applies GEGLU, stores
+//        the VJP stash [gelu(g) | a gelu'(g)] and writes its 64 x 32 slice of hg -- already scaled and split into the two
+//        fp16 planes an A operand needs -- into an LDS image PH[chunk & 1] (4 slabs of 32 k, the loop's own LDS layout);
+//   G2 = waves 4..7: FF2 on the PREVIOUS chunk's image: 8 k16 steps (A fragments from PH, W2 fragments straight from the
+//        packed planes) into a 64 x 256 accumulator that lives across the 8 chunks; after the last chunk bias + residual + store.
+// Waves w and w + 4 share a SIMD, so every matrix pipe alternates between one G1 and one G2 wave, and each wave carries
+// ONE accumulator set (64 registers): a single-role kernel would need both (128) on top of the loop's ~130 registers.
+// Both roles run the SAME loop skeleton -- per chunk interval eight iterations with one block barrier each (G1: one K slab,
+// G2: one k16 step) and one hand-off barrier -- so the barrier counts match by construction.
+// =================================================================================================================
+struct FfFwdArgs {
+  GemmArgs g1;     // FF1 as launch_gemm would get it: A = LN3 output (M, 256), Wx = packed [32 a | 32 g]-tiled W1 planes,
+                   // bias = packed b1, C = stash (M, 2048), scale / recording slots of ITS call site
+  GemmArgs g2;     // FF2: Wx = packed W2 planes (N = 256, K = 1024), bias = b2, resid = z1, C = z2; a_absmax_in / _out /
+                   // range_flag / site_id / w_scale_inv of ITS call site (the operand is hg)
+};
+
+constexpr int FF_PLANE = 64 * XLD;                        // halfs per plane of a 64-row, 32-k slab image
+constexpr int FF_BUF = 2 * FF_PLANE;                      // halfs per slab image (two planes): 8 KB
+constexpr int FF_PH = 4 * FF_BUF * 2;                     // bytes of one hidden-chunk image (4 slabs): 32 KB
+constexpr int FF_SCR = 32 * 68 * 4;                       // bytes of one wave scratch (32 rows x 64 columns + pad)
+constexpr size_t FF_LDS = 2 * (size_t)FF_BUF * 2 + 2 * (size_t)FF_PH + 8 * (size_t)FF_SCR;   // 16 + 64 + 68 KB = 151552 B
+static_assert(FF_LDS <= 160 * 1024, "LDS budget of the fused feed-forward kernel");
+
+__global__ __launch_bounds__(512)
+void ff_fwd_kernel(FfFwdArgs f, int n_mtiles) {
+  constexpr int NP = 2, MI = 2, NI = 2, AI = 2, NMF = 12;
+  constexpr int BUF = FF_BUF, PLANE = FF_PLANE;
+  constexpr long WBLK = NP * 1024;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* Ax = reinterpret_cast<unsigned short*>(smem);                                   // [2][2][64][XLD]
+  unsigned short* PH = Ax + 2 * BUF;                                                               // [2][4][2][64][XLD]
+  const GemmArgs& a = f.g1;
+  const GemmArgs& b = f.g2;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool G1 = wave < 4;
+  const int wn = wave & 3;
+  float* Sw = smem + (2 * BUF * 2 + 2 * FF_PH) / 4 + wave * (FF_SCR / 4);
+
+  // M-tiles of this block: its XCD's contiguous run, interleaved over the XCD's blocks
+  const int bid = blockIdx.x, nb = gridDim.x;
+  const int xcd = bid & 7, slot = bid >> 3, bpx = nb >> 3;
+  const long xlo = (long)xcd * n_mtiles / 8, xhi = (long)(xcd + 1) * n_mtiles / 8;
+  const int mt_begin = (int)xlo + slot, mt_end = (int)xhi, mt_step = bpx;
+  if (mt_begin >= mt_end) return;
+  const int n_my = (mt_end - mt_begin + mt_step - 1) / mt_step;
+  const int Q = n_my * 8;                                   // chunks this block processes
+
+  auto scale_of = [](const float* p) {
+    float s = 1.f;
+    const float mx = p ? *p : 0.f;
+    if (mx > 0.f) {
+      int eb = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu);
+      int sb = 259 - eb;
+      sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+      s = __builtin_bit_cast(float, (unsigned)sb << 23);
+    }
+    return s;
+  };
+  const float s_a = scale_of(a.a_absmax_in), s_h = scale_of(b.a_absmax_in);
+  const float oscale1 = a.w_scale_inv / s_a, oscale2 = b.w_scale_inv / s_h;
+  float amax = 0.f, amax_h = 0.f;
+
+  const int r = lane & 31, h = lane >> 5;
+  const int arow = r * XLD;
+  const int sw = (r >> 2) & 3;
+  const unsigned wlane = lane * 16;
+
+  // ------------------------------------------------------------------------------------------------------------------
+  // G1 state: the loader (one slab ahead of the LDS stores, two ahead in registers, across chunk and tile boundaries)
+  // ------------------------------------------------------------------------------------------------------------------
+  const int tg = tid & 255;
+  const int c4 = tg & 7, r0 = tg >> 3;
+  int ld_q = 0, ld_it = 0;
+  const char* abase = nullptr; unsigned aoff[AI];
+  auto setup_rows = [&](int mt) {
+    abase = reinterpret_cast<const char*>(a.A + (long)mt * 64 * a.lda);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int m = mt * 64 + r0 + 32 * i;
+      m = m < a.M ? m : a.M - 1;
+      aoff[i] = (unsigned)(m - mt * 64) * (unsigned)a.lda * 4u + c4 * 16u;
+    }
+  };
+  f32x4 ra[AI];
+  auto load_tile = [&]() {
+    const int k0 = ld_it * BK;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(abase + (long)k0 * 4 + aoff[i]);
+  };
+  auto store_tile = [&](unsigned short* dst) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      f32x4 v = ra[i];
+      amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), amax); amax = fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), amax);
+      scale4(v, s_a);
+      const int rowa = r0 + 32 * i;
+      const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * PLANE + off) = peel4<NP>(v, p + 1 < NP);
+    }
+  };
+  auto advance_loader = [&]() {
+    if (++ld_it == 8) {
+      ld_it = 0;
+      if (ld_q + 1 < Q) { ++ld_q; if ((ld_q & 7) == 0) setup_rows(mt_begin + (ld_q >> 3) * mt_step); }
+    }
+  };
+  const char* wl = reinterpret_cast<const char*>(a.Wx);
+  auto w_blocks = [&](int q, long (&blk)[NI]) {             // W1 fragment blocks of this wave's two 32-column groups in chunk q & 7
+    const int n0 = (q & 7) * 256 + wn * 64;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) blk[ni] = (long)((n0 + ni * 32) >> 5) * 16;       // K = 256: 16 k16 blocks per group
+  };
+  u32x4 av[2][NP][MI], bw[2][NP][NI];
+  long wblk[NI], wnext[NI];
+  auto load_w = [&](u32x4 (&dst)[NP][NI], const long (&blk)[NI], int it, int s2) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const char* q = wl + (blk[ni] + 2 * it + s2) * WBLK;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) dst[p][ni] = *reinterpret_cast<const u32x4*>(q + p * 1024 + wlane);
+    }
+  };
+  auto read_a = [&](u32x4 (&dst)[NP][MI], const unsigned short* src, int s2) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        dst[p][mi] = *reinterpret_cast<const u32x4*>(src + p * PLANE + arow + mi * 32 * XLD + (((2 * s2 + h) ^ sw) << 3));
+  };
+  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};       // small terms first: h2 h1', h1 h2', h1 h1'
+  int parity = 0;
+
+  // ------------------------------------------------------------------------------------------------------------------
+  // G2 state
+  // ------------------------------------------------------------------------------------------------------------------
+  const char* wl2 = reinterpret_cast<const char*>(b.Wx);
+  long blk2[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) blk2[ni] = (long)(wn * 2 + ni) * 64;                 // K = 1024: 64 k16 blocks per 32-column group
+  auto load_w2 = [&](u32x4 (&dst)[NP][NI], int kb) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) dst[p][ni] = *reinterpret_cast<const u32x4*>(wl2 + (blk2[ni] + kb) * WBLK + p * 1024 + wlane);
+  };
+
+  // The two roles are two separate loop nests with the SAME barrier structure (1 prologue barrier; per chunk interval
+  // q = 0 .. Q: eight slab barriers + one hand-off barrier): one nest with role tests inside would make every
+  // loop-carried value of either role live in both (the FF2 accumulator through G1's epilogue, ...) and spill.
+  if (G1) {
+    // ---- prologue --------------------------------------------------------------------------------------------------
+    setup_rows(mt_begin);
+    load_tile();
+    w_blocks(0, wblk);
+    load_w(bw[0], wblk, 0, 0);
+    load_w(bw[1], wblk, 0, 1);
+    store_tile(Ax);
+    advance_loader();
+    load_tile();
+    __syncthreads();
+    read_a(av[0], Ax, 0);
+    for (int q = 0; q <= Q; ++q) {
+      if (q == Q) {                                          // G2 finishes the last chunk: barriers only
+#pragma unroll 1
+        for (int it = 0; it < 9; ++it) __syncthreads();
+        break;
+      }
+      f32x16 acc[MI][NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+      if (q + 1 < Q) w_blocks(q + 1, wnext);
+      else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wnext[ni] = wblk[ni];
+      }
+#pragma unroll 1
+      for (int it = 0; it < 8; ++it) {
+        advance_loader();
+        unsigned short* cur = Ax + parity * BUF;
+        unsigned short* oth = Ax + (parity ^ 1) * BUF;
+        {
+          const long kb = 2 * it + 1;
+#pragma unroll
+          for (int j = 0; j < NMF; ++j) {
+            acc[(j >> 1) & 1][j & 1] = mfma_planes<NP>(av[0][PA[j >> 2]][(j >> 1) & 1], bw[0][PB[j >> 2]][j & 1], acc[(j >> 1) & 1][j & 1]);
+            if (j < 2 * NP) {
+              const int p = j >> 1, x = j & 1;
+              if (it != 0) bw[1][p][x] = *reinterpret_cast<const u32x4*>(wl + (wblk[x] + kb) * WBLK + p * 1024 + wlane);
+              av[1][p][x] = *reinterpret_cast<const u32x4*>(cur + p * PLANE + arow + x * 32 * XLD + (((2 + h) ^ sw) << 3));
+            } else if (j < (2 + AI) * NP) {
+              const int i = (j - 2 * NP) / NP, st = (j - 2 * NP) % NP;
+              if (st == 0) {
+                amax = fmaxf(fmaxf(fabsf(ra[i][0]), fabsf(ra[i][1])), amax);
+                amax = fmaxf(fmaxf(fabsf(ra[i][2]), fabsf(ra[i][3])), amax);
+                scale4(ra[i], s_a);
+              }
+              const int rowa = r0 + 32 * i;
+              const int off = rowa * XLD + ((((c4 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c4 & 1) * 4;
+              *reinterpret_cast<u32x2*>(oth + st * PLANE + off) = peel4<NP>(ra[i], st + 1 < NP);
+            }
+            if (j == NMF - 1) load_tile();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __syncthreads();
+        {
+          const bool last = it == 7;
+          const int it_next = last ? 0 : it + 1;
+          long wsel[NI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) wsel[ni] = last ? wnext[ni] : wblk[ni];
+          const long kb = 2 * it_next;
+#pragma unroll
+          for (int j = 0; j < NMF; ++j) {
+            acc[(j >> 1) & 1][j & 1] = mfma_planes<NP>(av[1][PA[j >> 2]][(j >> 1) & 1], bw[1][PB[j >> 2]][j & 1], acc[(j >> 1) & 1][j & 1]);
+            if (j < 2 * NP) {
+              const int p = j >> 1, x = j & 1;
+              bw[0][p][x] = *reinterpret_cast<const u32x4*>(wl + (wsel[x] + kb) * WBLK + p * 1024 + wlane);
+              av[0][p][x] = *reinterpret_cast<const u32x4*>(oth + p * PLANE + arow + x * 32 * XLD + ((h ^ sw) << 3));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        parity ^= 1;
+      }
+      // the next chunk's second-step fragments are requested before the stores of this one (vmcnt retires in order)
+      load_w(bw[1], wnext, 0, 1);
+      // ---- GEGLU epilogue of the chunk: stash to HBM, hg planes to PH[q & 1], slab `wn` ------------------------------
+      const int mt = mt_begin + (q >> 3) * mt_step;
+      const int cidx = q & 7;
+      const int rl0 = lane >> 3, c = (lane & 7) * 4;         // 4 steps of 8 rows; 8 lanes per row
+      const int nbase = cidx * 256 + wn * 64;                // this wave's packed columns: [32 a | 32 g]
+      const int half = a.N >> 1, j0 = cidx * 128 + wn * 32 + c;
+      f32x4 ba = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+      if (a.bias) { ba = *reinterpret_cast<const f32x4*>(a.bias + nbase + c); bg = *reinterpret_cast<const f32x4*>(a.bias + nbase + 32 + c); }
+      unsigned short* PHw = PH + (q & 1) * (FF_PH / 2) + wn * BUF;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m0 = mt * 64 + mi * 32;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            Sw[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 68 + ni * 32 + r] = acc[mi][ni][reg];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int rl = p * 8 + rl0, m = m0 + rl;
+          f32x4 av4 = *reinterpret_cast<const f32x4*>(Sw + rl * 68 + c);
+          f32x4 gv = *reinterpret_cast<const f32x4*>(Sw + rl * 68 + 32 + c);
+          av4 = av4 * oscale1 + ba; gv = gv * oscale1 + bg;
+          f32x4 hv, s1, s2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float cdf, pdf;
+            normal_cdf_pdf(gv[e], cdf, pdf);
+            s1[e] = gv[e] * cdf;
+            s2[e] = av4[e] * (cdf + gv[e] * pdf);
+            hv[e] = av4[e] * s1[e];
+          }
+          if (m < a.M) {
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + j0) = s1;
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + half + j0) = s2;
+          } else {
+            hv = f32x4{0, 0, 0, 0};                          // rows past M: keep the image finite, never stored
+          }
+          amax_h = fmaxf(fmaxf(fabsf(hv[0]), fabsf(hv[1])), amax_h); amax_h = fmaxf(fmaxf(fabsf(hv[2]), fabsf(hv[3])), amax_h);
+          scale4(hv, s_h);
+          const int rowa = mi * 32 + rl;
+          const int c8 = lane & 7;
+          const int off = rowa * XLD + ((((c8 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c8 & 1) * 4;
+#pragma unroll
+          for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<u32x2*>(PHw + pp * PLANE + off) = peel4<NP>(hv, pp + 1 < NP);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wblk[ni] = wnext[ni];
+      __syncthreads();                                        // hand-off: PH[q & 1] complete
+    }
+  } else {
+    u32x4 fa[NP][MI], fb[2][NP][NI];
+    load_w2(fb[0], 0);
+    __syncthreads();                                          // (G1's prologue barrier)
+#pragma unroll 1
+    for (int it = 0; it < 9; ++it) __syncthreads();           // interval 0: G1 computes the first chunk
+    f32x16 acc[MI][NI];
+    for (int cq = 0; cq < Q; ++cq) {                          // interval q = cq + 1
+      if ((cq & 7) == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+      }
+      const unsigned short* PHr = PH + (cq & 1) * (FF_PH / 2);
+#pragma unroll 1
+      for (int it2 = 0; it2 < 8; it2 += 2) {
+        // two k16 steps (one 32-k slab of the image) per trip: the W2 fragment double buffer is indexed statically
+        const int kb = (cq & 7) * 8 + it2;
+        load_w2(fb[1], (kb + 1) & 63);
+        read_a(fa, PHr + (it2 >> 1) * BUF, 0);
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = mfma_planes<NP>(fa[PA[t3]][mi], fb[0][PB[t3]][ni], acc[mi][ni]);
+        __syncthreads();
+        load_w2(fb[0], (kb + 2) & 63);                        // (the next chunk's first step at it2 == 6)
+        read_a(fa, PHr + (it2 >> 1) * BUF, 1);
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = mfma_planes<NP>(fa[PA[t3]][mi], fb[1][PB[t3]][ni], acc[mi][ni]);
+        __syncthreads();
+      }
+      if ((cq & 7) == 7) {
+        // ---- FF2 epilogue of the M-tile: z2 = acc * oscale2 + b2 + z1 -------------------------------------------------
+        const int mt = mt_begin + (cq >> 3) * mt_step;
+        epilogue_wave_aux<EPI_LINEAR, false, true, 64, 256, 1>(b, acc, Sw, mt, 1, lane, 0, wn, r, h, oscale2);
+      }
+      __syncthreads();                                        // hand-off
+    }
+  }
+
+  // ---- maxima for the next evaluation's scales, range guard (as in the stand-alone kernels) ---------------------------------
+  if (G1) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, o)); amax_h = fmaxf(amax_h, __shfl_xor(amax_h, o)); }
+    if (lane == 0) {
+      if (a.a_absmax_out) atomicMax(reinterpret_cast<unsigned*>(a.a_absmax_out), __builtin_bit_cast(unsigned, amax));
+      if (a.range_flag && (!(amax * s_a < 60000.f) || (amax > 0.f && amax * s_a < 0.125f))) atomicMax(a.range_flag, a.site_id + 1);
+      if (b.a_absmax_out) atomicMax(reinterpret_cast<unsigned*>(b.a_absmax_out), __builtin_bit_cast(unsigned, amax_h));
+      if (b.range_flag && (!(amax_h * s_h < 60000.f) || (amax_h > 0.f && amax_h * s_h < 0.125f))) atomicMax(b.range_flag, b.site_id + 1);
+    }
+  }
+}
+
+int launch_ff_fwd(const GemmArgs& g1, const GemmArgs& g2, hipStream_t s) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  RAMP_REQUIRE(g1.wx_packed == 2 && g2.wx_packed == 2 && g1.Wx && g2.Wx, "fused feed-forward needs the fp16 weight planes");
+  RAMP_REQUIRE(g1.K == 256 && g1.N == 2048 && g2.K == 1024 && g2.N == 256 && g1.M == g2.M && g1.M > 0, "fused feed-forward: 256 -> 2 x 1024 -> 256 only");
+  RAMP_REQUIRE(g1.geglu_group == 32 && g1.taps == 1 && g2.taps == 1 && !g1.A2 && !g1.Amul && !g2.rowbias && !g2.resid2 && !g2.C2, "fused feed-forward: unsupported operand");
+  RAMP_REQUIRE(g1.lda % 4 == 0 && g1.ldc % 4 == 0 && g2.ldc % 4 == 0 && (g2.resid == nullptr || g2.ldr % 4 == 0), "leading dimensions must be multiples of 4 floats");
+  RAMP_REQUIRE(al16(g1.A) && al16(g1.Wx) && al16(g2.Wx) && al16(g1.C) && al16(g2.C) && al16(g1.bias) && al16(g2.bias) && al16(g2.resid), "operands must be 16-byte aligned");
+  FfFwdArgs f; f.g1 = g1; f.g2 = g2;
+  f.g2.N1 = f.g2.N; f.g2.K1 = f.g2.K; f.g1.N1 = f.g1.N; f.g1.K1 = f.g1.K;
+  const int n_mtiles = (g1.M + 63) / 64;
+  const int nb = std::min(((n_mtiles + 7) / 8) * 8, 256);   // one 8-wave block per CU
+  hipLaunchKernelGGL(ff_fwd_kernel, dim3(nb), dim3(512), FF_LDS, s, f, n_mtiles);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // fp32 [rows][K] -> fragment-packed planes [rows/32][K/16][NP][64 lanes][8] (NP = 3: bf16, NP = 2: fp16)
 template <int NP>
 __global__ void pack_planes_kernel(const float* __restrict__ W, unsigned short* __restrict__ out, long rows, int K, float scale) {
@@ -973,6 +1351,7 @@ static int set_attr() {
   return 0;
 }
 int init_gemm_attributes() {
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_LDS));
   if (int e = set_attr<2, 2, 2, 2, EPI_LINEAR, false>()) return e;
   if (int e = set_attr<2, 2, 2, 2, EPI_LINEAR, true>()) return e;
   if (int e = set_attr<2, 2, 2, 2, EPI_GEGLU_FWD, false>()) return e;
