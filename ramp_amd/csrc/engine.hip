@@ -177,7 +177,8 @@ struct ramp_ctx {
   // previous evaluation's maxima, recording its own.  obs[2][MAX_SITES] floats, ping-pong by evaluation.
   static constexpr int MAX_SITES = 1024, N_OBS_TABLES = 3;
   int phase = 0, site = 0;
-  int ff_fused = 1;                  // fp16x3 evaluations: FF1 -> GEGLU -> FF2 as one launch (RAMP_FF_FUSED=0: two launches)
+  int ff_fused = 150000;             // fp16x3 evaluations: FF1 -> GEGLU -> FF2 as one launch for M >= this many rows
+                                     // (RAMP_FF_FUSED: 0 never, 1 always, n > 1 that threshold)
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
   bool score_calibrated = false; bool score_calibrated_bwd = false; int score_parity = 0; int score_last_mode = 0;
@@ -387,7 +388,7 @@ struct Run {
   // numbered in the same order, so calibration and fused evaluations read each other's maxima.
   int ff_forward(const GemmArgs& u, const GemmArgs& f2) {
     GemmArgs b1 = u, b2 = f2;
-    if (c->ff_fused && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe) {
+    if (c->ff_fused && u.M >= c->ff_fused && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe) {
       prof_pre(c, s, CAT_GEMM, 2.0 * u.M * u.N * u.K + 2.0 * f2.M * f2.N * f2.K, {u.M, -1, u.K, 2});
       const int k1 = prep(b1); if (k1 < 0) return k1;
       const int k2 = prep(b2); if (k2 < 0) return k2;
@@ -890,7 +891,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
     const char* pe = getenv("RAMP_X6_PIPE");
     c->x6_pipe = !(pe && pe[0] == '0');
     const char* fe = getenv("RAMP_FF_FUSED");
-    c->ff_fused = !(fe && fe[0] == '0');
+    if (fe) c->ff_fused = atoi(fe);
     c->geglu_group = (c->gemm_mode >= 1 && c->x6_pipe) ? 32 : 64;
   }
   const int nl = c->cfg.n_levels, S = c->cfg.state_dim, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim;
@@ -1666,7 +1667,42 @@ __global__ void fill_uniform_kernel(float* p, long n, unsigned seed, float scale
 }
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 4, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 5, "bad arguments");
+  if (mode == 5) {                                     // the fused FF1 -> GEGLU -> FF2 kernel (N, K ignored: 256 -> 2 x 1024 -> 256)
+    hipStream_t s5 = as_stream(stream);
+    DevArena ar5;
+    float* A5 = ar5.alloc((size_t)M * 256); float* W1 = ar5.alloc(2048 * 256); float* W2 = ar5.alloc(256 * 1024);
+    float* st5 = ar5.alloc((size_t)M * 2048); float* z1 = ar5.alloc((size_t)M * 256); float* z2 = ar5.alloc((size_t)M * 256);
+    float* b1 = ar5.alloc(2048); float* b2 = ar5.alloc(256); float* sl = ar5.alloc(8);
+    unsigned short* p1 = reinterpret_cast<unsigned short*>(ar5.alloc(2048 * 256 + 4));
+    unsigned short* p2 = reinterpret_cast<unsigned short*>(ar5.alloc(256 * 1024 + 4));
+    RAMP_REQUIRE(A5 && W1 && W2 && st5 && z1 && z2 && b1 && b2 && sl && p1 && p2, "hipMalloc failed");
+    auto fill5 = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s5, p, (long)n, seed, sc); };
+    fill5(A5, (size_t)M * 256, 1u, 1.f); fill5(W1, 2048 * 256, 2u, 1.f / 16.f); fill5(W2, 256 * 1024, 3u, 1.f / 32.f);
+    fill5(z1, (size_t)M * 256, 4u, 1.f); fill5(b1, 2048, 5u, 1.f); fill5(b2, 256, 6u, 1.f);
+    const float one[8] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, 32, hipMemcpyHostToDevice, s5));
+    CK(launch_pack_h3(W1, p1, 2048, 256, 16384.f, s5)); CK(launch_pack_h3(W2, p2, 256, 1024, 32768.f, s5));
+    GemmArgs g1; g1.A = A5; g1.lda = 256; g1.W = W1; g1.Wx = p1; g1.wx_packed = 2; g1.w_scale_inv = 1.f / 16384.f; g1.bias = b1;
+    g1.C = st5; g1.ldc = 2048; g1.M = M; g1.N = 2048; g1.K = 256; g1.epi = EPI_GEGLU_FWD; g1.geglu_group = 32;
+    g1.a_absmax_in = sl; g1.a_absmax_out = sl + 1; g1.range_flag = reinterpret_cast<int*>(sl + 2); g1.ablate = (flags >> 8) & 31;
+    GemmArgs g2; g2.W = W2; g2.Wx = p2; g2.wx_packed = 2; g2.w_scale_inv = 1.f / 32768.f; g2.bias = b2; g2.resid = z1; g2.ldr = 256;
+    g2.C = z2; g2.ldc = 256; g2.M = M; g2.N = 256; g2.K = 1024;
+    g2.a_absmax_in = sl + 4; g2.a_absmax_out = sl + 5; g2.range_flag = reinterpret_cast<int*>(sl + 6); g2.site_id = 1;
+    for (int i = 0; i < warmup; ++i) CK(launch_ff_fwd(g1, g2, s5));
+    hipEvent_t e0, e1;
+    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+    RAMP_HIP_CHECK(hipEventRecord(e0, s5));
+    int rc5 = 0;
+    for (int i = 0; i < iters && rc5 == 0; ++i) rc5 = launch_ff_fwd(g1, g2, s5);
+    RAMP_HIP_CHECK(hipEventRecord(e1, s5));
+    RAMP_HIP_CHECK(hipEventSynchronize(e1));
+    float ms5 = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&ms5, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = ms5 * 1e3f / iters;
+    return rc5;
+  }
   hipStream_t s = as_stream(stream);
   DevArena ar;
   auto fill = [&](float* p, size_t n, unsigned seed, float sc) {

@@ -847,15 +847,19 @@ void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 //
 // Eight waves per block, one block per CU, an M-tile of 64 tokens at a time, TWO ROLES:
 //   G1 = waves 0..3: the register-staged fp16x3 loop of gemm_x6p_body.inc (64 x 256 tile: each wave 64 rows x [32 a | 32 g]
-//        packed columns) over one 256-column chunk of W1 at a time (8 chunks per M-tile); its epilogue applies GEGLU, stores
-//        the VJP stash [gelu(g) | a gelu'(g)] and writes its 64 x 32 slice of hg -- already scaled and split into the two
-//        fp16 planes an A operand needs -- into an LDS image PH[chunk & 1] (4 slabs of 32 k, the loop's own LDS layout);
-//   G2 = waves 4..7: FF2 on the PREVIOUS chunk's image: 8 k16 steps (A fragments from PH, W2 fragments straight from the
-//        packed planes) into a 64 x 256 accumulator that lives across the 8 chunks; after the last chunk bias + residual + store.
+//        packed columns) over one 256-column chunk of W1 at a time (8 chunks per M-tile), and nothing else: at the end of a
+//        chunk it drops its raw accumulators into LDS (RAW, 17 KB per wave) and starts the next chunk;
+//   G2 = waves 4..7 work on the PREVIOUS chunk while G1 computes: during G1's first four slabs wave w turns G1 wave w's raw
+//        tile into GEGLU -- stores the VJP stash [gelu(g) | a gelu'(g)] and writes its 64 x 32 slice of hg, already scaled and
+//        split into the two fp16 planes an A operand needs, into the LDS image PH (4 slabs of 32 k, the loop's own layout);
+//        during the last four slabs all four run FF2 on PH: 8 k16 steps (A fragments from PH, W2 fragments straight from
+//        the packed planes) into a 64 x 256 accumulator that lives across the 8 chunks; after the last chunk bias + residual +
+//        store.  The GEGLU math and every global store of the pair therefore sit on waves whose stalls do not hold the
+//        FF1 loop (measured on the first version, where G1 carried the GEGLU epilogue: 38 % of the kernel).
 // Waves w and w + 4 share a SIMD, so every matrix pipe alternates between one G1 and one G2 wave, and each wave carries
 // ONE accumulator set (64 registers): a single-role kernel would need both (128) on top of the loop's ~130 registers.
 // Both roles run the SAME loop skeleton -- per chunk interval eight iterations with one block barrier each (G1: one K slab,
-// G2: one k16 step) and one hand-off barrier -- so the barrier counts match by construction.
+// G2: 16 GEGLU rows or two k16 steps) and one hand-off barrier -- so the barrier counts match by construction.
 // =================================================================================================================
 struct FfFwdArgs {
   GemmArgs g1;     // FF1 as launch_gemm would get it: A = LN3 output (M, 256), Wx = packed [32 a | 32 g]-tiled W1 planes,
@@ -866,9 +870,10 @@ struct FfFwdArgs {
 
 constexpr int FF_PLANE = 64 * XLD;                        // halfs per plane of a 64-row, 32-k slab image
 constexpr int FF_BUF = 2 * FF_PLANE;                      // halfs per slab image (two planes): 8 KB
-constexpr int FF_PH = 4 * FF_BUF * 2;                     // bytes of one hidden-chunk image (4 slabs): 32 KB
-constexpr int FF_SCR = 32 * 68 * 4;                       // bytes of one wave scratch (32 rows x 64 columns + pad)
-constexpr size_t FF_LDS = 2 * (size_t)FF_BUF * 2 + 2 * (size_t)FF_PH + 8 * (size_t)FF_SCR;   // 16 + 64 + 68 KB = 151552 B
+constexpr int FF_PH = 4 * FF_BUF * 2;                     // bytes of the hidden-chunk image (4 slabs): 32 KB
+constexpr int FF_SCR = 32 * 68 * 4;                       // bytes of one wave scratch of the FF2 epilogue (32 rows x 64 columns + pad)
+constexpr int FF_RAW = 64 * 68 * 4;                       // bytes of one G1 wave's raw [a | g] tile (64 rows x 64 columns + pad)
+constexpr size_t FF_LDS = 2 * (size_t)FF_BUF * 2 + 4 * (size_t)FF_RAW + (size_t)FF_PH + 4 * (size_t)FF_SCR;   // 16 + 68 + 32 + 34 KB
 static_assert(FF_LDS <= 160 * 1024, "LDS budget of the fused feed-forward kernel");
 
 __global__ __launch_bounds__(512)
@@ -878,7 +883,8 @@ void ff_fwd_kernel(FfFwdArgs f, int n_mtiles) {
   constexpr long WBLK = NP * 1024;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned short* Ax = reinterpret_cast<unsigned short*>(smem);                                   // [2][2][64][XLD]
-  unsigned short* PH = Ax + 2 * BUF;                                                               // [2][4][2][64][XLD]
+  float* RAW = smem + (2 * BUF * 2) / 4;                                                          // [4 waves][64][68]
+  unsigned short* PH = reinterpret_cast<unsigned short*>(RAW + 4 * (FF_RAW / 4));                 // [4][2][64][XLD]
   const GemmArgs& a = f.g1;
   const GemmArgs& b = f.g2;
 
@@ -886,7 +892,7 @@ void ff_fwd_kernel(FfFwdArgs f, int n_mtiles) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool G1 = wave < 4;
   const int wn = wave & 3;
-  float* Sw = smem + (2 * BUF * 2 + 2 * FF_PH) / 4 + wave * (FF_SCR / 4);
+  float* Sw = smem + (2 * BUF * 2 + 4 * FF_RAW + FF_PH) / 4 + (wave & 3) * (FF_SCR / 4);       // FF2 epilogue scratch (G2 waves)
 
   // M-tiles of this block: its XCD's contiguous run, interleaved over the XCD's blocks
   const int bid = blockIdx.x, nb = gridDim.x;
@@ -1001,6 +1007,7 @@ void ff_fwd_kernel(FfFwdArgs f, int n_mtiles) {
   // q = 0 .. Q: eight slab barriers + one hand-off barrier): one nest with role tests inside would make every
   // loop-carried value of either role live in both (the FF2 accumulator through G1's epilogue, ...) and spill.
   if (G1) {
+    if (!(a.ablate & 16)) __builtin_amdgcn_s_setprio(2);     // the FF1 loop is the critical path: its wave wins the issue arbitration
     // ---- prologue --------------------------------------------------------------------------------------------------
     setup_rows(mt_begin);
     load_tile();
@@ -1082,60 +1089,28 @@ void ff_fwd_kernel(FfFwdArgs f, int n_mtiles) {
       }
       // the next chunk's second-step fragments are requested before the stores of this one (vmcnt retires in order)
       load_w(bw[1], wnext, 0, 1);
-      // ---- GEGLU epilogue of the chunk: stash to HBM, hg planes to PH[q & 1], slab `wn` ------------------------------
-      const int mt = mt_begin + (q >> 3) * mt_step;
-      const int cidx = q & 7;
-      const int rl0 = lane >> 3, c = (lane & 7) * 4;         // 4 steps of 8 rows; 8 lanes per row
-      const int nbase = cidx * 256 + wn * 64;                // this wave's packed columns: [32 a | 32 g]
-      const int half = a.N >> 1, j0 = cidx * 128 + wn * 32 + c;
-      f32x4 ba = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-      if (a.bias) { ba = *reinterpret_cast<const f32x4*>(a.bias + nbase + c); bg = *reinterpret_cast<const f32x4*>(a.bias + nbase + 32 + c); }
-      unsigned short* PHw = PH + (q & 1) * (FF_PH / 2) + wn * BUF;
+      if (a.ablate & 2) {                                    // diagnostic (ramp_bench_gemm): main loop only
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int m0 = mt * 64 + mi * 32;
+        for (int qq = 0; qq < 4; ++qq) asm volatile("" :: "v"(acc[qq >> 1][qq & 1]));
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni) wblk[ni] = wnext[ni];
+        __syncthreads();
+        continue;
+      }
+      // ---- hand the chunk's raw [a | g] accumulators to G2 (wave-private 64 x 64 image, the C layout transposed) -------
+      {
+        float* Rw = RAW + wn * (FF_RAW / 4);
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg)
-            Sw[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 68 + ni * 32 + r] = acc[mi][ni][reg];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int rl = p * 8 + rl0, m = m0 + rl;
-          f32x4 av4 = *reinterpret_cast<const f32x4*>(Sw + rl * 68 + c);
-          f32x4 gv = *reinterpret_cast<const f32x4*>(Sw + rl * 68 + 32 + c);
-          av4 = av4 * oscale1 + ba; gv = gv * oscale1 + bg;
-          f32x4 hv, s1, s2;
+          for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float cdf, pdf;
-            normal_cdf_pdf(gv[e], cdf, pdf);
-            s1[e] = gv[e] * cdf;
-            s2[e] = av4[e] * (cdf + gv[e] * pdf);
-            hv[e] = av4[e] * s1[e];
-          }
-          if (m < a.M) {
-            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + j0) = s1;
-            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + half + j0) = s2;
-          } else {
-            hv = f32x4{0, 0, 0, 0};                          // rows past M: keep the image finite, never stored
-          }
-          amax_h = fmaxf(fmaxf(fabsf(hv[0]), fabsf(hv[1])), amax_h); amax_h = fmaxf(fmaxf(fabsf(hv[2]), fabsf(hv[3])), amax_h);
-          scale4(hv, s_h);
-          const int rowa = mi * 32 + rl;
-          const int c8 = lane & 7;
-          const int off = rowa * XLD + ((((c8 >> 1) ^ (rowa >> 2)) & 3) << 3) + (c8 & 1) * 4;
-#pragma unroll
-          for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<u32x2*>(PHw + pp * PLANE + off) = peel4<NP>(hv, pp + 1 < NP);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+            for (int reg = 0; reg < 16; ++reg)
+              Rw[(mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * 68 + ni * 32 + r] = acc[mi][ni][reg];
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) wblk[ni] = wnext[ni];
-      __syncthreads();                                        // hand-off: PH[q & 1] complete
+      __syncthreads();                                        // hand-off: RAW holds chunk q
     }
   } else {
     u32x4 fa[NP][MI], fb[2][NP][NI];
@@ -1153,13 +1128,62 @@ void ff_fwd_kernel(FfFwdArgs f, int n_mtiles) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
       }
-      const unsigned short* PHr = PH + (cq & 1) * (FF_PH / 2);
+      if (a.ablate & 1) {                                    // diagnostic (ramp_bench_gemm): this role only keeps the barriers
 #pragma unroll 1
-      for (int it2 = 0; it2 < 8; it2 += 2) {
-        // two k16 steps (one 32-k slab of the image) per trip: the W2 fragment double buffer is indexed statically
-        const int kb = (cq & 7) * 8 + it2;
+        for (int it = 0; it < 9; ++it) __syncthreads();
+        continue;
+      }
+      const int mtq = mt_begin + (cq >> 3) * mt_step, cidx = cq & 7;
+      // ---- slabs 0..3 of G1's next chunk: GEGLU of wave wn's raw tile, 16 rows per slab ---------------------------------
+      {
+        const float* Rw = RAW + wn * (FF_RAW / 4);
+        const int rl0 = lane >> 3, c = (lane & 7) * 4;       // 8 rows per step; 8 lanes per row
+        const int nbase = cidx * 256 + wn * 64;              // this tile's packed columns: [32 a | 32 g]
+        const int half = a.N >> 1, j0 = cidx * 128 + wn * 32 + c;
+        f32x4 ba = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+        if (a.bias) { ba = *reinterpret_cast<const f32x4*>(a.bias + nbase + c); bg = *reinterpret_cast<const f32x4*>(a.bias + nbase + 32 + c); }
+        unsigned short* PHw = PH + wn * BUF;
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+          if (a.ablate & 8) { __syncthreads(); continue; }   // diagnostic: no GEGLU phase
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int rl = (it * 2 + p) * 8 + rl0, m = mtq * 64 + rl;
+            f32x4 av4 = *reinterpret_cast<const f32x4*>(Rw + rl * 68 + c);
+            f32x4 gv = *reinterpret_cast<const f32x4*>(Rw + rl * 68 + 32 + c);
+            av4 = av4 * oscale1 + ba; gv = gv * oscale1 + bg;
+            f32x4 hv, s1, s2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float cdf, pdf;
+              normal_cdf_pdf(gv[e], cdf, pdf);
+              s1[e] = gv[e] * cdf;                           // gelu(g)
+              s2[e] = av4[e] * (cdf + gv[e] * pdf);          // a * gelu'(g)
+              hv[e] = av4[e] * s1[e];                        // hg = a * gelu(g)
+            }
+            if (m < a.M) {
+              *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + j0) = s1;
+              *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + half + j0) = s2;
+            } else {
+              hv = f32x4{0, 0, 0, 0};                        // rows past M: keep the image finite, never stored
+            }
+            amax_h = fmaxf(fmaxf(fabsf(hv[0]), fabsf(hv[1])), amax_h); amax_h = fmaxf(fmaxf(fabsf(hv[2]), fabsf(hv[3])), amax_h);
+            scale4(hv, s_h);
+            const int c8 = lane & 7;
+            const int off = rl * XLD + ((((c8 >> 1) ^ (rl >> 2)) & 3) << 3) + (c8 & 1) * 4;
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<u32x2*>(PHw + pp * PLANE + off) = peel4<NP>(hv, pp + 1 < NP);
+          }
+          __syncthreads();
+        }
+      }
+      // ---- slabs 4..7: FF2 on the image, two k16 steps (one 32-k slab of it) per slab -----------------------------------
+#pragma unroll 1
+      for (int it = 0; it < 4; ++it) {
+        if (a.ablate & 4) { __syncthreads(); continue; }     // diagnostic: no FF2 phase
+        const int kb = cidx * 8 + 2 * it;
         load_w2(fb[1], (kb + 1) & 63);
-        read_a(fa, PHr + (it2 >> 1) * BUF, 0);
+        read_a(fa, PH + it * BUF, 0);
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3)
 #pragma unroll
@@ -1167,9 +1191,8 @@ void ff_fwd_kernel(FfFwdArgs f, int n_mtiles) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
               acc[mi][ni] = mfma_planes<NP>(fa[PA[t3]][mi], fb[0][PB[t3]][ni], acc[mi][ni]);
-        __syncthreads();
-        load_w2(fb[0], (kb + 2) & 63);                        // (the next chunk's first step at it2 == 6)
-        read_a(fa, PHr + (it2 >> 1) * BUF, 1);
+        load_w2(fb[0], (kb + 2) & 63);                        // (the next chunk's first step at it == 3)
+        read_a(fa, PH + it * BUF, 1);
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3)
 #pragma unroll
@@ -1181,22 +1204,22 @@ void ff_fwd_kernel(FfFwdArgs f, int n_mtiles) {
       }
       if ((cq & 7) == 7) {
         // ---- FF2 epilogue of the M-tile: z2 = acc * oscale2 + b2 + z1 -------------------------------------------------
-        const int mt = mt_begin + (cq >> 3) * mt_step;
-        epilogue_wave_aux<EPI_LINEAR, false, true, 64, 256, 1>(b, acc, Sw, mt, 1, lane, 0, wn, r, h, oscale2);
+        epilogue_wave_aux<EPI_LINEAR, false, true, 64, 256, 1>(b, acc, Sw, mtq, 1, lane, 0, wn, r, h, oscale2);
       }
       __syncthreads();                                        // hand-off
     }
   }
 
-  // ---- maxima for the next evaluation's scales, range guard (as in the stand-alone kernels) ---------------------------------
-  if (G1) {
+  // ---- maxima for the next evaluation's scales, range guard (as in the stand-alone kernels): G1 saw LN3's output, G2 saw hg ------
+  {
+    float mx = G1 ? amax : amax_h;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, o)); amax_h = fmaxf(amax_h, __shfl_xor(amax_h, o)); }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if (lane == 0) {
-      if (a.a_absmax_out) atomicMax(reinterpret_cast<unsigned*>(a.a_absmax_out), __builtin_bit_cast(unsigned, amax));
-      if (a.range_flag && (!(amax * s_a < 60000.f) || (amax > 0.f && amax * s_a < 0.125f))) atomicMax(a.range_flag, a.site_id + 1);
-      if (b.a_absmax_out) atomicMax(reinterpret_cast<unsigned*>(b.a_absmax_out), __builtin_bit_cast(unsigned, amax_h));
-      if (b.range_flag && (!(amax_h * s_h < 60000.f) || (amax_h > 0.f && amax_h * s_h < 0.125f))) atomicMax(b.range_flag, b.site_id + 1);
+      const GemmArgs& g = G1 ? a : b;
+      const float sc = G1 ? s_a : s_h;
+      if (g.a_absmax_out) atomicMax(reinterpret_cast<unsigned*>(g.a_absmax_out), __builtin_bit_cast(unsigned, mx));
+      if (g.range_flag && (!(mx * sc < 60000.f) || (mx > 0.f && mx * sc < 0.125f))) atomicMax(g.range_flag, g.site_id + 1);
     }
   }
 }

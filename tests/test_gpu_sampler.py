@@ -50,11 +50,15 @@ def test_ddpm_chain_free_running(tag, nwn, graph):
     assert np.array_equal(chain[:, :, 47], np.broadcast_to(synth.default_hard_conds(4, 48)[47], chain[:, :, 47].shape))
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "fp16x3"])
-def test_ddpm_chain_every_gemm_mode(mode):
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "fp16x3", "fp16x3-fusedff"])
+def test_ddpm_chain_every_gemm_mode(mode, monkeypatch):
     """The same reference chain in each GEMM mode: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bf16x6 (three bf16 planes,
-    six products) and fp16x3 (two scaled fp16 planes, three products; its first evaluation calibrates in bf16x6)."""
+    six products) and fp16x3 (two scaled fp16 planes, three products; its first evaluation calibrates in bf16x6),
+    the last one also with every feed-forward through the fused FF1 -> GEGLU -> FF2 kernel (by default only launches
+    of 150000 rows and more take it)."""
     g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
+    monkeypatch.setenv("RAMP_FF_FUSED", "1" if mode.endswith("-fusedff") else "0")
+    mode = mode.split("-")[0]
     chain, _ = run(make_static(25, gemm_mode=mode), g, 4)
     err = np.abs(chain - g["chain"]).max()
     print(f"ddpm plain {mode} mode: max {err:.2e}")
