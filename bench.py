@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-calibration-reuse", action="store_true",
+                    help="every job's first evaluation calibrates (bf16x6) instead of continuing from the previous job's maxima")
     ap.add_argument("--cpu-sample", type=int, default=256, help="trajectories in the PyTorch-CPU baseline sample (halved "
                                                                   "until the projected chain time is <= 40 s)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
@@ -275,6 +277,8 @@ def main():
     torch.manual_seed(1234 + rank)
 
     dm, sd = build_model(B, device)
+    if args.no_calibration_reuse:
+        dm.model.set_calibration_reuse(False)
     cloud_np = synth.make_cloud(WL["cloud"][0], WL["cloud"][1], 3 if WL["o3"] else 2, seed=42)   # config 2: 16 x 64 = 1024 pts
     cloud = torch.from_numpy(cloud_np).to(device)
     hard_conds = {k: torch.from_numpy(v).to(device) for k, v in synth.default_hard_conds(WL["S"], WL["H"]).items()}
@@ -313,9 +317,13 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32-emulated (2 x fp16 planes per operand, fp32 accumulate)", "data": "synthetic",
         "gemm_mode": "fp16x3 (default): every fp32 operand is scaled by a power of two and split into 2 fp16 planes (22 "
-                     "significand bits), 3 fp16 MFMA products accumulated in fp32; the first score evaluation of each job "
-                     "runs bf16x6 and records the operand maxima the scales come from (fp32-level accuracy: the parity "
-                     "tests run in this mode); the bf16x6 and exact fp32-MFMA modes are timed below",
+                     "significand bits), 3 fp16 MFMA products accumulated in fp32; the scales of an evaluation come from the operand "
+                     "maxima its predecessor recorded -- for a job's first evaluation, the first evaluation of the previous "
+                     "job of the same shape (the warm-up job here; the very first job on a context calibrates on the bf16x6 "
+                     "kernels; --no-calibration-reuse makes every job do that) -- under an on-device range guard "
+                     "(fp32-level accuracy: the parity tests run in this mode); the bf16x6 and exact fp32-MFMA modes are "
+                     "timed below",
+        "calibration_reuse": not args.no_calibration_reuse,
         "config": {"workload": {2: "BASELINE configs[1]: Maze2D static DDPM, B=4096 trajectories/GPU x 2 CFG rows, "
                                    "H=48, S=4, T=25, 1024-pt cloud, APF forward_t>20, hipGraph replay",
                                 3: "BASELINE configs[2]: Maze3D DDPM (w=5.75), B=4096/GPU x 2 CFG rows, H=48, S=6, T=25, 4000-pt cloud",

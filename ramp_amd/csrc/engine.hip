@@ -153,7 +153,11 @@ struct ramp_ctx {
   int* s_hard_idx = nullptr; float* s_hard_val = nullptr; size_t s_hard_val_cap = 0; float* s_window = nullptr;
   float* s_cloud = nullptr; size_t s_cloud_cap = 0;
   // graph cache
-  hipGraphExec_t graph_exec = nullptr; std::string graph_key;
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; std::string graph_key;   // [0] first evaluation calibrates, [1] it continues
+  // fp16x3 calibration kept from one ramp_sample to the next of the same job shape (ramp_set_calibration_reuse): the
+  // job's first evaluation then reads the maxima the previous job's first evaluation recorded (table 2).  A job becomes
+  // the next one's calibration only when ramp_range_status has reported it clean.
+  int cal_reuse = 1; bool s_calibrated = false, s_pending = false; std::string s_cal_key, s_pending_key;
   // receding-horizon replanning (ramp_replan): fixed device buffers the captured graphs read, the graph of a replan whose
   // first evaluation calibrates ([0]) and of one that continues from the previous replan's operand maxima ([1])
   float *r_noise = nullptr, *r_hist = nullptr, *r_xclean = nullptr, *r_best = nullptr, *r_plen = nullptr, *r_smooth = nullptr,
@@ -862,7 +866,7 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
 
 int ramp_destroy(ramp_ctx* c) {
   if (!c) return 0;
-  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  for (auto& g : c->graph_exec) if (g) (void)hipGraphExecDestroy(g);
   for (auto& g : c->r_graph) if (g) (void)hipGraphExecDestroy(g);
   if (c->d_ptr_tables) (void)hipFree(c->d_ptr_tables);
   delete c;
@@ -1119,7 +1123,7 @@ int ramp_set_scene(ramp_ctx* c, const float* latents, int32_t n_variants, const 
   RAMP_HIP_CHECK(hipFree(d));
   c->graph_key.clear();     // scene changed: cross_bias pointer may have moved
   c->r_key.clear();
-  c->score_calibrated = false; c->r_calibrated = false;
+  c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false;
   return rc;
 }
 
@@ -1140,6 +1144,7 @@ int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, 
   RAMP_REQUIRE(c && x, "null argument");
   c->launches = 0;
   hipStream_t s = as_stream(stream);
+  c->s_calibrated = false; c->s_pending = false;          // single evaluations overwrite the tables a kept job calibration reads
   if (c->gemm_mode != 2 || c->force_x6) { c->score_last_mode = c->gemm_mode == 2 ? 1 : c->gemm_mode; return score_all(c, x, B, n_rp, t, f_out, eps_out, s); }
   // fp16x3: the same delayed scaling as inside ramp_sample, with the calibration kept across calls.  The first
   // evaluation after context creation / a scene change / a ramp_sample runs the bf16x6 kernels and records every call
@@ -1178,7 +1183,7 @@ int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, 
   return 0;
 }
 
-static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, bool chain) {
+static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, bool chain, bool steady) {
   const int B = p->B, H = c->cfg.horizon, S = c->cfg.state_dim;
   const size_t HS = (size_t)H * S, n = (size_t)B * HS;
   HardConds hc; hc.idx = c->s_hard_idx; hc.val = c->s_hard_val; hc.n = p->n_hard;
@@ -1194,10 +1199,12 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
   }
   for (int j = 0; j < p->n_steps; ++j) {
     if (c->gemm_mode == 2 && !c->force_x6) {
-      // evaluation 0 calibrates (bf16x6 + recorded operand maxima); evaluation j >= 1 runs fp16x3 scaled from j - 1
-      c->phase = j == 0 ? 1 : 2;
+      // evaluation 0 calibrates (bf16x6 + recorded operand maxima) or, in a job that continues from the previous one
+      // of the same shape, runs fp16x3 scaled from THAT job's evaluation 0 (table 2); evaluation j >= 1 runs fp16x3
+      // scaled from j - 1
+      c->phase = (j == 0 && !steady) ? 1 : 2;
       c->obs_out = c->obs + (j & 1) * ramp_ctx::MAX_SITES;
-      c->obs_in = c->obs + ((j & 1) ^ 1) * ramp_ctx::MAX_SITES;
+      c->obs_in = c->obs + (j == 0 ? 2 : ((j & 1) ^ 1)) * ramp_ctx::MAX_SITES;
       hipLaunchKernelGGL(zero_words_kernel, dim3(ramp_ctx::MAX_SITES / 256), dim3(256), 0, s,
                          reinterpret_cast<unsigned*>(c->obs_out), ramp_ctx::MAX_SITES);
       RAMP_HIP_CHECK(hipGetLastError());
@@ -1205,6 +1212,8 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
     const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s);
     c->phase = 0;
     CK(rc_score);
+    if (j == 0 && c->gemm_mode == 2 && !c->force_x6)      // what the next job's evaluation 0 is scaled from
+      RAMP_HIP_CHECK(hipMemcpyAsync(c->obs + 2 * ramp_ctx::MAX_SITES, c->obs, ramp_ctx::MAX_SITES * 4, hipMemcpyDeviceToDevice, s));
     CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = p->n_rp;
     m.w0 = (float)p->w0; m.w1 = (float)p->w1; m.w0p1 = (float)(1.0 + p->w0);
     m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised;
@@ -1265,11 +1274,10 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
   RAMP_HIP_CHECK(hipMemcpyAsync(c->s_noise, noise, n_noise * 4, hipMemcpyDeviceToDevice, s));
   c->launches = 0;
   c->score_calibrated = false; c->r_calibrated = false;      // the loop below overwrites the delayed-scaling tables
-  if (!p->use_graph) {
-    CK(sample_body(c, p, s, chain));
-  } else {
-    // key: everything baked into the captured nodes
-    std::string key;
+  // key: everything baked into the captured nodes (and what a kept calibration belongs to)
+  std::string key;
+  bool steady = false;
+  {
     auto put = [&](const void* q, size_t b) { key.append(static_cast<const char*>(q), b); };
     put(&p->B, 4); put(&p->n_rp, 4); put(&p->n_steps, 4); put(&p->ddim, 4); put(&p->w0, 8); put(&p->w1, 8);
     put(p->t, 4 * p->n_steps); put(p->sqrt_recip, 4 * p->n_steps); put(p->sqrt_recipm1, 4 * p->n_steps);
@@ -1281,23 +1289,34 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
     const int has_apf = p->apf.cloud != nullptr; put(&has_apf, 4);
     put(&p->apf.n_points, 4); put(&p->apf.window, 4); put(&p->apf.threshold, 8); put(&p->apf.strength, 8); put(&p->apf.passes, 4);
     const int ch = chain; put(&ch, 4); put(&c->force_x6, 4);
-    if (key != c->graph_key || !c->graph_exec) {
-      if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  }
+  const bool h3 = c->gemm_mode == 2 && !c->force_x6;
+  steady = h3 && c->cal_reuse && c->s_calibrated && c->s_cal_key == key;
+  c->s_calibrated = false;
+  c->s_pending = h3; if (h3) c->s_pending_key = key;
+  if (!p->use_graph) {
+    CK(sample_body(c, p, s, chain, steady));
+  } else {
+    if (key != c->graph_key) {
+      for (auto& g : c->graph_exec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+      c->graph_key = key;
+    }
+    const int which = steady ? 1 : 0;
+    if (!c->graph_exec[which]) {
       hipStream_t cs;
       RAMP_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
       RAMP_HIP_CHECK(hipStreamSynchronize(s));
       RAMP_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-      int rc = sample_body(c, p, cs, chain);
+      int rc = sample_body(c, p, cs, chain, steady);
       hipGraph_t g = nullptr;
       hipError_t e = hipStreamEndCapture(cs, &g);
       if (rc != 0) { if (g) (void)hipGraphDestroy(g); (void)hipStreamDestroy(cs); return rc; }
       if (e != hipSuccess) { (void)hipStreamDestroy(cs); RAMP_HIP_CHECK(e); }
-      e = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+      e = hipGraphInstantiate(&c->graph_exec[which], g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g); (void)hipStreamDestroy(cs);
       RAMP_HIP_CHECK(e);
-      c->graph_key = key;
     }
-    RAMP_HIP_CHECK(hipGraphLaunch(c->graph_exec, s));
+    RAMP_HIP_CHECK(hipGraphLaunch(c->graph_exec[which], s));
   }
   if (chain_out) RAMP_HIP_CHECK(hipMemcpyAsync(chain_out, c->s_chain, (size_t)(p->n_steps + 1) * n * 4, hipMemcpyDeviceToDevice, s));
   if (x_out) RAMP_HIP_CHECK(hipMemcpyAsync(x_out, c->s_x, n * 4, hipMemcpyDeviceToDevice, s));
@@ -1429,7 +1448,7 @@ int ramp_replan(ramp_ctx* c, const ramp_replan_params* p, const ramp_replan_stat
   ReplanState hs{}; hs.n_hist = st->n_hist; hs.stepp = st->stepp; hs.pursuer[0] = st->pursuer[0]; hs.pursuer[1] = st->pursuer[1];
   RAMP_HIP_CHECK(hipMemcpyAsync(c->r_state, &hs, sizeof(hs), hipMemcpyHostToDevice, s));
   c->launches = 0;
-  c->score_calibrated = false;
+  c->score_calibrated = false; c->s_calibrated = false; c->s_pending = false;
   const bool h3 = c->gemm_mode == 2 && !c->force_x6;
   auto run = [&](bool calibrate) -> int {
     if (!p->use_graph) return replan_body(c, p, s, calibrate);
@@ -1728,6 +1747,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
   if (amul) { a.Amul = mul; a.lda_mul = K; a.a_period = Ka; }
   a.tile_pref = (flags & 16) ? 1 : (flags & 32) ? 3 : 0;
   a.ablate = (flags >> 8) & 127;
+  a.stagger = (flags >> 16) & 0xffff;
   const long n = (long)taps * N * K;
   const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
   unsigned short* planes = nullptr;
@@ -1859,7 +1879,7 @@ int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
 int ramp_set_fallback(ramp_ctx* c, int32_t bf16x6_only) {
   RAMP_REQUIRE(c, "null argument");
   c->force_x6 = bf16x6_only ? 1 : 0;
-  c->score_calibrated = false; c->r_calibrated = false;
+  c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false;
   return 0;
 }
 int ramp_score_mode(ramp_ctx* c, int32_t* mode) {
@@ -1874,6 +1894,17 @@ int ramp_range_status(ramp_ctx* c, int32_t* flag, void* stream) {
     RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
     RAMP_HIP_CHECK(hipMemcpy(flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost));
   }
+  if (c->s_pending) {                                  // a clean fp16x3 job is the next one's calibration
+    c->s_pending = false;
+    c->s_calibrated = *flag == 0;
+    if (c->s_calibrated) c->s_cal_key = c->s_pending_key;
+  }
+  return 0;
+}
+int ramp_set_calibration_reuse(ramp_ctx* c, int32_t on) {
+  RAMP_REQUIRE(c, "null argument");
+  c->cal_reuse = on ? 1 : 0;
+  c->s_calibrated = false; c->s_pending = false;
   return 0;
 }
 int ramp_workspace_bytes(ramp_ctx* c, int64_t* bytes) {

@@ -253,6 +253,11 @@ class TemporalUnetInference(nn.Module):
         _lib.check(_lib.load().ramp_score_mode(self.ctx(), C.byref(n)))
         return {0: "fp32", 1: "bf16x6", 2: "fp16x3"}[n.value]
 
+    def set_calibration_reuse(self, on: bool) -> None:
+        """fp16x3: whether a sampling job may start from the operand maxima of the previous job of the same shape
+        (default) or calibrates itself every time (ramp_set_calibration_reuse, include/ramp_hip.h)."""
+        _lib.check(_lib.load().ramp_set_calibration_reuse(self.ctx(), int(bool(on))), "ramp_set_calibration_reuse")
+
     def workspace_bytes(self) -> int:
         n = C.c_int64()
         _lib.check(_lib.load().ramp_workspace_bytes(self.ctx(), C.byref(n)))
