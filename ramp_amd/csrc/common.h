@@ -116,6 +116,12 @@ int launch_ln_fwd(const float* x, const float* gamma, const float* beta, float* 
 int launch_ln_bwd(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
                   int n_tok, hipStream_t s);
 
+// rows of one trajectory leaving / re-entering the shared prefix (rowops.hip): out[r] = in[r / n_rp] (+ rowbias[variant]),
+// out[b] = sum_j w[j] in[b n_rp + j]; (rows, L, C) channels-last, w on the host
+int launch_expand_rows(const float* in, float* out, int R, int n_rp, int L, int C, const float* rowbias, int rb_stride,
+                       const int* rowvar, int row0, hipStream_t s);
+int launch_combine_rows(const float* in, float* out, int B, int n_rp, int L, int C, const float* w, hipStream_t s);
+
 // GEGLU on ag (n_tok, 2*F): hg = a * gelu(g); backward writes dag (n_tok, 2*F)
 int launch_geglu_fwd(const float* ag, float* hg, int n_tok, int F, hipStream_t s);
 int launch_geglu_bwd(const float* dhg, const float* ag, float* dag, int n_tok, int F, hipStream_t s);

@@ -183,6 +183,7 @@ struct ramp_ctx {
   int phase = 0, site = 0;
   int ff_fused = 150000;             // fp16x3 evaluations: FF1 -> GEGLU -> FF2 as one launch for M >= this many rows
                                      // (RAMP_FF_FUSED: 0 never, 1 always, n > 1 that threshold)
+  int share_prefix = 1;              // sampling jobs: rows of one trajectory share the network prefix (RAMP_SHARE_PREFIX=0: off)
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
   bool score_calibrated = false; bool score_calibrated_bwd = false; int score_parity = 0; int score_last_mode = 0;
@@ -496,23 +497,30 @@ int rtb_backward(Run& r, RTB& m, const float* dy, float* dxa, int ca, float* dxb
 }
 
 // ---- SpatialTransformer ------------------------------------------------------------------------
-int st_forward(Run& r, ST& m, const float* x) {
+// share > 1 (first transformer of the network inside a sampling job): x and everything up to the first block's
+// attention output projection hold ONE row per trajectory (r.R / share rows); the rows part ways where the
+// cross-attention constant of their scene variant is added (expand_rows), and the outer residual uses x expanded.
+int st_forward(Run& r, ST& m, const float* x, int share = 1) {
   ramp_ctx* c = r.c; const int R = r.R, M = R * m.L, D = 256;
-  GnArgs g; g.x = x; g.gamma = m.gn_g; g.beta = m.gn_b; g.y = c->t_xn; g.stats = m.a_gst; g.R = R; g.L = m.L;
+  const int Rp = R / share, Mp = Rp * m.L;              // prefix rows
+  GnArgs g; g.x = x; g.gamma = m.gn_g; g.beta = m.gn_b; g.y = c->t_xn; g.stats = m.a_gst; g.R = Rp; g.L = m.L;
   g.C = m.C; g.eps = 1e-6f; g.mish = 0;
   LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_fwd(g, r.s));
-  CK(r.gemm(lin(c->t_xn, m.C, m.wpi_f, m.bpi, m.a_z0, D, M, D, m.C)));
+  CK(r.gemm(lin(c->t_xn, m.C, m.wpi_f, m.bpi, m.a_z0, D, Mp, D, m.C)));
   const float* zin = m.a_z0;
   for (int b = 0; b < 2; ++b) {
     STBlock& k = m.blk[b];
-    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(zin, k.ln1_g, k.ln1_b, c->t_ln, M, r.s));
-    CK(r.gemm(lin(c->t_ln, D, k.wqkv_f, nullptr, k.a_qkv, 768, M, 768, D)));
-    LAUNCH(c, r.s, CAT_ATTN, 16.0 * R * m.L * m.L * 64, launch_attn_fwd(k.a_qkv, c->t_o, R, m.L, r.s));
-    GemmArgs a = lin(c->t_o, D, k.wo_f, k.bo, k.a_z1, D, M, D, D);
+    const bool pre = share > 1 && b == 0;
+    const int Rb = pre ? Rp : R, Mb = Rb * m.L;
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(zin, k.ln1_g, k.ln1_b, c->t_ln, Mb, r.s));
+    CK(r.gemm(lin(c->t_ln, D, k.wqkv_f, nullptr, k.a_qkv, 768, Mb, 768, D)));
+    LAUNCH(c, r.s, CAT_ATTN, 16.0 * Rb * m.L * m.L * 64, launch_attn_fwd(k.a_qkv, c->t_o, Rb, m.L, r.s));
+    GemmArgs a = lin(c->t_o, D, k.wo_f, k.bo, pre ? c->t_ln : k.a_z1, D, Mb, D, D);
     a.resid = zin; a.ldr = D; a.L = m.L;
-    a.rowbias = c->cross_bias + (size_t)(m.blk0 + b) * D; a.rb_stride = c->n_blocks_total * D;
-    a.rowvar = c->row_variant; a.row0 = r.row0;
+    const float* rowbias = c->cross_bias + (size_t)(m.blk0 + b) * D; const int rb_stride = c->n_blocks_total * D;
+    if (!pre) { a.rowbias = rowbias; a.rb_stride = rb_stride; a.rowvar = c->row_variant; a.row0 = r.row0; }
     CK(r.gemm(a));
+    if (pre) LAUNCH(c, r.s, CAT_ROW, 0, launch_expand_rows(c->t_ln, k.a_z1, R, share, m.L, D, rowbias, rb_stride, c->row_variant, r.row0, r.s));
     LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(k.a_z1, k.ln3_g, k.ln3_b, c->t_ln, M, r.s));
     GemmArgs u = lin(c->t_ln, D, k.w1_pk, k.b1_pk, k.a_ag, 2048, M, 2048, D);
     u.epi = EPI_GEGLU_FWD; u.aux_out = c->t_hg; u.ld_aux = 1024;        // writes ag (stash) and hg = a * gelu(g)
@@ -524,13 +532,20 @@ int st_forward(Run& r, ST& m, const float* x) {
   }
   GemmArgs o = lin(zin, D, m.wpo_f, m.bpo, m.a_y, m.C, M, m.C, D);
   o.resid = x; o.ldr = m.C;
+  if (share > 1) {
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_expand_rows(x, c->t_xn, R, share, m.L, m.C, nullptr, 0, nullptr, 0, r.s));
+    o.resid = c->t_xn;
+  }
   CK(r.gemm(o));
   CK(dbg_store(c, "out/" + m.name, m.a_y, (size_t)M * m.C, r.s));
   return 0;
 }
 
-int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx) {
+// share > 1: see st_forward; comb = the weights of the rows' gradients in what the sampler uses.  dy, and everything down
+// to d(z1) of the first block, have r.R rows; from there on (and dx) one COMBINED row per trajectory.
+int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx, int share = 1, const float* comb = nullptr) {
   ramp_ctx* c = r.c; const int R = r.R, M = R * m.L, D = 256;
+  const int Rp = R / share, Mp = Rp * m.L;
   CK(dbg_store(c, "gout/" + m.name, dy, (size_t)M * m.C, r.s));
   float* dz = c->t_dz; float* dz1 = c->t_dz1;
   CK(r.gemm(lin(dy, m.C, m.wpo_b, nullptr, dz, D, M, D, m.C)));
@@ -551,30 +566,44 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx) {
       CK(r.gemm(lin(c->t_dag, 2048, k.w1_b, nullptr, c->t_dln, D, M, D, 2048)));        // d(ln3)
     }
     LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, k.a_z1, k.ln3_g, dz, dz1, M, r.s));         // dz1
-    CK(r.gemm(lin(dz1, D, k.wo_b, nullptr, c->t_o, D, M, D, D)));                       // d(o)
-    LAUNCH(c, r.s, CAT_ATTN, 32.0 * R * m.L * m.L * 64, launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, R, m.L, r.s));
-    CK(r.gemm(lin(c->t_dqkv, 768, k.wqkv_b, nullptr, c->t_dln, D, M, D, 768)));         // d(ln1)
-    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, zin, k.ln1_g, dz1, dz, M, r.s));            // dz (block input)
+    const bool pre = share > 1 && b == 0;
+    const int Rb = pre ? Rp : R, Mb = Rb * m.L;
+    if (pre) {      // the rows of a trajectory meet again: dz (free now) <- sum_j comb_j dz1[row j]
+      LAUNCH(c, r.s, CAT_ROW, 0, launch_combine_rows(dz1, dz, Rp, share, m.L, D, comb, r.s));
+      std::swap(dz, dz1);
+    }
+    CK(r.gemm(lin(dz1, D, k.wo_b, nullptr, c->t_o, D, Mb, D, D)));                      // d(o)
+    LAUNCH(c, r.s, CAT_ATTN, 32.0 * Rb * m.L * m.L * 64, launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, Rb, m.L, r.s));
+    CK(r.gemm(lin(c->t_dqkv, 768, k.wqkv_b, nullptr, c->t_dln, D, Mb, D, 768)));        // d(ln1)
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, zin, k.ln1_g, dz1, dz, Mb, r.s));           // dz (block input)
   }
-  CK(r.gemm(lin(dz, D, m.wpi_b, nullptr, c->t_xn, m.C, M, m.C, D)));                    // d(xn)
+  CK(r.gemm(lin(dz, D, m.wpi_b, nullptr, c->t_xn, m.C, Mp, m.C, D)));                   // d(xn)
   GnBwdArgs g; g.dy = c->t_xn; g.x = x; g.stats = m.a_gst; g.gamma = m.gn_g; g.beta = m.gn_b; g.add = dy; g.dx = dx;
-  g.R = R; g.L = m.L; g.C = m.C; g.mish = 0;
+  g.R = Rp; g.L = m.L; g.C = m.C; g.mish = 0;
+  if (share > 1) {   // the gradient through the outer residual, combined (t_o is free after the attention backward)
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_combine_rows(dy, c->t_o, Rp, share, m.L, m.C, comb, r.s));
+    g.add = c->t_o;
+  }
   LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));
   return 0;
 }
 
 // ---- whole network -----------------------------------------------------------------------------
 // x (B,H,S) device pointer of the FIRST trajectory of this chunk; rows [row0, row0 + R)
+// share = n_rp (> 1) inside a sampling job: the rows of a trajectory carry the same x and t, so the two residual blocks
+// of level 0 and the first transformer down to its first cross-attention constant run on one row per trajectory
 int net_forward(ramp_ctx* c, const float* x_chunk, int row0, int R, int n_rp, int t, float* f_out, bool want_grad,
-                hipStream_t s) {
+                hipStream_t s, int share = 1) {
   Run r{c, s, R, row0};
+  Run rp{c, s, R / share, row0 / share};
   const int nl = c->cfg.n_levels;
   const float* cur = nullptr; int cc = 0;
   for (int k = 0; k < nl; ++k) {
     RTB& a = c->rtbs[2 * k]; RTB& b = c->rtbs[2 * k + 1]; ST& st = c->sts[k];
-    CK(rtb_forward(r, a, cur, cc, nullptr, 0, x_chunk, n_rp, t));
-    CK(rtb_forward(r, b, a.a_out, a.cout, nullptr, 0, nullptr, n_rp, t));
-    CK(st_forward(r, st, b.a_out));
+    const bool pre = share > 1 && k == 0;
+    CK(rtb_forward(pre ? rp : r, a, cur, cc, nullptr, 0, x_chunk, pre ? 1 : n_rp, t));
+    CK(rtb_forward(pre ? rp : r, b, a.a_out, a.cout, nullptr, 0, nullptr, pre ? 1 : n_rp, t));
+    CK(st_forward(r, st, b.a_out, pre ? share : 1));
     if (k < nl - 1) {
       Resample& d = c->downs[k];
       // Downsample1d: y[lo] = b + sum_j x[2 lo + j - 1] W_j^T  -> 3 taps over stride-2 source rows
@@ -617,8 +646,10 @@ int net_forward(ramp_ctx* c, const float* x_chunk, int row0, int R, int n_rp, in
   return 0;
 }
 
-int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s) {
+// share > 1: eps_out gets ONE row per trajectory, sum_j comb[j] * (input gradient of row j)
+int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s, int share = 1, const float* comb = nullptr) {
   Run r{c, s, R, row0};
+  Run rp{c, s, R / share, row0 / share};
   const int nl = c->cfg.n_levels, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim, M = R * H;
   GnBwdArgs g; g.dy = c->a_fin_da; g.x = c->a_fin_c; g.stats = c->a_fin_st; g.gamma = c->fin_g; g.beta = c->fin_b;
   g.dx = c->g_t1; g.R = R; g.L = H; g.C = C0; g.mish = 1;
@@ -659,10 +690,11 @@ int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s) {
       }
       std::swap(d, e);
     }
-    CK(st_backward(r, st, b.a_out, d, e)); std::swap(d, e);
-    CK(rtb_backward(r, b, d, e, b.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e);
+    const bool pre = share > 1 && k == 0;
+    CK(st_backward(r, st, b.a_out, d, e, pre ? share : 1, comb)); std::swap(d, e);
+    CK(rtb_backward(pre ? rp : r, b, d, e, b.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e);
     if (k > 0) { CK(rtb_backward(r, a, d, e, a.cin, nullptr, 0, nullptr, nullptr)); std::swap(d, e); }
-    else CK(rtb_backward(r, a, d, nullptr, 0, nullptr, 0, nullptr, eps_out));
+    else CK(rtb_backward(pre ? rp : r, a, d, nullptr, 0, nullptr, 0, nullptr, eps_out));
   }
   return 0;
 }
@@ -817,7 +849,10 @@ int ensure_sampler_buffers(ramp_ctx* c, int B, int n_rp, int n_steps, bool chain
 }
 
 // one score evaluation over all rows of a batch, chunked to the context capacity
-int score_all(ramp_ctx* c, const float* x, int B, int n_rp, int t, float* f_out, float* eps_out, hipStream_t s) {
+// comb != nullptr (n_rp host floats; sampling jobs): the rows of a trajectory share the network prefix they have in
+// common and eps_out receives (B, H, S) = sum_j comb[j] * eps of row j instead of the (B n_rp, H, S) row gradients
+int score_all(ramp_ctx* c, const float* x, int B, int n_rp, int t, float* f_out, float* eps_out, hipStream_t s,
+              const float* comb = nullptr) {
   const int H = c->cfg.horizon, S = c->cfg.state_dim;
   RAMP_REQUIRE(c->finalized, "weights not finalized");
   RAMP_REQUIRE(c->time_table != nullptr && t >= 0 && t < c->tt_T, "timestep outside the prepared time table");
@@ -830,8 +865,11 @@ int score_all(ramp_ctx* c, const float* x, int B, int n_rp, int t, float* f_out,
     const int nb = std::min(cap_traj, B - b0), R = nb * n_rp, row0 = b0 * n_rp;
     float* fo = f_out ? f_out + (size_t)row0 * H * S : nullptr;
     c->site = 0;                                       // every chunk walks the same GEMM call sites
-    CK(net_forward(c, x + (size_t)b0 * H * S, row0, R, n_rp, t, fo, eps_out != nullptr, s));
-    if (eps_out) CK(net_backward(c, row0, R, eps_out + (size_t)row0 * H * S, s));
+    const int share = (comb && n_rp > 1 && c->share_prefix) ? n_rp : 1;
+    RAMP_REQUIRE(!comb || (eps_out && !f_out), "combined evaluation: gradient only");
+    CK(net_forward(c, x + (size_t)b0 * H * S, row0, R, n_rp, t, fo, eps_out != nullptr, s, share));
+    if (eps_out && share > 1) CK(net_backward(c, row0, R, eps_out + (size_t)b0 * H * S, s, share, comb));
+    else if (eps_out) CK(net_backward(c, row0, R, eps_out + (size_t)row0 * H * S, s));
   }
   return 0;
 }
@@ -896,6 +934,8 @@ int ramp_finalize_weights(ramp_ctx* c) {
     c->x6_pipe = !(pe && pe[0] == '0');
     const char* fe = getenv("RAMP_FF_FUSED");
     if (fe) c->ff_fused = atoi(fe);
+    const char* se = getenv("RAMP_SHARE_PREFIX");
+    if (se) c->share_prefix = atoi(se) != 0;
     c->geglu_group = (c->gemm_mode >= 1 && c->x6_pipe) ? 32 : 64;
   }
   const int nl = c->cfg.n_levels, S = c->cfg.state_dim, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim;
@@ -1209,12 +1249,17 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
                          reinterpret_cast<unsigned*>(c->obs_out), ramp_ctx::MAX_SITES);
       RAMP_HIP_CHECK(hipGetLastError());
     }
-    const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s);
+    // the weights of the rows' gradients in e_comb (diffusion_model_static.py:164-165, 214): the network prefix the rows
+    // of a trajectory have in common is evaluated once and its input gradient once, on the combined gradient
+    const float comb[3] = {p->n_rp == 2 ? (float)(1.0 + p->w0) : (float)p->w0, p->n_rp == 2 ? -(float)p->w0 : (float)p->w1,
+                           (float)(1.0 - p->w0 - p->w1)};
+    const bool shared = p->n_rp > 1 && c->share_prefix;
+    const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s, shared ? comb : nullptr);
     c->phase = 0;
     CK(rc_score);
     if (j == 0 && c->gemm_mode == 2 && !c->force_x6)      // what the next job's evaluation 0 is scaled from
       RAMP_HIP_CHECK(hipMemcpyAsync(c->obs + 2 * ramp_ctx::MAX_SITES, c->obs, ramp_ctx::MAX_SITES * 4, hipMemcpyDeviceToDevice, s));
-    CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = p->n_rp;
+    CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = shared ? 1 : p->n_rp;
     m.w0 = (float)p->w0; m.w1 = (float)p->w1; m.w0p1 = (float)(1.0 + p->w0);
     m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised;
     float* chain_j = chain ? c->s_chain + (size_t)(j + 1) * n : nullptr;
@@ -1354,10 +1399,12 @@ static int replan_body(ramp_ctx* c, const ramp_replan_params* p, hipStream_t s, 
                          reinterpret_cast<unsigned*>(c->obs_out), ramp_ctx::MAX_SITES);
       RAMP_HIP_CHECK(hipGetLastError());
     }
-    const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s);
+    const float comb[3] = {(float)(1.0 + p->w), -(float)p->w, 0.f};
+    const bool shared = p->n_rp > 1 && c->share_prefix;
+    const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s, shared ? comb : nullptr);
     c->phase = 0;
     CK(rc_score);
-    CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = p->n_rp;
+    CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = shared ? 1 : p->n_rp;
     m.w0 = (float)p->w; m.w1 = 0.f; m.w0p1 = (float)(1.0 + p->w);
     m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised;
     m.mean = nullptr; m.x0 = c->s_x0;

@@ -252,6 +252,55 @@ int launch_ln_bwd(const float* dy, const float* x, const float* gamma, const flo
 }
 
 // ------------------------------------------------------------------------------------------
+// Shared prefix of the rows of one trajectory (engine.hip, net_forward): the n_rp network rows of a trajectory (CFG:
+// conditional / unconditional; composition: two scenes + unconditional) get the same x and t and first differ in the
+// per-scene constant of the first cross-attention, so everything before it runs once per trajectory.
+// expand: out[r] = in[r / n_rp] (+ rowbias[variant(row0 + r)], the cross-attention constant) -- the rows part ways;
+// combine: out[b] = sum_j w_j in[b n_rp + j] -- the input gradient is linear in what flows back into the prefix, and
+// the sampler only ever uses the weighted sum of the rows' gradients (diffusion_model_static.py:164-165, 214).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ in, float* __restrict__ out, long n4,
+                                                           int row4, int c4, int n_rp, const float* __restrict__ rowbias,
+                                                           int rb_stride4, const int* __restrict__ rowvar, int row0) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / row4; const int w = (int)(i - r * row4);
+    f32x4 v = reinterpret_cast<const f32x4*>(in)[(r / n_rp) * row4 + w];
+    if (rowbias) v += reinterpret_cast<const f32x4*>(rowbias)[(long)rowvar[row0 + r] * rb_stride4 + (w % c4)];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
+int launch_expand_rows(const float* in, float* out, int R, int n_rp, int L, int C, const float* rowbias, int rb_stride,
+                       const int* rowvar, int row0, hipStream_t s) {
+  RAMP_REQUIRE(R > 0 && n_rp >= 1 && R % n_rp == 0 && C % 4 == 0 && rb_stride % 4 == 0 && (!rowbias || rowvar), "bad expand_rows arguments");
+  const long n4 = (long)R * L * C / 4;
+  long g = (n4 + 255) / 256; if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(expand_rows_kernel, dim3((int)g), dim3(256), 0, s, in, out, n4, L * C / 4, C / 4, n_rp, rowbias,
+                     rb_stride / 4, rowvar, row0);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+__global__ __launch_bounds__(256) void combine_rows_kernel(const float* __restrict__ in, float* __restrict__ out, long n4,
+                                                            int row4, int n_rp, float w0, float w1, float w2) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long b = i / row4; const int w = (int)(i - b * row4);
+    const f32x4* src = reinterpret_cast<const f32x4*>(in) + (b * n_rp) * row4 + w;
+    f32x4 v = src[0] * w0;
+    if (n_rp > 1) v += src[row4] * w1;
+    if (n_rp > 2) v += src[2 * (long)row4] * w2;
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
+int launch_combine_rows(const float* in, float* out, int B, int n_rp, int L, int C, const float* w, hipStream_t s) {
+  RAMP_REQUIRE(B > 0 && n_rp >= 1 && n_rp <= 3 && C % 4 == 0 && w, "bad combine_rows arguments");
+  const long n4 = (long)B * L * C / 4;
+  long g = (n4 + 255) / 256; if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(combine_rows_kernel, dim3((int)g), dim3(256), 0, s, in, out, n4, L * C / 4, n_rp, w[0],
+                     n_rp > 1 ? w[1] : 0.f, n_rp > 2 ? w[2] : 0.f);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // GEGLU
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* __restrict__ ag, float* __restrict__ hg,

@@ -65,8 +65,11 @@ def test_config2_full_size_against_embedded_reference_trajectories():
     noise = _noise_with_seeds((26, B, 48, 4), g["noise"], 5)
     a = _run(dm, noise, cloud, B)
     assert _range_flag(u) == 0                                   # fp16x3 ran to the end: no fallback happened
-    b = _run(dm, noise, cloud, B)
-    assert torch.equal(a, b)                                     # graph replay is deterministic
+    b = _run(dm, noise, cloud, B)                                # continues from the first job's calibration
+    assert _range_flag(u) == 0
+    assert torch.equal(b, _run(dm, noise, cloud, B))             # graph replay is deterministic
+    print(f"config 2 full size: calibrating vs continuing job, max {float((a - b).abs().max()):.2e}")
+    del b
     a = a.cpu().numpy()
     assert a.shape == (26, B, 48, 4) and np.isfinite(a).all()
     err = np.abs(a[:22, :4] - g["chain"][:22]).reshape(22, -1).max(1)
@@ -104,7 +107,10 @@ def test_config3_full_size_against_embedded_reference_trajectories():
     noise = _noise_with_seeds((26, B, 48, 6), g["noise"], 6)
     a = _run(dm, noise, cloud, B)
     assert _range_flag(u) == 0
-    assert torch.equal(a, _run(dm, noise, cloud, B))
+    b = _run(dm, noise, cloud, B)                                # continues from the first job's calibration
+    assert _range_flag(u) == 0
+    assert torch.equal(b, _run(dm, noise, cloud, B))
+    del b
     a = a.cpu().numpy()
     assert np.isfinite(a).all() and np.abs(a[-1]).max() <= 1.0
     # w = 5.75 amplifies rounding ~12x per step: the free-running chain is comparable at 5e-4 (the float64 truth is 1e-4
@@ -156,7 +162,9 @@ def test_config5_per_gpu_shard_full_size():
     x1 = _run(dm, noise, big, B, return_chain=False)
     assert _range_flag(u) == 0
     x2 = _run(dm, noise, big, B, return_chain=False)
-    assert torch.equal(x1, x2) and bool(torch.isfinite(x1).all()) and float(x1.abs().max()) <= 1.0
+    assert _range_flag(u) == 0
+    assert torch.equal(x2, _run(dm, noise, big, B, return_chain=False))
+    assert bool(torch.isfinite(x1).all()) and float(x1.abs().max()) <= 1.0
     hc = synth.default_hard_conds(6, 64)
     assert torch.equal(x1[:, 0], torch.from_numpy(hc[0]).cuda().expand(B, -1))
     assert torch.equal(x1[:, 63], torch.from_numpy(hc[63]).cuda().expand(B, -1))
