@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--max-rows", type=int, default=0, help="network rows per chunk of a score evaluation (0: all 2 B rows at once)")
     ap.add_argument("--no-calibration-reuse", action="store_true",
                     help="every job's first evaluation calibrates (bf16x6) instead of continuing from the previous job's maxima")
     ap.add_argument("--cpu-sample", type=int, default=256, help="trajectories in the PyTorch-CPU baseline sample (halved "
@@ -72,6 +73,9 @@ WORKLOADS = {   # S, H, T, 3-D?, cloud (n_obstacles, n_points), use_apf
 WL = WORKLOADS[2]
 
 
+MAX_ROWS = None       # --max-rows: network rows per chunk (default: the whole batch, 2 B, in one chunk)
+
+
 def build_model(B, device, gemm_mode="default"):
     import torch
     from ramp_amd import synth
@@ -81,7 +85,7 @@ def build_model(B, device, gemm_mode="default"):
     sp = make_unet_spec(WL["S"], WL["H"], obstacle_3d=WL["o3"])
     sd = synth.make_unet_state_dict(sp, seed=0)
     unet = TemporalUnetInference(n_support_points=WL["H"], state_dim=WL["S"], unet_input_dim=32, dim_mults=(1, 2, 4, 8),
-                                 obstacle_3d=WL["o3"], max_rows=2 * B, gemm_mode=gemm_mode)
+                                 obstacle_3d=WL["o3"], max_rows=MAX_ROWS or 2 * B, gemm_mode=gemm_mode)
     load_numpy_state_dict(unet, sd)
     if WL.get("dynamic"):
         from ramp_amd.models import DynamicGaussianDiffusionModel
@@ -256,8 +260,9 @@ def main():
     from ramp_amd import dist as rdist
     from ramp_amd import synth
 
-    global WL
+    global WL, MAX_ROWS
     WL = WORKLOADS[args.config]
+    MAX_ROWS = args.max_rows or None
     if args.config in (4, 5) and args.batch == 4096:
         args.batch = 8192
     rank, world, local = rdist.env_rank()

@@ -1793,8 +1793,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
   if (geglu) { a.epi = EPI_GEGLU_FWD; a.aux_out = aux; a.ld_aux = N / 2; a.geglu_group = (mode == 1 || mode == 3) ? 32 : 64; }
   if (amul) { a.Amul = mul; a.lda_mul = K; a.a_period = Ka; }
   a.tile_pref = (flags & 16) ? 1 : (flags & 32) ? 3 : 0;
-  a.ablate = (flags >> 8) & 127;
-  a.stagger = (flags >> 16) & 0xffff;
+  a.ablate = ((flags >> 8) & 255) | ((flags & (1 << 30)) ? 256 : 0);
   const long n = (long)taps * N * K;
   const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
   unsigned short* planes = nullptr;

@@ -814,9 +814,13 @@ void gemm_x6p_abl_kernel(GemmArgs a, int tiles_n, int n_tiles) {
   constexpr int EPI = EPI_LINEAR; constexpr bool GEN = false, AMUL = false, REC = true; constexpr int NP = 2;
 #define X6P_THREE 0
 #define X6P_ABL (ABLV & 15)
-#define X6P_EABL (ABLV >> 5)
+#define X6P_EABL ((ABLV >> 5) & 3)
 #define X6P_DEEP (!(ABLV & 16))
+#define X6P_NOMFMA ((ABLV >> 7) & 1)
+#define X6P_TRICKLE (ABLV >> 8)
 #include "gemm_x6p_body.inc"
+#undef X6P_TRICKLE
+#undef X6P_NOMFMA
 #undef X6P_EABL
 #undef X6P_DEEP
 #undef X6P_ABL
@@ -1303,7 +1307,7 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
       const size_t lds = wide ? X6P_LDS2W : X6P_LDS2R;
 #define ABL_CASE(V) case V: if (wide) hipLaunchKernelGGL((gemm_x6p_abl_kernel<V, true>), dim3(nb), dim3(256), lds, s, a, tiles_n, n_tiles); \
                             else hipLaunchKernelGGL((gemm_x6p_abl_kernel<V, false>), dim3(nb), dim3(256), lds, s, a, tiles_n, n_tiles); break;
-      switch (a.ablate) { ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(15) ABL_CASE(16) ABL_CASE(32) ABL_CASE(64) default: RAMP_REQUIRE(false, "ablation variant not built"); }
+      switch (a.ablate) { ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(15) ABL_CASE(16) ABL_CASE(32) ABL_CASE(64) ABL_CASE(128) ABL_CASE(136) ABL_CASE(129) ABL_CASE(130) ABL_CASE(131) ABL_CASE(160) ABL_CASE(192) ABL_CASE(144) ABL_CASE(288) ABL_CASE(416) default: RAMP_REQUIRE(false, "ablation variant not built"); }
 #undef ABL_CASE
     }
   } else if (wide) {
