@@ -11,11 +11,11 @@ import sys
 
 
 def klass(name):
-    if "gemm_x6" in name or "gemm_kernel" in name:
+    if "gemm_x6" in name or "gemm_kernel" in name or "ff_fwd_kernel" in name:
         return "gemm"
     if "attn2" in name:
         return "attention"
-    if "gn_" in name or "ln_" in name:
+    if "gn_" in name or "ln_" in name or "expand_rows" in name or "combine_rows" in name:
         return "norm_rows"
     if "ramp::" in name:
         return "other_ramp"
