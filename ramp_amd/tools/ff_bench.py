@@ -15,7 +15,7 @@ def t(M, N, K, mode, flags, iters=5):
     return us.value
 
 
-for M in (393216, 196608, 49152):
+for M in (393216, 196608, 98304, 49152):
     ff1 = min(t(M, 2048, 256, 3, 1 | 4) for _ in range(2))
     ff2 = min(t(M, 256, 1024, 3, 3) for _ in range(2))
     fused = min(t(M, 2048, 256, 5, 0) for _ in range(2))
