@@ -829,9 +829,10 @@ void gemm_x6p_abl_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 // ... or three (fp16x3: 168 VGPRs, 51 KB of LDS): a third resident block covers the epilogue-store stalls of the others;
 // the compiler spills registers around the epilogue (once per tile), none inside the slab loop.  Used where it
 // measured faster (launch_x6).
-template <int EPI, bool GEN, bool AMUL = false, int NP = 2, bool REC = true, bool WIDE = false>
+template <int EPI, bool GEN, bool AMUL = false, int NP = 2, bool REC = true, bool WIDE = false, bool PLAIN = false>   // PLAIN: no addend besides the bias
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
+#define X6P_PLAIN PLAIN
 #define X6P_THREE 1
 #define X6P_ABL 0
 #define X6P_EABL 0
@@ -840,6 +841,7 @@ void gemm_x6p3_kernel(GemmArgs a, int tiles_n, int n_tiles) {
 #undef X6P_EABL
 #undef X6P_DEEP
 #undef X6P_ABL
+#undef X6P_PLAIN
 #undef X6P_THREE
 }
 
@@ -1296,7 +1298,15 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
   // fp16x3 GEGLU forward (the kernel with the longest epilogue): 3 blocks per CU.  The plain shapes measured slower that
   // way (the ~60 registers spilled around every tile's epilogue cost more than the third block hides: 228 -> 172 TFLOP/s
   // at 393216 x 256 x 256), GEGLU forward faster (189 -> 201).
-  const bool three = a.wx_packed == 2 && !a.Amul && (EPI == EPI_GEGLU_FWD || a.tile_pref == 3);
+  // A third resident block where it measured faster (ramp_amd/tools, M = 49152 .. 393216): the bias-only epilogue (no residual /
+  // row-variant prefetch registers: 168 VGPRs without a spill) from four tiles per block up, +4..9 %; the A-multiplier kernel
+  // only where it turns two rounds into one (+13 %).  Fewer tiles per block lose more to the un-amortised prologue than the
+  // third block hides (-1..-40 %).
+  static const bool three_auto = [] { const char* e = getenv("RAMP_X6_THREE"); return !(e && e[0] == '0'); }();   // launch-plan knob
+  const bool plain = three_auto && EPI == EPI_LINEAR && wide && !a.Amul && !a.resid && !a.rowbias;
+  const bool three = a.wx_packed == 2 && (!a.Amul || wide) &&
+                     (EPI == EPI_GEGLU_FWD || a.tile_pref == 3 ||
+                      (a.tile_pref == 0 && ((plain && n_tiles >= 3072) || (three_auto && wide && a.Amul && n_tiles > 512 && n_tiles <= 768))));
   const int slots = three ? 768 : 512;
   const int rounds = (n_tiles + slots - 1) / slots;
   const int nb = std::min((((n_tiles + rounds - 1) / rounds + 7) / 8) * 8, slots);
@@ -1314,9 +1324,12 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
     if constexpr (!GEN) {
       if (a.Amul) {
         RAMP_REQUIRE(EPI == EPI_LINEAR && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
-        if constexpr (EPI == EPI_LINEAR)
-          hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
-      } else if (three) hipLaunchKernelGGL((gemm_x6p3_kernel<EPI, false, false, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
+        if constexpr (EPI == EPI_LINEAR) {
+          if (three) hipLaunchKernelGGL((gemm_x6p3_kernel<EPI_LINEAR, false, true, 2, true, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
+          else hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
+        }
+      } else if (three && EPI == EPI_LINEAR && !a.resid && !a.rowbias) hipLaunchKernelGGL((gemm_x6p3_kernel<EPI, false, false, 2, true, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
+      else if (three) hipLaunchKernelGGL((gemm_x6p3_kernel<EPI, false, false, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
       else hipLaunchKernelGGL((gemm_x6p_kernel<EPI, false, false, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
     }
   } else if (a.wx_packed && a.Amul) {
