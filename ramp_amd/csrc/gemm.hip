@@ -1323,7 +1323,7 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
   } else if (wide) {
     if constexpr (!GEN) {
       if (a.Amul) {
-        RAMP_REQUIRE(EPI == EPI_LINEAR && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
+        RAMP_REQUIRE(EPI == EPI_LINEAR && a.a_period > 0 && a.a_period % 32 == 0 && a.K == 2 * a.a_period && a.lda_mul % 4 == 0, "bad A-multiplier operand (K = 2 x period)");
         if constexpr (EPI == EPI_LINEAR) {
           if (three) hipLaunchKernelGGL((gemm_x6p3_kernel<EPI_LINEAR, false, true, 2, true, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
           else hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
@@ -1333,7 +1333,7 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
       else hipLaunchKernelGGL((gemm_x6p_kernel<EPI, false, false, 2, true, true>), dim3(nb), dim3(256), X6P_LDS2W, s, a, tiles_n, n_tiles);
     }
   } else if (a.wx_packed && a.Amul) {
-    RAMP_REQUIRE(EPI == EPI_LINEAR && !GEN && a.a_period > 0 && a.a_period % 32 == 0 && a.lda_mul % 4 == 0, "bad A-multiplier operand");
+    RAMP_REQUIRE(EPI == EPI_LINEAR && !GEN && a.a_period > 0 && a.a_period % 32 == 0 && a.K == 2 * a.a_period && a.lda_mul % 4 == 0, "bad A-multiplier operand (K = 2 x period)");
     if (a.wx_packed == 2) hipLaunchKernelGGL((gemm_x6p_kernel<EPI_LINEAR, false, true, 2, true>), dim3(nb), dim3(256), X6P_LDS2R, s, a, tiles_n, n_tiles);
     else if (rec) X6P_LAUNCH(EPI_LINEAR, false, true, 3, true);
     else X6P_LAUNCH(EPI_LINEAR, false, true, 3, false);
