@@ -36,7 +36,8 @@ typedef struct ramp_config {
   int32_t max_rows;        /* capacity in network rows per chunk (rows = B * n_rp)     */
   int32_t debug_taps;      /* 1: keep per-module outputs / output-grads for ramp_debug_read */
   int32_t gemm_mode;       /* 0 = library default (env RAMP_GEMM_MODE=fp32|bf16x6|fp16x3), 1 = exact fp32 MFMA, 2 = bf16x6 split,
-                            * 3 = fp16x3 split with delayed operand scaling (ramp_sample calibrates on its first evaluation,
+                            * 3 = fp16x3 split with delayed operand scaling (ramp_sample calibrates on its first evaluation
+                            *     unless it continues from the previous job, see ramp_set_calibration_reuse;
                             *     ramp_score keeps its calibration from call to call; see ramp_score) */
 } ramp_config;
 
