@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(const float* __restrict_
 }
 
 template <int L>
-__global__ __launch_bounds__(256, (L == 48 ? 3 : L == 24 ? 4 : 1)) void attn2_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, (L == 48 ? 3 : L == 24 ? 4 : L == 64 ? 2 : L == 32 ? 3 : 1)) void attn2_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                          float* __restrict__ dqkv, int n_pairs) {
   using C = A2<L>;
   extern __shared__ __attribute__((aligned(16))) float lds[];

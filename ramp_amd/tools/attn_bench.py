@@ -8,7 +8,7 @@ import torch  # noqa: E402
 from ramp_amd import _lib  # noqa: E402
 
 lib = _lib.load()
-for (R, L) in [(8192, 48), (4096, 48), (8192, 24), (8192, 12), (8192, 6)]:
+for (R, L) in [(8192, 48), (4096, 48), (8192, 24), (8192, 12), (8192, 6), (8192, 64), (8192, 32), (8192, 16), (8192, 8)]:
     qkv = torch.randn(R * L, 768, device="cuda")
     do = torch.randn(R * L, 256, device="cuda")
     o = torch.empty(R * L, 256, device="cuda")
