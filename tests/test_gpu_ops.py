@@ -57,6 +57,30 @@ def test_gemm_taps(M, N, K, taps, L, backward, mode):
     assert rel(out.cpu().numpy(), ref) < 3e-6
 
 
+@pytest.mark.parametrize("M,N,K,resid", [(70000, 768, 256, False), (66000, 1024, 256, False), (200000, 256, 768, False),
+                                         (200000, 256, 256, True)])
+def test_gemm_fp16x3_launch_rules_at_scale(M, N, K, resid):
+    """The fp16x3 launch rules that only many-tile launches reach (launch_x6, gemm.hip): a bias-only linear with at least
+    3072 tiles of 64 x 256 runs the three-blocks-per-CU kernel built with only that epilogue; with a residual it stays on
+    the two-block kernel.  Same bar as the small shapes, against float64 on the device; the launch repeats bit for bit."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=gen)
+    W = torch.randn(1, N, K, device="cuda", generator=gen) / np.sqrt(K)
+    bias = torch.randn(N, device="cuda", generator=gen)
+    R = torch.randn(M, N, device="cuda", generator=gen) if resid else None
+    out = torch.empty(M, N, device="cuda"); out2 = torch.empty(M, N, device="cuda")
+    _, flag = _lib.op_gemm(A, W, bias, R, out, M, N, K, 1, 0, 0, 1, mode="fp16x3")
+    _lib.op_gemm(A, W, bias, R, out2, M, N, K, 1, 0, 0, 1, mode="fp16x3")
+    assert flag == 0 and torch.equal(out, out2)
+    worst = 0.0
+    for r0 in range(0, M, 50000):                              # float64 reference in row blocks
+        ref = A[r0:r0 + 50000].double() @ W[0].double().T + bias.double()
+        if resid:
+            ref += R[r0:r0 + 50000].double()
+        worst = max(worst, float((out[r0:r0 + 50000].double() - ref).abs().max() / ref.abs().max()))
+    assert worst < 3e-6, worst
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 256, 256), (384, 768, 256), (1024, 256, 1024), (256, 512, 2048), (2048, 2048, 256),
                                    (128 * 37, 1024, 512)])
 @pytest.mark.parametrize("extras", [False, True])
