@@ -260,6 +260,15 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
                       int32_t M, int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step,
                       int32_t L, int32_t mode, float a_absmax_prev, float* a_absmax_out_host,
                       int32_t* range_flag_out_host, void* stream);
+/* the fused feed-forward with token-owning waves (ffx.hip) on raw weights, forward then (dz, dz1 non-NULL) backward:
+ *   z2 = z1 + W2 (a gelu(g)) + b2, [a | g] = W1 LN(z1; ln_g, ln_b) + b1          (reference: layers_attention_mini.py:38-45, 147)
+ *   dz1 = dz + LNbwd(W1^T [d(hg) gelu(g) | d(hg) a gelu'(g)]; z1), d(hg) = W2^T dz  (its input gradient)
+ * W1 (2048, 256) rows = 1024 value then 1024 gate features, W2 (256, 1024), z1 / dz / z2 / dz1 (M, 256), all device fp32.
+ * absmax_prev_host[4]: the operand maxima the delayed fp16 scaling assumes for LN(z1), a gelu(g), dz, d(ag) (0 = unscaled);
+ * absmax_out_host[4] the maxima recorded, *range_flag_out_host the range guard.  Packs the weights on every call (tests). */
+int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
+                const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
+                float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
 /* micro-benchmark (profiling tools only): one GEMM shape on the kernel `mode` names (as ramp_op_gemm_mode), operands
  * allocated and filled inside, weights packed once, `warmup` untimed then `iters` timed back-to-back launches on `stream`
  * between two HIP events; *avg_us = microseconds per launch.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue

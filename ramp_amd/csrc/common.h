@@ -88,6 +88,34 @@ int launch_ff_fwd(const GemmArgs& ff1, const GemmArgs& ff2, hipStream_t s);   //
 int init_gemm_attributes();        // raise the dynamic-LDS limit of every GEMM instantiation (once)
 int init_attention_attributes();   // same for the attention kernels
 
+// ---- fused feed-forward with token-owning waves (ffx.hip) ---------------------------------------
+// forward : Y = z2 (M,256) = z1 + W2 (a gelu(g)) + b2, [a | g] = W1 LN3(z1) + b1; writes the VJP stash (private layout)
+// backward: Y = dz1 (M,256) = dz + LN3bwd(W1^T [d(hg) s1 | d(hg) s2]; z1), d(hg) = W2^T dz; reads the stash
+struct FfxArgs {
+  int M = 0;
+  const float* X = nullptr;            // forward: z1; backward: dz
+  const float* Z1 = nullptr;           // z1 (forward: == X)
+  float* Y = nullptr;
+  float* stash = nullptr;              // ceil(M / 128) * 128 * 2048 floats, layout private to the two kernels
+  const float* ln_g = nullptr; const float* ln_b = nullptr;
+  const unsigned short* Wstream = nullptr;   // this direction's weight stream (ffx_build_stream): 96 slabs x 32 KB in consumption order
+  const float* b1 = nullptr;           // forward: b1 in the [32 a | 32 g] tiling (2048)
+  const float* b2 = nullptr;           // forward: b2 (256)
+  const float* amax_in1 = nullptr; float* amax_out1 = nullptr; float wsi1 = 1.f; int site1 = 0;   // first product's operand site
+  const float* amax_in2 = nullptr; float* amax_out2 = nullptr; float wsi2 = 1.f; int site2 = 0;   // second product's
+  int* range_flag = nullptr;
+  unsigned long long* stamps = nullptr; // diagnostic (ablate 64): per wave 4 cycle sums [slab-top wait, barrier, DMA issue, slab body]
+  int ablate = 0;                      // diagnostic (ramp_bench_gemm only; wrong results): 1 no LDS-DMA after the first slabs, 2 no stash traffic, 4 no elementwise step, 8 no slab barrier
+};
+int launch_ffx(const FfxArgs& f, bool bwd, hipStream_t s);
+// W [rows][cols] fp32 -> column-gathered copy (tmp, rows * cols floats) -> fragment-packed fp16 planes (out, 2 * rows * cols halves)
+int ffx_pack_second(const float* W, int rows, int cols, int mode, float scale, float* tmp, unsigned short* out, hipStream_t s);
+// p1: the first product's fragment-packed fp16 planes (forward: W1 tiled [32 a | 32 g], K = 256; backward: W2^T [1024][256]);
+// p2: the second product's, k order permuted by ffx_pack_second (forward: W2 [256][1024]; backward: W1^T [256][2048]);
+// out: 96 * 32 KB
+int ffx_build_stream(const unsigned short* p1, const unsigned short* p2, unsigned short* out, bool bwd, hipStream_t s);
+int init_ffx_attributes();
+
 // ---- row-wise ops (rowops.hip) --------------------------------------------------------------
 // GroupNorm over (L, C/8) per (row, group) [+ Mish] [+ per-channel time bias] [+ residual]
 struct GnArgs {

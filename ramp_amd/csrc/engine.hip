@@ -1087,6 +1087,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
   CK(init_gemm_q_attributes());
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
   CK(init_attention_attributes());
+  CK(init_ffx_attributes());
   c->finalized = true;
   return 0;
 }
@@ -1722,6 +1723,82 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
   RAMP_HIP_CHECK(e);
   return rc;
 }
+// ---- the token-owning fused feed-forward (ffx.hip) on raw fp32 weights: packs exactly as ramp_finalize_weights does --------
+namespace {
+struct FfxPack {
+  unsigned short *stream_f = nullptr, *stream_b = nullptr;   // 96 x 32 KB each
+  float *b1_pk = nullptr; float wsi_w1 = 1.f, wsi_w2 = 1.f;
+};
+// W1 [2048][256] (rows: 1024 a then 1024 g), W2 [256][1024]; everything allocated from `ar`
+int ffx_pack_all(DevArena& ar, const float* W1, const float* b1, const float* W2, FfxPack* out, hipStream_t s) {
+  auto maxabs = [&](const float* d, size_t n, float* sc) -> int {
+    std::vector<float> hw(n);
+    RAMP_HIP_CHECK(hipMemcpy(hw.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
+    float mx = 0.f; for (float v : hw) mx = std::max(mx, std::fabs(v));
+    *sc = 1.f;
+    if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); *sc = std::ldexp(1.f, 11 - e); }
+    return 0;
+  };
+  float sc1 = 1.f, sc2 = 1.f;
+  CK(maxabs(W1, 2048 * 256, &sc1)); CK(maxabs(W2, 256 * 1024, &sc2));
+  float* w1_pk = ar.alloc(2048 * 256); out->b1_pk = ar.alloc(2048);
+  float* w1t = ar.alloc(2048 * 256); float* w2t = ar.alloc(1024 * 256); float* tmp = ar.alloc(2048 * 256);
+  auto planes = [&](size_t n) { return reinterpret_cast<unsigned short*>(ar.alloc(n + 4)); };   // 2 n halves
+  unsigned short *p_w1 = planes(2048 * 256), *p_w2p = planes(256 * 1024), *p_w2t = planes(1024 * 256), *p_w1tp = planes(256 * 2048);
+  out->stream_f = planes(96 * 8192); out->stream_b = planes(96 * 8192);
+  RAMP_REQUIRE(w1_pk && out->b1_pk && w1t && w2t && tmp && p_w1 && p_w2p && p_w2t && p_w1tp && out->stream_f && out->stream_b, "hipMalloc failed");
+  hipLaunchKernelGGL(geglu_pack_kernel, dim3(1024), dim3(256), 0, s, W1, w1_pk, 1024, 256, 32);
+  hipLaunchKernelGGL(geglu_pack_kernel, dim3(8), dim3(256), 0, s, b1, out->b1_pk, 1024, 1, 32);
+  hipLaunchKernelGGL(permute3_kernel, dim3(2048), dim3(256), 0, s, W1, w1t, 2048, 256, 1, 1, 0, 2);      // [256][2048]
+  hipLaunchKernelGGL(permute3_kernel, dim3(1024), dim3(256), 0, s, W2, w2t, 256, 1024, 1, 1, 0, 2);      // [1024][256]
+  RAMP_HIP_CHECK(hipGetLastError());
+  CK(launch_pack_h3(w1_pk, p_w1, 2048, 256, sc1, s));
+  CK(ffx_pack_second(W2, 256, 1024, 0, sc2, tmp, p_w2p, s));
+  CK(launch_pack_h3(w2t, p_w2t, 1024, 256, sc2, s));
+  CK(ffx_pack_second(w1t, 256, 2048, 1, sc1, tmp, p_w1tp, s));
+  CK(ffx_build_stream(p_w1, p_w2p, out->stream_f, false, s));
+  CK(ffx_build_stream(p_w2t, p_w1tp, out->stream_b, true, s));
+  out->wsi_w1 = 1.f / sc1; out->wsi_w2 = 1.f / sc2;
+  return 0;
+}
+}  // namespace
+
+int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
+                const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
+                float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  RAMP_REQUIRE(z1 && W1 && b1 && W2 && b2 && ln_g && ln_b && z2 && M > 0, "null argument");
+  hipStream_t s = as_stream(stream);
+  DevArena ar;
+  FfxPack pk;
+  CK(ffx_pack_all(ar, W1, b1, W2, &pk, s));
+  const size_t mt = ((size_t)M + 127) / 128;
+  float* stash = ar.alloc(mt * 128 * 2048); float* slots = ar.alloc(12);
+  RAMP_REQUIRE(stash && slots, "hipMalloc failed");
+  float host[12] = {0};
+  for (int i = 0; i < 4; ++i) host[i] = absmax_prev_host ? absmax_prev_host[i] : 0.f;
+  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
+  FfxArgs f; f.M = M; f.X = z1; f.Z1 = z1; f.Y = z2; f.stash = stash; f.ln_g = ln_g; f.ln_b = ln_b; f.Wstream = pk.stream_f;
+  f.b1 = pk.b1_pk; f.b2 = b2; f.range_flag = reinterpret_cast<int*>(slots + 8);
+  f.amax_in1 = host[0] > 0.f ? slots + 0 : nullptr; f.amax_out1 = slots + 4; f.wsi1 = pk.wsi_w1; f.site1 = 0;
+  f.amax_in2 = host[1] > 0.f ? slots + 1 : nullptr; f.amax_out2 = slots + 5; f.wsi2 = pk.wsi_w2; f.site2 = 1;
+  int rc = launch_ffx(f, false, s);
+  if (rc == 0 && dz && dz1) {
+    FfxArgs g; g.M = M; g.X = dz; g.Z1 = z1; g.Y = dz1; g.stash = stash; g.ln_g = ln_g; g.ln_b = ln_b; g.Wstream = pk.stream_b;
+    g.range_flag = reinterpret_cast<int*>(slots + 8);
+    g.amax_in1 = host[2] > 0.f ? slots + 2 : nullptr; g.amax_out1 = slots + 6; g.wsi1 = pk.wsi_w2; g.site1 = 2;
+    g.amax_in2 = host[3] > 0.f ? slots + 3 : nullptr; g.amax_out2 = slots + 7; g.wsi2 = pk.wsi_w1; g.site2 = 3;
+    rc = launch_ffx(g, true, s);
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  if (rc == 0 && e == hipSuccess) {
+    e = hipMemcpy(host, slots, sizeof(host), hipMemcpyDeviceToHost);
+    if (absmax_out_host) for (int i = 0; i < 4; ++i) absmax_out_host[i] = host[4 + i];
+    if (range_flag_out_host) std::memcpy(range_flag_out_host, &host[8], 4);
+  }
+  RAMP_HIP_CHECK(e);
+  return rc;
+}
+
 // micro-benchmark of one GEMM shape on a named kernel: packs once, `warmup` + `iters` back-to-back launches on `stream`,
 // HIP events around the timed ones.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue (N = 2F, writes the F-wide
 // product too), 8 A-multiplier operand (K = 2 * period).  Operands are allocated and filled here (uniform [-1, 1)).
@@ -1733,7 +1810,53 @@ __global__ void fill_uniform_kernel(float* p, long n, unsigned seed, float scale
 }
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 5, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 7, "bad arguments");
+  if (mode == 6 || mode == 7) {                        // ffx.hip: fused feed-forward with token-owning waves, forward / backward
+    hipStream_t s6 = as_stream(stream);
+    DevArena ar6;
+    const size_t mt = ((size_t)M + 127) / 128;
+    float* z1 = ar6.alloc((size_t)M * 256); float* dz = ar6.alloc((size_t)M * 256); float* out = ar6.alloc((size_t)M * 256);
+    float* W1 = ar6.alloc(2048 * 256); float* W2 = ar6.alloc(256 * 1024); float* b1 = ar6.alloc(2048); float* b2 = ar6.alloc(256);
+    float* lg = ar6.alloc(256); float* lb = ar6.alloc(256); float* stash = ar6.alloc(mt * 128 * 2048); float* sl = ar6.alloc(12);
+    RAMP_REQUIRE(z1 && dz && out && W1 && W2 && b1 && b2 && lg && lb && stash && sl, "hipMalloc failed");
+    auto fill6 = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s6, p, (long)n, seed, sc); };
+    fill6(z1, (size_t)M * 256, 1u, 1.f); fill6(dz, (size_t)M * 256, 7u, 1.f); fill6(W1, 2048 * 256, 2u, 1.f / 16.f); fill6(W2, 256 * 1024, 3u, 1.f / 32.f);
+    fill6(b1, 2048, 5u, 1.f); fill6(b2, 256, 6u, 1.f); fill6(lg, 256, 8u, 1.f); fill6(lb, 256, 9u, 1.f);
+    FfxPack pk;
+    CK(ffx_pack_all(ar6, W1, b1, W2, &pk, s6));
+    const float one[12] = {4.f, 2.f, 1.f, 1.f, 0, 0, 0, 0, 0, 0, 0, 0};
+    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, s6));
+    FfxArgs f; f.M = M; f.X = z1; f.Z1 = z1; f.Y = out; f.stash = stash; f.ln_g = lg; f.ln_b = lb; f.Wstream = pk.stream_f; f.b1 = pk.b1_pk; f.b2 = b2;
+    f.amax_in1 = sl; f.amax_out1 = sl + 4; f.wsi1 = pk.wsi_w1; f.amax_in2 = sl + 1; f.amax_out2 = sl + 5; f.wsi2 = pk.wsi_w2; f.site2 = 1;
+    f.range_flag = reinterpret_cast<int*>(sl + 8); f.ablate = (flags >> 8) & 255;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ar6.alloc(256 * 4 * 4 * 2));
+    if (f.ablate & 64) { RAMP_REQUIRE(stamps, "hipMalloc failed"); RAMP_HIP_CHECK(hipMemsetAsync(stamps, 0, 256 * 4 * 4 * 8, s6)); f.stamps = stamps; }
+    FfxArgs g = f; g.X = dz; g.Wstream = pk.stream_b; g.amax_in1 = sl + 2; g.amax_out1 = sl + 6; g.wsi1 = pk.wsi_w2; g.amax_in2 = sl + 3; g.amax_out2 = sl + 7; g.wsi2 = pk.wsi_w1;
+    CK(launch_ffx(f, false, s6));                        // the backward kernel reads this stash
+    auto go6 = [&]() { return mode == 6 ? launch_ffx(f, false, s6) : launch_ffx(g, true, s6); };
+    for (int i = 0; i < warmup; ++i) CK(go6());
+    hipEvent_t e0, e1;
+    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+    RAMP_HIP_CHECK(hipEventRecord(e0, s6));
+    int rc6 = 0;
+    for (int i = 0; i < iters && rc6 == 0; ++i) rc6 = go6();
+    RAMP_HIP_CHECK(hipEventRecord(e1, s6));
+    RAMP_HIP_CHECK(hipEventSynchronize(e1));
+    float ms6 = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&ms6, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = ms6 * 1e3f / iters;
+    if (rc6 == 0 && (f.ablate & 64)) {                   // per-wave cycle sums of the LAST launch, averaged, on stderr
+      std::vector<unsigned long long> h(256 * 4 * 4);
+      RAMP_HIP_CHECK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+      double sm[4] = {0, 0, 0, 0}; int nw = 0;
+      for (int w = 0; w < 1024; ++w) if (h[w * 4 + 3]) { ++nw; for (int j = 0; j < 4; ++j) sm[j] += (double)h[w * 4 + j]; }
+      const double slabs = std::max(1, nw) * 96.0 * (double)((mt + 255) / 256);
+      fprintf(stderr, "[ffx stamps] per slab (s_memtime ticks): vm wait %.0f, barrier %.0f, DMA issue %.0f, body %.0f (%d waves)\n",
+              sm[0] / slabs, sm[1] / slabs, sm[2] / slabs, sm[3] / slabs, nw);
+    }
+    return rc6;
+  }
   if (mode == 5) {                                     // the fused FF1 -> GEGLU -> FF2 kernel (N, K ignored: 256 -> 2 x 1024 -> 256)
     hipStream_t s5 = as_stream(stream);
     DevArena ar5;

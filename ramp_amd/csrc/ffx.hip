@@ -1,0 +1,655 @@
+// Fused feed-forward of one transformer block, both directions, as TOKEN-OWNING waves (layers_attention_mini.py:38-45,
+// 130-149: z2 = z1 + W2 (a * gelu(g)) + b2, [a | g] = W1 LN3(z1) + b1, and its input gradient).
+//
+// Why another dataflow (profiles/r02_*): the tile kernels move every K = 256 layer through HBM (1 KB in, 1-8 KB out per
+// token and layer) and re-stage the activation tile once per 256 output columns; the two-role fused forward kernel
+// (gemm.hip, ff_fwd_kernel) still round-trips the hidden through LDS, re-splits the activation tile eight times per M-tile
+// and its two roles' work adds up.  Here nothing but the weights moves during the 32 hidden-unit steps of a token tile:
+//
+//   * a block = 4 waves = 128 tokens, wave w OWNS tokens [32 w, 32 w + 32) of the tile for the whole feed-forward;
+//   * every product is computed TRANSPOSED, D^T[feature][token] = W[feature][k] * X^T[k][token]: the weight fragment is
+//     the MFMA's A operand, the wave's tokens are the B operand, and the accumulator holds, per lane, ONE token and 16
+//     features.  The LayerNorm output (forward) / dz (backward) of the wave's 32 tokens stays in registers for the whole
+//     tile as two scaled fp16 planes (128 VGPRs), the 256-wide result accumulates in 128 more;
+//   * GEGLU is lane-local: the a- and g-accumulators of a hidden unit hold the same (token, j) in the same lane and
+//     register, and after the split into planes those registers ARE the B operand of the second product (the k order of
+//     its weight fragments is permuted at pack time to the accumulator's row order) -- the hidden never leaves registers;
+//   * the VJP stash [gelu(g) | a gelu'(g)] is written in the accumulator's own layout (1 KB per store instruction, fully
+//     coalesced) and read back the same way by the backward kernel; no other kernel ever looks at it;
+//   * LayerNorm-3 forward (prologue) and backward (epilogue) run on the registers the tile already holds: a token's row is
+//     split over lanes r and r + 32, one shuffle per row sum.  ln_fwd / ln_bwd and their HBM round trips disappear;
+//   * the weights (3 MB of fp16 planes per direction) stream through a 4-slot x 32 KB LDS ring filled by LDS-DMA
+//     (global_load_lds, 1 KB per wave instruction, each wave issues a quarter of every slab): every fragment is fetched
+//     ONCE per 128 tokens instead of once per 64, costs no VGPR and no VALU, and is read by ds_read_b128 at lane * 16.
+//     One workgroup barrier per slab (= 48 MFMAs per wave), placed so that the next slab's first fragments are read
+//     before it (no bubble): the barrier at the top of slab g certifies slab g + 1 and frees the slot of slab g - 1.
+//
+// Arithmetic is the fp16x3 split of gemm.hip (two scaled fp16 planes per operand, h1h1' + h1h2' + h2h1', fp32 accumulate),
+// same delayed per-call-site scales, maxima recording and range guard: the kernels consume the call sites of the launches
+// they replace (forward: FF1, FF2; backward: d(hg), FF1-dX) in the same order.
+#include "common.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace ramp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int FX_SLAB = 32 * 1024;                      // bytes per ring slot: 8 macro-steps x 4 fragments x 1 KB
+constexpr int FX_R = 4;                                 // ring slots
+constexpr int FX_B1 = FX_R * FX_SLAB;                   // forward: the packed b1 (2048 floats) behind the ring
+constexpr size_t FX_LDS = (size_t)FX_R * FX_SLAB + 2048 * 4;
+constexpr int FX_SLABS = 96;                            // slabs per 128-token tile (32 units x 3)
+static_assert(FX_LDS <= 160 * 1024, "LDS budget");
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* glb_ptr_t;
+__device__ __forceinline__ void glds16(const void* src, char* dst) {
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)(uintptr_t)src, (lds_ptr_t)(unsigned)(uintptr_t)dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ float scale_of(const float* p) {      // 2^(5 - floor(log2 max)): the operand lands in [2^5, 2^6)
+  float s = 1.f;
+  const float mx = p ? *p : 0.f;
+  if (mx > 0.f) {
+    int eb = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu);
+    int sb = 259 - eb;
+    sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+    s = __builtin_bit_cast(float, (unsigned)sb << 23);
+  }
+  return s;
+}
+// Phi(x), phi(x) from one exp2 and one rcp (A&S 26.2.17; same evaluation as gemm.hip's GEGLU epilogues)
+__device__ __forceinline__ void cdf_pdf(float x, float& cdf, float& pdf) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316419f, ax, 1.f));
+  pdf = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f) * 0.39894228040143267794f;
+  float poly = fmaf(1.330274429f, t, -1.821255978f);
+  poly = fmaf(poly, t, 1.781477937f);
+  poly = fmaf(poly, t, -0.356563782f);
+  poly = fmaf(poly, t, 0.319381530f);
+  const float q = pdf * (poly * t);
+  cdf = x >= 0.f ? 1.f - q : q;
+}
+// eight scaled floats -> their two fp16 planes (8 halves each): hi = rn(x), lo = rn(x - hi)
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
+  const half2v h0 = __builtin_convertvector(f32x2{a[0], a[1]}, half2v), h1 = __builtin_convertvector(f32x2{a[2], a[3]}, half2v);
+  const half2v h2 = __builtin_convertvector(f32x2{b[0], b[1]}, half2v), h3 = __builtin_convertvector(f32x2{b[2], b[3]}, half2v);
+  const f32x2 r0 = __builtin_convertvector(h0, f32x2), r1 = __builtin_convertvector(h1, f32x2);
+  const f32x2 r2 = __builtin_convertvector(h2, f32x2), r3 = __builtin_convertvector(h3, f32x2);
+  const half2v l0 = __builtin_convertvector(f32x2{a[0] - r0[0], a[1] - r0[1]}, half2v);
+  const half2v l1 = __builtin_convertvector(f32x2{a[2] - r1[0], a[3] - r1[1]}, half2v);
+  const half2v l2 = __builtin_convertvector(f32x2{b[0] - r2[0], b[1] - r2[1]}, half2v);
+  const half2v l3 = __builtin_convertvector(f32x2{b[2] - r3[0], b[3] - r3[1]}, half2v);
+  hi = u32x4{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+  lo = u32x4{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1), __builtin_bit_cast(unsigned, l2), __builtin_bit_cast(unsigned, l3)};
+}
+__device__ __forceinline__ float amax4(const f32x4 v, float m) {
+  m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), m);
+  return fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), m);
+}
+__device__ __forceinline__ f32x16 mfma16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 quad(const f32x16& v, int q) { return f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; }
+
+}  // namespace
+
+// slab kinds: which product a 32 KB slab of weight fragments feeds
+enum { K_P1A = 0, K_P1B = 1, K_P2A = 2, K_P2B = 3 };
+template <int V> using FO = std::integral_constant<int, V>;
+
+// ABL (diagnostic twins for ramp_bench_gemm, wrong results; 0 in the product): 1 no LDS-DMA after the first slabs, 2 no stash
+// traffic, 4 no elementwise step, 8 no slab barrier -- compile-time, a run-time test inside the slabs would split their
+// scheduling regions
+template <bool BWD, int ABL = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void ffx_kernel(FfxArgs f, int n_mt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int n_my = (n_mt - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // >= 1 (grid <= n_mt)
+  const int total_slabs = n_my * FX_SLABS;
+
+  const float s_1 = scale_of(f.amax_in1), s_2 = scale_of(f.amax_in2);
+  const float os1 = f.wsi1 / s_1, os2 = f.wsi2 / s_2;
+  float amax1 = 0.f, amax2 = 0.f;
+
+  // ---- weight ring: the tile's 96 slabs lie in consumption order in ONE 3 MB stream (ffx_build_stream), so a slab is one
+  // pointer step: wave w copies bytes [8 w KB, 8 w KB + 8 KB) of it as 8 LDS-DMA pieces of 1 KB, one per macro-step.
+  // The pieces are inline asm: with __builtin_amdgcn_global_load_lds in the kernel hipcc stops counting LDS returns and waits
+  // lgkmcnt(0) before every fragment use.  The compiler's own vmcnt waits stay safe: operations it does not know about are
+  // younger or older IN ORDER, so its counts can only over-wait.  m0 = LDS address of the piece group; the instruction offset
+  // applies to both addresses.  (Measured alternative: global_load_dwordx4 into staging registers + ds_write_b128 one slab
+  // later -- two instructions the compiler can place freely -- is 15 % slower than the DMA.)
+  const char* wsrc = reinterpret_cast<const char*>(f.Wstream) + wave * 8192 + lane * 16;
+  int is_q = 0, is_g = 0;                                   // next slab to issue: position in the tile's sequence, global count
+  const char* cur_src = wsrc; unsigned cur_dst = 0;        // the slab being issued piece by piece
+  auto dma_begin = [&]() __attribute__((always_inline)) {
+    cur_src = wsrc + (long)is_q * FX_SLAB;
+    cur_dst = (unsigned)(uintptr_t)(smem + (is_g & (FX_R - 1)) * FX_SLAB + wave * 8192);
+    is_q = is_q + 1 == FX_SLABS ? 0 : is_q + 1;
+    ++is_g;
+  };
+#define FX_PIECE(C) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" \
+                                 :: "v"(cur_src + ((C) >> 2) * 4096), "s"(cur_dst + ((C) >> 2) * 4096), "n"(((C) & 3) * 1024) : "memory", "m0")
+  auto dma_piece = [&](int c) __attribute__((always_inline)) {       // c: compile-time after unrolling
+    switch (c) { case 0: FX_PIECE(0); break; case 1: FX_PIECE(1); break; case 2: FX_PIECE(2); break; case 3: FX_PIECE(3); break;
+                 case 4: FX_PIECE(4); break; case 5: FX_PIECE(5); break; case 6: FX_PIECE(6); break; default: FX_PIECE(7); break; }
+  };
+  auto issue_slab = [&]() __attribute__((always_inline)) {           // (prologue only: a whole slab at once)
+    dma_begin();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dma_piece(c);
+  };
+
+  // ---- consumer state ------------------------------------------------------------------------------------------------
+  u32x4 F[3][4];                                            // fragment ring: macro-step m of a slab in F[(m + fo) % 3], two steps ahead of the MFMAs
+  int g = 0;                                                // slabs consumed so far (ring position)
+  const char* rd = smem + lane * 16;
+  auto read_macro = [&](u32x4 (&dst)[4], int slot, int m) __attribute__((always_inline)) {
+    const char* p = rd + slot * FX_SLAB + m * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const u32x4*>(p + i * 1024);
+  };
+  // top of slab g: slab g + 1 is certified (every wave's share has landed: its pieces were issued during slab g - 2, the only
+  // younger LDS-DMA are my 8 pieces of slab g + 2), the slot of slab g - 1 is free -> slab g + 3, one piece per macro-step of
+  // slab g, behind an MFMA (issued back to back at the slab top the eight pieces held the wave for ~700 cycles).  The pieces
+  // are issued unconditionally: past the block's last slab they refill the free slot with bytes nobody reads.
+  unsigned long long tk[4] = {0, 0, 0, 0}, tlast = 0;
+  auto slab_top = [&]() __attribute__((always_inline)) {
+    if (ABL & 64) {                                          // diagnostic: where a slab's cycles go (s_memtime perturbs the LDS waits a little)
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      if (tlast) tk[3] += t0 - tlast;
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      dma_begin();
+      tlast = __builtin_amdgcn_s_memtime();
+      tk[0] += t1 - t0; tk[1] += t2 - t1; tk[2] += tlast - t2;
+      return;
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+    dma_begin();
+  };
+
+  u32x4 XB[16][2];                                          // the wave's tokens as B operand: [k16 step][plane]
+  f32x16 acc2[8];                                           // 256 features x 32 tokens
+  f32x16 acc1[2][BWD ? 1 : 2];                              // [unit parity][a, g] (backward: d(hg))
+  u32x4 HB[BWD ? 4 : 2][2];                                 // the second product's B operand: [k16 step][plane]
+  f32x4 st1[BWD ? 4 : 1], st2[BWD ? 4 : 1];                 // backward: the stash of the unit E works on next
+
+  // six MFMAs of a macro-step: small terms first (lo x hi, hi x lo, hi x hi), two k16 steps or two accumulators.
+  // Issue order, pinned with sched_barrier: MFMA 1 | two ds_read_b128 | MFMAs 2..4 | two ds_read_b128 | MFMAs 5, 6 + side work
+  // (at most two fragment reads per MFMA gap: a third saturates the LDS array).
+  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define FX_MAC_HEAD(X, BX, FB, Z) X = mfma16(FB[1], BX[0], (Z) ? zero16 : X)
+#define FX_MAC_MID(X, Y, BX, BY, FB, Z)                                \
+  do {                                                                 \
+    X = mfma16(FB[0], BX[1], X); X = mfma16(FB[0], BX[0], X);          \
+    Y = mfma16(FB[3], BY[0], (Z) ? zero16 : Y);                        \
+  } while (0)
+#define FX_MAC_TAIL(Y, BY, FB) do { Y = mfma16(FB[2], BY[1], Y); Y = mfma16(FB[2], BY[0], Y); } while (0)
+
+  // one slab = 8 macro-steps.  The fragment reads run TWO macro-steps ahead of the MFMAs (three buffers: the registers a
+  // read overwrites were last used two steps ago, and its data has ~380 cycles to land): entering a slab, its macro 0 and 1
+  // are already in F[FO % 3], F[(FO + 1) % 3]; leaving it, macro 0 and 1 of the NEXT slab are (8 = 2 mod 3: FO advances by 2).
+  auto slab = [&](auto kind_c, auto fo_c, int par, auto side) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value, FO = decltype(fo_c)::value;
+    slab_top();
+    const int slot = g & (FX_R - 1), nslot = (g + 1) & (FX_R - 1);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      u32x4 (&FB)[4] = F[(m + FO) % 3];
+      u32x4 (&FN)[4] = F[(m + 2 + FO) % 3];
+      const char* np = rd + (m < 6 ? slot * FX_SLAB + (m + 2) * 4096 : nslot * FX_SLAB + (m - 6) * 4096);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!BWD) {
+        if constexpr (KIND == K_P1A || KIND == K_P1B) FX_MAC_HEAD(acc1[par][0], XB[8 * KIND + m], FB, KIND == K_P1A && m == 0);
+        else FX_MAC_HEAD(acc2[m], HB[0], FB, false);
+      } else {
+        if constexpr (KIND == K_P1A) FX_MAC_HEAD(acc1[par][0], XB[2 * m], FB, m == 0);
+        else FX_MAC_HEAD(acc2[4 * (KIND - K_P2A) + (m >> 1)], HB[2 * (m & 1)], FB, false);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ABL & 1)) dma_piece(m);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- one scheduling region: the four fragment reads, MFMAs 2..6 and this step's share of the elementwise work ----
+#pragma unroll
+      for (int i = 0; i < 4; ++i) FN[i] = *reinterpret_cast<const u32x4*>(np + i * 1024);
+      if constexpr (!BWD) {
+        if constexpr (KIND == K_P1A || KIND == K_P1B) {
+          const int s = 8 * KIND + m;
+          FX_MAC_MID(acc1[par][0], acc1[par][1], XB[s], XB[s], FB, KIND == K_P1A && m == 0); FX_MAC_TAIL(acc1[par][1], XB[s], FB);
+        } else { FX_MAC_MID(acc2[m], acc2[m], HB[0], HB[1], FB, false); FX_MAC_TAIL(acc2[m], HB[1], FB); }
+      } else {
+        if constexpr (KIND == K_P1A) { FX_MAC_MID(acc1[par][0], acc1[par][0], XB[2 * m], XB[2 * m + 1], FB, false); FX_MAC_TAIL(acc1[par][0], XB[2 * m + 1], FB); }
+        else {
+          const int kb = 4 * (KIND - K_P2A) + (m >> 1), t = 2 * (m & 1);
+          FX_MAC_MID(acc2[kb], acc2[kb], HB[t], HB[t + 1], FB, false); FX_MAC_TAIL(acc2[kb], HB[t + 1], FB);
+        }
+      }
+      side(m);
+      // issue order hints: 2 reads | MFMA + up to 7 vector instructions, five times, the other 2 reads after the second MFMA
+      // (at most two fragment reads per MFMA gap: a third saturates the LDS array)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ++g;
+  };
+  auto no_side = [](int) __attribute__((always_inline)) {};
+
+  // ---- prologue: b1 into LDS, first three slabs in flight --------------------------------------------------------------
+  if (!BWD) {
+    float* b1s = reinterpret_cast<float*>(smem + FX_B1);
+    for (int i = tid; i < 512; i += 256) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(f.b1)[i];
+  }
+  issue_slab(); issue_slab(); issue_slab();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // slab 0 (my share)
+  __syncthreads();                                           // (also publishes b1 in LDS)
+  read_macro(F[0], 0, 0); read_macro(F[1], 0, 1);
+
+  const float* b1s = reinterpret_cast<const float*>(smem + FX_B1);
+
+  for (int ti = 0; ti < n_my; ++ti) {
+    const int mt = (int)blockIdx.x + ti * (int)gridDim.x;
+    const long tok = (long)mt * 128 + wave * 32 + r;
+    const bool tok_ok = tok < f.M;
+    const long tokc = tok_ok ? tok : f.M - 1;
+    float* stash_w = f.stash + (((long)mt * 32) * 4 + wave) * 2048 + lane * 4;      // + unit * 8192 + (2 q + which) * 256
+
+    // ---- the wave's 32 tokens -> B-operand planes (forward: through LayerNorm-3) ---------------------------------------
+    {
+      const float* xrow = f.X + tokc * 256 + 8 * h;          // lane (r, h) holds k = 16 s + 8 h + i of token r
+      f32x4 xv[32];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        xv[2 * s] = *reinterpret_cast<const f32x4*>(xrow + 16 * s);
+        xv[2 * s + 1] = *reinterpret_cast<const f32x4*>(xrow + 16 * s + 4);
+      }
+      if (!BWD) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.f / 256.f);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
+        ss += __shfl_xor(ss, 32);
+        const float rstd = 1.f / sqrtf(ss * (1.f / 256.f) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const int k = 16 * (i >> 1) + 8 * h + 4 * (i & 1);
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(f.ln_g + k), bt = *reinterpret_cast<const f32x4*>(f.ln_b + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[i][e] = (xv[i][e] - mean) * rstd * gm[e] + bt[e];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        amax1 = amax4(xv[2 * s], amax1); amax1 = amax4(xv[2 * s + 1], amax1);
+        split8(xv[2 * s] * s_1, xv[2 * s + 1] * s_1, XB[s][0], XB[s][1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+
+    auto stash_load = [&](int u) __attribute__((always_inline)) {                           // backward: prefetch unit u's stash
+      if (BWD && !(ABL & 2)) {
+        const float* p = stash_w + (long)u * 8192;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          st1[BWD ? q : 0] = *reinterpret_cast<const f32x4*>(p + (2 * q) * 256);
+          st2[BWD ? q : 0] = *reinterpret_cast<const f32x4*>(p + (2 * q + 1) * 256);
+        }
+      }
+    };
+    // E(u): the elementwise step between the two products, on acc1[par], cut into work items that the slabs of a group
+    // take one at a time (E_step): forward 16 elements (one GEGLU each; a quad's stash rows leave with its last element)
+    // and 2 plane packs, backward 4 quads and 4 packs.
+    f32x4 hq[BWD ? 8 : 4];                                   // forward: h quads; backward: [da quads | dg quads]
+    f32x4 ba, bg;                                            // forward: b1 of the quad whose stage 0 comes next
+    // forward: GEGLU of one quad (four independent dependency chains: a lone wave has nothing else to fill the vector
+    // latencies with) in three stages of ~30 vector instructions, one stage per macro-step
+    // (the bias quad of the NEXT stage 0 is read during stage 1: read where it is used, the fma behind it exposes the LDS latency)
+    f32x4 qa, qg, qt, qp;                                    // the quad in progress: a, g, t = 1 / (1 + p |g|) then Phi(g), phi(g)
+    auto bias_load = [&](int u, int q) __attribute__((always_inline)) {
+      if constexpr (!BWD) {
+        ba = *reinterpret_cast<const f32x4*>(b1s + (2 * u) * 32 + 8 * q + 4 * h);
+        bg = *reinterpret_cast<const f32x4*>(b1s + (2 * u + 1) * 32 + 8 * q + 4 * h);
+      }
+    };
+    bias_load(0, 0);
+    auto geglu_stage = [&](int u, int par, int q, int st) __attribute__((always_inline)) {
+      if constexpr (!BWD) {
+        if (ABL & 128) {                                     // diagnostic: two instructions per element instead of ~30
+          if (st == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hq[q][e] = fmaf(acc1[par][0][4 * q + e], os1, acc1[par][1][4 * q + e]) * s_2;
+          }
+          return;
+        }
+        if (st == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            qa[e] = fmaf(acc1[par][0][4 * q + e], os1, ba[e]);
+            qg[e] = fmaf(acc1[par][1][4 * q + e], os1, bg[e]);
+            qt[e] = __builtin_amdgcn_rcpf(fmaf(0.2316419f, fabsf(qg[e]), 1.f));
+            qp[e] = __builtin_amdgcn_exp2f(qg[e] * qg[e] * -0.72134752044448170368f) * 0.39894228040143267794f;
+          }
+        } else if (st == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float poly = fmaf(1.330274429f, qt[e], -1.821255978f);
+            poly = fmaf(poly, qt[e], 1.781477937f);
+            poly = fmaf(poly, qt[e], -0.356563782f);
+            poly = fmaf(poly, qt[e], 0.319381530f);
+            const float qq = qp[e] * (poly * qt[e]);
+            qt[e] = qg[e] >= 0.f ? 1.f - qq : qq;            // Phi(g)
+          }
+          if (q < 3) bias_load(u, q + 1); else bias_load(u < 31 ? u + 1 : 31, 0);
+        } else {
+          f32x4 s1, s2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s1[e] = qg[e] * qt[e];                            // gelu(g)
+            s2[e] = qa[e] * fmaf(qg[e], qp[e], qt[e]);        // a * gelu'(g)
+            const float hv = qa[e] * s1[e];                   // a * gelu(g)
+            amax2 = fmaxf(fabsf(hv), amax2);
+            hq[q][e] = hv * s_2;
+          }
+          if (!(ABL & 2)) {
+            float* p = stash_w + (long)u * 8192;
+            *reinterpret_cast<f32x4*>(p + (2 * q) * 256) = s1;
+            *reinterpret_cast<f32x4*>(p + (2 * q + 1) * 256) = s2;
+          }
+        }
+      }
+    };
+    auto quad_b = [&](int par, int q) __attribute__((always_inline)) {
+      if constexpr (BWD) {
+        const f32x4 d = quad(acc1[par][0], q) * os1;
+        const f32x4 da = d * st1[q], dg = d * st2[q];
+        amax2 = amax4(da, amax2); amax2 = amax4(dg, amax2);
+        hq[q] = da * s_2; hq[4 + q] = dg * s_2;
+      }
+    };
+    auto pack1 = [&](int t) __attribute__((always_inline)) { split8(hq[2 * t], hq[2 * t + 1], HB[t][0], HB[t][1]); };
+    // step idx of n: forward items = the quads' stages and the two packs (a pack not before step `pack_from`: the second
+    // product still reads HB),
+    // backward items q0..q3 [stash prefetch of unit u + 1] P0..P3, the packs not before step `pack_from`
+    auto E_step = [&](int u, int par, int idx, int n, int pack_from) __attribute__((always_inline)) {
+      if (ABL & 4) return;
+      if constexpr (!BWD) {
+#pragma unroll
+        for (int it = 0; it < 14; ++it) {                    // q0 s0..s2, q1 s0..s2, P0, q2 s0..s2, q3 s0..s2, P1
+          const bool is_pack = it == 6 || it == 13;
+          int at = it * n / 14;
+          if (is_pack && at < pack_from) at = pack_from;
+          if (at > n - 1) at = n - 1;
+          if (at != idx) continue;
+          if (it == 6) pack1(0);
+          else if (it == 13) pack1(1);
+          else { const int j = it < 6 ? it : it - 1; geglu_stage(u, par, j / 3, j % 3); }
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {
+          int at = it < 4 ? it * pack_from / 4 : (it == 4 ? pack_from - 1 : pack_from + (it - 5) * (n - pack_from) / 4);
+          if (at > n - 1) at = n - 1;
+          if (at != idx) continue;
+          if (it < 4) quad_b(par, it);
+          else if (it == 4) { if (u + 1 < 32) stash_load(u + 1); }
+          else pack1(it - 5);
+        }
+      }
+    };
+
+    // ---- the 32 hidden units, software-pipelined: P2(k - 1), P1(k + 1) and E(k) share a group ---------------------------
+    using KA = std::integral_constant<int, K_P1A>; using KB = std::integral_constant<int, K_P1B>;
+    using KC = std::integral_constant<int, K_P2A>; using KD = std::integral_constant<int, K_P2B>;
+    // FO<x>: which fragment buffer holds the slab's macro-step 0 (every slab advances the ring by 8 = 2 mod 3)
+    if constexpr (!BWD) {
+      slab(KA{}, FO<0>{}, 0, no_side); slab(KB{}, FO<2>{}, 0, no_side);
+      slab(KA{}, FO<1>{}, 1, [&](int m) __attribute__((always_inline)) { E_step(0, 0, m, 16, 0); });
+      slab(KB{}, FO<0>{}, 1, [&](int m) __attribute__((always_inline)) { E_step(0, 0, 8 + m, 16, 0); });
+#pragma unroll 1
+      for (int kk = 1; kk <= 29; kk += 2) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {                        // k = kk + o: acc1 parity of E(k) is k & 1 = 1 - o
+          const int k = kk + o, pe = 1 - o, pn = o;
+          slab(KC{}, FO<2>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, m, 24, 8); });
+          slab(KA{}, FO<1>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 8 + m, 24, 8); });
+          slab(KB{}, FO<0>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 16 + m, 24, 8); });
+        }
+      }
+      slab(KC{}, FO<2>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(31, 1, m, 9, 8); });      // P2(30) with E(31)
+      E_step(31, 1, 8, 9, 8);                                                                    // its packs, after P2(30)
+      slab(KC{}, FO<1>{}, 0, no_side);                                                                    // P2(31)
+    } else {
+      stash_load(0);
+      slab(KA{}, FO<0>{}, 0, no_side);
+      slab(KA{}, FO<2>{}, 1, [&](int m) __attribute__((always_inline)) { E_step(0, 0, m, 8, 4); });
+#pragma unroll 1
+      for (int kk = 1; kk <= 29; kk += 2) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const int k = kk + o, pe = 1 - o, pn = o;
+          slab(KC{}, FO<1>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, m, 24, 16); });
+          slab(KD{}, FO<0>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 8 + m, 24, 16); });
+          slab(KA{}, FO<2>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 16 + m, 24, 16); });
+        }
+      }
+      slab(KC{}, FO<1>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(31, 1, m, 20, 16); });
+      slab(KD{}, FO<0>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(31, 1, 8 + m, 20, 16); });
+#pragma unroll
+      for (int i = 16; i < 20; ++i) E_step(31, 1, i, 20, 16);
+      slab(KC{}, FO<2>{}, 0, no_side); slab(KD{}, FO<1>{}, 0, no_side);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    // ---- epilogue: lane (r, h) holds features n = 32 nb + 8 q + 4 h + i of token r --------------------------------------
+    if (!BWD) {
+      const float* zrow = f.Z1 + tokc * 256 + 4 * h;
+      float* orow = f.Y + tokc * 256 + 4 * h;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        f32x4 rz[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rz[q] = *reinterpret_cast<const f32x4*>(zrow + 32 * nb + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b2 = *reinterpret_cast<const f32x4*>(f.b2 + 32 * nb + 8 * q + 4 * h);
+          const f32x4 v = quad(acc2[nb], q) * os2 + b2 + rz[q];
+          if (tok_ok) *reinterpret_cast<f32x4*>(orow + 32 * nb + 8 * q) = v;
+        }
+      }
+    } else {
+      // dz1 = dz + LNbwd(d(ln3); z1, gamma)   (rowops.hip, ln_bwd_kernel)
+      const float* zrow = f.Z1 + tokc * 256 + 4 * h;
+      const float* drow = f.X + tokc * 256 + 4 * h;
+      float* orow = f.Y + tokc * 256 + 4 * h;
+      f32x4 xz[32];
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) { xz[i] = *reinterpret_cast<const f32x4*>(zrow + 8 * i); sum += (xz[i][0] + xz[i][1]) + (xz[i][2] + xz[i][3]); }
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.f / 256.f);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xz[i][e] - mean; ss += d * d; }
+      ss += __shfl_xor(ss, 32);
+      const float rstd = 1.f / sqrtf(ss * (1.f / 256.f) + 1e-5f);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {                          // i = 4 nb + q
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(f.ln_g + 8 * i + 4 * h);
+        f32x4 gq = quad(acc2[i >> 2], i & 3) * os2 * gm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xz[i][e] = (xz[i][e] - mean) * rstd;
+          t1 += gq[e]; t2 += gq[e] * xz[i][e];
+          acc2[i >> 2][4 * (i & 3) + e] = gq[e];
+        }
+      }
+      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+      const float m1 = t1 * (1.f / 256.f), m2 = t2 * (1.f / 256.f);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const f32x4 add = *reinterpret_cast<const f32x4*>(drow + 8 * i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (acc2[i >> 2][4 * (i & 3) + e] - m1 - xz[i][e] * m2) * rstd + add[e];
+        if (tok_ok) *reinterpret_cast<f32x4*>(orow + 8 * i) = o;
+      }
+    }
+  }
+#undef FX_PIECE
+#undef FX_MAC_HEAD
+#undef FX_MAC_MID
+#undef FX_MAC_TAIL
+  if ((ABL & 64) && f.stamps && lane == 0) {
+    unsigned long long* o = f.stamps + ((long)blockIdx.x * 4 + wave) * 4;
+    o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3];
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the block
+
+  // ---- maxima for the next evaluation's scales, range guard (as in gemm_x6p_body.inc) ---------------------------------
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { amax1 = fmaxf(amax1, __shfl_xor(amax1, o)); amax2 = fmaxf(amax2, __shfl_xor(amax2, o)); }
+  if (lane == 0) {
+    if (f.amax_out1) atomicMax(reinterpret_cast<unsigned*>(f.amax_out1), __builtin_bit_cast(unsigned, amax1));
+    if (f.amax_out2) atomicMax(reinterpret_cast<unsigned*>(f.amax_out2), __builtin_bit_cast(unsigned, amax2));
+    if (f.range_flag) {
+      if (!(amax1 * s_1 < 60000.f) || (amax1 > 0.f && amax1 * s_1 < 0.125f)) atomicMax(f.range_flag, f.site1 + 1);
+      if (!(amax2 * s_2 < 60000.f) || (amax2 > 0.f && amax2 * s_2 < 0.125f)) atomicMax(f.range_flag, f.site2 + 1);
+    }
+  }
+}
+
+// out[row][c] = in[row][src(c)]: the k order of the second product's weight fragments follows the accumulator rows of
+// the first (element i of lane half h in k16 step s of a 32-block <-> row 4 h + 8 (2 s + (i >> 2)) + (i & 3)).
+//   mode 0 (forward,  W2  [256][1024]): blocks of 32 columns, 2 steps each
+//   mode 1 (backward, W1^T [256][2048]): per unit u 64 columns = steps 0, 1 from a-columns 32 u.., steps 2, 3 from g-columns 1024 + 32 u..
+__global__ void ffx_gather_cols_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int mode) {
+  const long total = (long)rows * cols;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long row = idx / cols; const int c = (int)(idx - row * cols);
+    const int i = c & 7, hh = (c >> 3) & 1;
+    int src;
+    if (mode == 0) { const int u = c >> 5, s = (c >> 4) & 1; src = 32 * u + 4 * hh + 8 * (2 * s + (i >> 2)) + (i & 3); }
+    else { const int u = c >> 6, t = (c >> 4) & 3; src = (t >= 2 ? 1024 : 0) + 32 * u + 4 * hh + 8 * (2 * (t & 1) + (i >> 2)) + (i & 3); }
+    out[idx] = in[row * cols + src];
+  }
+}
+int ffx_pack_second(const float* W, int rows, int cols, int mode, float scale, float* tmp, unsigned short* out, hipStream_t s) {
+  RAMP_REQUIRE(W && tmp && out && rows % 32 == 0 && ((mode == 0 && cols % 32 == 0) || (mode == 1 && cols == 2048)), "ffx_pack_second: bad shape");
+  hipLaunchKernelGGL(ffx_gather_cols_kernel, dim3(1024), dim3(256), 0, s, W, tmp, rows, cols, mode);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return launch_pack_h3(tmp, out, rows, cols, scale, s);
+}
+
+// The weight stream of one direction: 96 slabs x 32 KB in the order the kernel consumes them; a slab = 8 macro-steps x
+// 4 fragments (1 KB each, [lane][8 halves] as launch_pack_h3 writes them).
+//   forward : P1(0)a P1(0)b | P1(1)a P1(1)b | { P2(k-1) P1(k+1)a P1(k+1)b } k = 1..30 | P2(30) | P2(31)
+//             P1(u)x: macro m = k16 step 8 x + m of W1's row blocks 2 u (a) and 2 u + 1 (g): [a hi, a lo, g hi, g lo]
+//             P2(u) : macro m = row block m of W2 (permuted), k16 steps 2 u, 2 u + 1: [s0 hi, s0 lo, s1 hi, s1 lo]
+//   backward: P1(0) | P1(1) | { P2(k-1)a P2(k-1)b P1(k+1) } k = 1..30 | P2(30)a P2(30)b | P2(31)a P2(31)b
+//             P1(u) : macro m = k16 steps 2 m, 2 m + 1 of W2^T's row block u
+//             P2(u)x: macro m = row block 4 x + (m >> 1) of W1^T (permuted), k16 steps 4 u + 2 (m & 1), + 1
+__global__ void ffx_build_stream_kernel(const unsigned short* __restrict__ p1, const unsigned short* __restrict__ p2,
+                                        unsigned short* __restrict__ out, int bwd) {
+  const int q = blockIdx.x;                                  // slab
+  int kind, u;
+  if (!bwd) {
+    if (q < 4) { kind = q & 1; u = q >> 1; }
+    else if (q < 94) { const int k = 1 + (q - 4) / 3, j = (q - 4) - 3 * (k - 1); if (j == 0) { kind = K_P2A; u = k - 1; } else { kind = j - 1; u = k + 1; } }
+    else { kind = K_P2A; u = q - 64; }
+  } else {
+    if (q < 2) { kind = K_P1A; u = q; }
+    else if (q < 92) { const int k = 1 + (q - 2) / 3, j = (q - 2) - 3 * (k - 1); if (j == 2) { kind = K_P1A; u = k + 1; } else { kind = K_P2A + j; u = k - 1; } }
+    else { kind = K_P2A + (q & 1); u = 30 + ((q - 92) >> 1); }
+  }
+  for (int i = threadIdx.x >> 6; i < 32; i += blockDim.x >> 6) {       // fragment i = 4 m + j of the slab
+    const int m = i >> 2, j = i & 3, lane = threadIdx.x & 63;
+    const unsigned short* src;
+    if (!bwd) {
+      if (kind <= K_P1B) src = p1 + ((long)(((2 * u + (j >> 1)) * 16 + 8 * kind + m) * 2 + (j & 1))) * 512;
+      else src = p2 + ((long)((m * 64 + 2 * u + (j >> 1)) * 2 + (j & 1))) * 512;
+    } else {
+      if (kind == K_P1A) src = p1 + ((long)((u * 16 + 2 * m + (j >> 1)) * 2 + (j & 1))) * 512;
+      else src = p2 + ((long)(((4 * (kind - K_P2A) + (m >> 1)) * 128 + 4 * u + 2 * (m & 1) + (j >> 1)) * 2 + (j & 1))) * 512;
+    }
+    reinterpret_cast<u32x4*>(out + ((long)q * 32 + i) * 512)[lane] = reinterpret_cast<const u32x4*>(src)[lane];
+  }
+}
+int ffx_build_stream(const unsigned short* p1, const unsigned short* p2, unsigned short* out, bool bwd, hipStream_t s) {
+  RAMP_REQUIRE(p1 && p2 && out, "ffx_build_stream: null operand");
+  hipLaunchKernelGGL(ffx_build_stream_kernel, dim3(FX_SLABS), dim3(256), 0, s, p1, p2, out, bwd ? 1 : 0);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_ffx(const FfxArgs& f, bool bwd, hipStream_t s) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  RAMP_REQUIRE(f.M > 0 && f.X && f.Y && f.Z1 && f.stash && f.Wstream && f.ln_g && (bwd || (f.ln_b && f.b1 && f.b2)), "ffx: null operand");
+  RAMP_REQUIRE(al16(f.X) && al16(f.Y) && al16(f.Z1) && al16(f.stash) && al16(f.Wstream) && al16(f.ln_g) && al16(f.ln_b) &&
+               al16(f.b1) && al16(f.b2), "ffx: operands must be 16-byte aligned");
+  const int n_mt = (f.M + 127) / 128;
+  const int nb = std::min(n_mt, 256);                        // one 4-wave block per CU
+#define FX_GO(B, A) hipLaunchKernelGGL((ffx_kernel<B, A>), dim3(nb), dim3(256), FX_LDS, s, f, n_mt)
+  if (f.ablate == 0) { if (bwd) FX_GO(true, 0); else FX_GO(false, 0); }
+  else if (f.ablate == 1) { if (bwd) FX_GO(true, 1); else FX_GO(false, 1); }
+  else if (f.ablate == 2) { if (bwd) FX_GO(true, 2); else FX_GO(false, 2); }
+  else if (f.ablate == 4) { if (bwd) FX_GO(true, 4); else FX_GO(false, 4); }
+  else if (f.ablate == 7) { if (bwd) FX_GO(true, 7); else FX_GO(false, 7); }
+  else if (f.ablate == 16) { if (bwd) FX_GO(true, 16); else FX_GO(false, 16); }
+  else if (f.ablate == 32) { if (bwd) FX_GO(true, 32); else FX_GO(false, 32); }
+  else if (f.ablate == 40) { if (bwd) FX_GO(true, 40); else FX_GO(false, 40); }
+  else if (f.ablate == 64) { if (bwd) FX_GO(true, 64); else FX_GO(false, 64); }
+  else if (f.ablate == 66) { if (bwd) FX_GO(true, 66); else FX_GO(false, 66); }
+  else if (f.ablate == 68) { if (bwd) FX_GO(true, 68); else FX_GO(false, 68); }
+  else if (f.ablate == 65) { if (bwd) FX_GO(true, 65); else FX_GO(false, 65); }
+  else if (f.ablate == 67) { if (bwd) FX_GO(true, 67); else FX_GO(false, 67); }
+  else if (f.ablate == 192) { if (bwd) FX_GO(true, 192); else FX_GO(false, 192); }
+  else RAMP_REQUIRE(false, "ffx: ablation variant not built");
+#undef FX_GO
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int init_ffx_attributes() {
+#define FX_ATTR(B, A) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffx_kernel<B, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS))
+  FX_ATTR(false, 0); FX_ATTR(true, 0); FX_ATTR(false, 1); FX_ATTR(true, 1); FX_ATTR(false, 2); FX_ATTR(true, 2);
+  FX_ATTR(false, 4); FX_ATTR(true, 4); FX_ATTR(false, 7); FX_ATTR(true, 7); FX_ATTR(false, 16); FX_ATTR(true, 16);
+  FX_ATTR(false, 32); FX_ATTR(true, 32); FX_ATTR(false, 40); FX_ATTR(true, 40); FX_ATTR(false, 64); FX_ATTR(true, 64); FX_ATTR(false, 65); FX_ATTR(true, 65); FX_ATTR(false, 67); FX_ATTR(true, 67); FX_ATTR(false, 192); FX_ATTR(true, 192); FX_ATTR(false, 66); FX_ATTR(true, 66); FX_ATTR(false, 68); FX_ATTR(true, 68);
+#undef FX_ATTR
+  return 0;
+}
+
+}  // namespace ramp

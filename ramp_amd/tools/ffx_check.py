@@ -1,0 +1,69 @@
+"""The token-owning fused feed-forward (ffx.hip): parity against float64 autograd and timing against the launches it replaces."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from ramp_amd import _lib
+
+lib = _lib.load()
+dev = "cuda:0"
+
+
+def ref(z1, dz, W1, b1, W2, b2, g, b):
+    z = z1.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(z, (256,), g.double(), b.double(), 1e-5)
+    ag = y @ W1.double().T + b1.double()
+    hg = ag[:, :1024] * torch.nn.functional.gelu(ag[:, 1024:])
+    z2 = z + hg @ W2.double().T + b2.double()
+    (dz1,) = torch.autograd.grad(z2, z, dz.double())
+    return z2.detach(), dz1, y.detach().abs().max().item(), hg.detach().abs().max().item()
+
+
+def check(M, seed=0):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(dev)
+    z1, dz = r(M, 256, sc=1.3), r(M, 256, sc=0.7)
+    W1, b1, W2, b2 = r(2048, 256, sc=1 / 16), r(2048, sc=0.1), r(256, 1024, sc=1 / 32), r(256, sc=0.1)
+    g, b = 1 + r(256, sc=0.1), r(256, sc=0.1)
+    z2r, dz1r, ymax, hmax = ref(z1, dz, W1, b1, W2, b2, g, b)
+    z2, dz1 = torch.empty_like(z1), torch.empty_like(z1)
+    prev = (C.c_float * 4)(ymax, hmax, dz.abs().max().item(), 0.0)
+    out = (C.c_float * 4)()
+    flag = C.c_int32(0)
+    # first call: d(ag) unscaled (its maximum unknown); second call: scaled from the maximum the first recorded
+    for it in range(2):
+        _lib.check(lib.ramp_op_ffx(_lib.ptr(z1), _lib.ptr(dz), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(g),
+                                   _lib.ptr(b), M, prev, _lib.ptr(z2), _lib.ptr(dz1), out, C.byref(flag), None), "ramp_op_ffx")
+        e1 = (z2.double() - z2r).abs().max().item() / z2r.abs().max().item()
+        e2 = (dz1.double() - dz1r).abs().max().item() / dz1r.abs().max().item()
+        print(f"M={M} pass {it}: z2 rel err {e1:.2e}, dz1 rel err {e2:.2e}, recorded maxima {[round(v, 4) for v in out]} "
+              f"(expected {ymax:.4f}, {hmax:.4f}, {dz.abs().max().item():.4f}, -), range flag {flag.value}", flush=True)
+        prev[3] = out[3]
+    return e1, e2
+
+
+def t(M, mode, flags=0, iters=5, N=2048, K=256):
+    us = C.c_float()
+    _lib.check(lib.ramp_bench_gemm(M, N, K, 1, 1, mode, flags, 2, iters, C.byref(us), None))
+    return us.value
+
+
+if __name__ == "__main__":
+    worst = 0.0
+    for M in (128, 293, 4096 + 77):
+        worst = max(worst, *check(M))
+    print("worst", worst, flush=True)
+    if "--bench" in sys.argv:
+        for M in (393216, 196608, 98304, 49152):
+            fl = 2.0 * M * (256 * 2048 + 1024 * 256) / 1e12
+            fx_f = min(t(M, 6) for _ in range(2))
+            fx_b = min(t(M, 7) for _ in range(2))
+            fused = min(t(M, 5) for _ in range(2))
+            dhg = min(t(M, 3, 0, N=1024, K=256) for _ in range(2))
+            ff1dx = min(t(M, 3, 8, N=256, K=2048) for _ in range(2))
+            print(f"M={M}: ffx fwd {fx_f:.0f} us ({fl / fx_f * 1e6:.0f} TF) vs ff_fwd_kernel {fused:.0f} us (+ 2 LN launches); "
+                  f"ffx bwd {fx_b:.0f} us ({fl / fx_b * 1e6:.0f} TF) vs d(hg) {dhg:.0f} + FF1-dX {ff1dx:.0f} = {dhg + ff1dx:.0f} us (+ LN bwd)", flush=True)
+    assert worst < 2e-5, worst
