@@ -44,6 +44,24 @@ typedef struct ramp_config {
 const char* ramp_last_error(void);
 int ramp_version(void);
 
+/* Launch plan: which kernels serve the feed-forward pairs and the shared CFG prefix.  Pure performance knobs -- every plan
+ * meets the same parity bar (tests/test_gpu_unet.py, test_gpu_sampler.py run all of them against the reference fixtures).
+ * ramp_create fills the plan with the library defaults; the environment variables RAMP_FF_FUSED, RAMP_FFX, RAMP_SHARE_PREFIX,
+ * RAMP_X6_THREE, RAMP_X6_PIPE, read ONCE there, override those defaults; nothing below ramp_create reads the environment.
+ * ramp_set_launch_plan may be called any time; after ramp_finalize_weights `x6_pipe` can no longer change (the weight
+ * packing depends on it) and a change of the other fields drops the captured graphs and the kept fp16x3 calibration. */
+typedef struct ramp_launch_plan {
+  int32_t ff_fused_rows;  /* FF1 -> GEGLU -> FF2 forward as one launch (gemm.hip, ff_fwd_kernel) from this many tokens: 0 never, 1 always */
+  int32_t ffx_rows;       /* token-owning fused feed-forward, forward AND backward with LayerNorm-3 folded in (ffx.hip), from
+                           * this many tokens (takes precedence over ff_fused_rows): 0 never, 1 always */
+  int32_t share_prefix;   /* sampling jobs: the CFG rows of a trajectory share the network prefix (0 / 1) */
+  int32_t three_blocks;   /* a third resident block for the bias-only linears where it measured faster (0 / 1) */
+  int32_t x6_pipe;        /* fragment-packed weights + pipelined split-precision kernels (1) or LDS-staged weights (0) */
+  int32_t reserved[3];
+} ramp_launch_plan;
+int ramp_get_launch_plan(ramp_ctx* ctx, ramp_launch_plan* out);
+int ramp_set_launch_plan(ramp_ctx* ctx, const ramp_launch_plan* plan);
+
 /* nn.Module construction / .to(device)  (inference_static.py:99-105). */
 int ramp_create(const ramp_config* cfg, ramp_ctx** out);
 int ramp_destroy(ramp_ctx* ctx);

@@ -22,6 +22,11 @@ class RampConfig(C.Structure):
                 ("debug_taps", C.c_int32), ("gemm_mode", C.c_int32)]
 
 
+class RampLaunchPlan(C.Structure):
+    _fields_ = [("ff_fused_rows", C.c_int32), ("ffx_rows", C.c_int32), ("share_prefix", C.c_int32),
+                ("three_blocks", C.c_int32), ("x6_pipe", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
 class RampApfParams(C.Structure):
     _fields_ = [("cloud", C.c_void_p), ("n_points", C.c_int32), ("window", C.c_int32),
                 ("window_weights_host", c_f32p), ("threshold", C.c_double), ("strength", C.c_double),
@@ -68,6 +73,8 @@ PROTOTYPES = {
     "ramp_version": (C.c_int, []),
     "ramp_create": (C.c_int, [C.POINTER(RampConfig), C.POINTER(C.c_void_p)]),
     "ramp_destroy": (C.c_int, [C.c_void_p]),
+    "ramp_get_launch_plan": (C.c_int, [C.c_void_p, C.POINTER(RampLaunchPlan)]),
+    "ramp_set_launch_plan": (C.c_int, [C.c_void_p, C.POINTER(RampLaunchPlan)]),
     "ramp_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, c_f32p, c_i64p, C.c_int32]),
     "ramp_finalize_weights": (C.c_int, [C.c_void_p]),
     "ramp_prepare_time_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

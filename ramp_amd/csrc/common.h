@@ -50,6 +50,7 @@ struct GemmArgs {
   const float* Amul = nullptr; int lda_mul = 0; int a_period = 0;   // optional: A_eff[m][k] = A[m][k % a_period] * Amul[m][k]
   const unsigned short* Ap = nullptr; long ap_plane = 0;    // optional: A already split into two scaled fp16 planes, row-major [2][M][K] (gemm_q.hip)
   int ablate = 0;                                           // diagnostic kernel variant (ramp_bench_gemm only)
+  int three_ok = 1;                                         // launch plan: a third resident block where it measured faster
   int tile_pref = 0;                                        // tuning override (micro-benchmarks): 0 auto, 1 force the 128 x 128 tile, 3 force 3 blocks / CU
   int wx_packed = 0;                                        // 1: Wx is fragment-packed [taps*N/32][K/16][3][64][8] bf16 (launch_pack_x6); 2: [..][2][64][8] fp16 (launch_pack_h3)
   const float* bias = nullptr;                              // [N]

@@ -100,6 +100,8 @@ struct STBlock {
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
   const float *wv2 = nullptr, *wo2 = nullptr, *bo2 = nullptr;    // attn2 (cross) raw
   float *a_qkv = nullptr, *a_z1 = nullptr, *a_ag = nullptr, *a_z2 = nullptr;
+  // token-owning fused feed-forward (ffx.hip): the two weight streams, the weight scales of their first / second product
+  unsigned short *ffx_f = nullptr, *ffx_b = nullptr; float ffx_wsi_w1 = 1.f, ffx_wsi_w2 = 1.f;
 };
 struct ST {
   std::string name;
@@ -183,6 +185,9 @@ struct ramp_ctx {
   int phase = 0, site = 0;
   int ff_fused = 150000;             // fp16x3 evaluations: FF1 -> GEGLU -> FF2 as one launch for M >= this many rows
                                      // (RAMP_FF_FUSED: 0 never, 1 always, n > 1 that threshold)
+  int three_blocks = 1;              // launch plan: third resident block for the bias-only linears
+  int ffx_min_rows = 65536;          // fp16x3 evaluations: feed-forward pairs with at least this many tokens run the token-owning fused
+                                     // kernels of ffx.hip, forward and backward (RAMP_FFX: 0 never, n that threshold)
   int share_prefix = 1;              // sampling jobs: rows of one trajectory share the network prefix (RAMP_SHARE_PREFIX=0: off)
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
@@ -193,7 +198,7 @@ struct ramp_ctx {
   std::map<std::string, std::pair<float*, size_t>> dbg;
   int64_t launches = 0;
   // per-launch HIP-event profiler (eager mode only): category, algorithmic flops, start/stop events
-  bool prof_on = false;
+  bool prof_on = false, prof_dump = false;
   std::vector<hipEvent_t> prof_ev; size_t prof_used = 0;
   std::vector<int> prof_cat; std::vector<double> prof_flops; std::vector<std::array<int, 4>> prof_shape;
 };
@@ -344,7 +349,7 @@ int build_st(ramp_ctx* c, ST& s) {
     CK(get_raw(c, t + ".attn2.to_k.weight", {D, ctx}, &tmp));
     CK(get_raw(c, t + ".norm2.weight", {D}, &tmp)); CK(get_raw(c, t + ".norm2.bias", {D}, &tmp));
     CK(dev_alloc(c, &k.a_qkv, tok * 768)); CK(dev_alloc(c, &k.a_z1, tok * D));
-    CK(dev_alloc(c, &k.a_ag, tok * 2048)); CK(dev_alloc(c, &k.a_z2, tok * D));
+    CK(dev_alloc(c, &k.a_ag, (tok + 127) * 2048)); CK(dev_alloc(c, &k.a_z2, tok * D));     // (+ 127: ffx.hip stashes whole 128-token tiles)
   }
   return 0;
 }
@@ -381,9 +386,30 @@ struct Run {
   int gemm(const GemmArgs& a) {
     prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, a.taps});
     GemmArgs b = a;
+    b.three_ok = c->three_blocks;
     const int kind = prep(b);
     if (kind < 0) return kind;
     int rc = launch_gemm(b, s);
+    prof_post(c, s);
+    c->launches++;
+    return rc;
+  }
+  // the token-owning fused feed-forward (ffx.hip) serves this feed-forward pair, forward AND backward (the stash layout is
+  // private to the two kernels, so both directions of an evaluation must agree: same phase, same M)
+  bool use_ffx(const STBlock& k, int M) const {
+    return k.ffx_f && c->ffx_min_rows > 0 && M >= c->ffx_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe;
+  }
+  // consumes the two call sites of the launches it replaces (forward: FF1, FF2; backward: d(hg), FF1-dX), in their order
+  int ffx(const STBlock& k, bool bwd, const float* X, const float* z1, float* Y, int M) {
+    RAMP_REQUIRE(c->site + 2 <= ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
+    prof_pre(c, s, CAT_GEMM, 2.0 * M * (2048.0 * 256 + 256.0 * 1024), {M, bwd ? -3 : -2, 256, 2});
+    FfxArgs f; f.M = M; f.X = X; f.Z1 = z1; f.Y = Y; f.stash = k.a_ag; f.ln_g = k.ln3_g; f.ln_b = k.ln3_b;
+    f.Wstream = bwd ? k.ffx_b : k.ffx_f; f.b1 = k.b1_pk; f.b2 = k.b2; f.range_flag = c->range_flag;
+    f.amax_in1 = c->obs_in + c->site; f.amax_out1 = c->obs_out + c->site; f.site1 = c->site;
+    f.amax_in2 = c->obs_in + c->site + 1; f.amax_out2 = c->obs_out + c->site + 1; f.site2 = c->site + 1;
+    f.wsi1 = bwd ? k.ffx_wsi_w2 : k.ffx_wsi_w1; f.wsi2 = bwd ? k.ffx_wsi_w1 : k.ffx_wsi_w2;
+    c->site += 2;
+    int rc = launch_ffx(f, bwd, s);
     prof_post(c, s);
     c->launches++;
     return rc;
@@ -521,6 +547,11 @@ int st_forward(Run& r, ST& m, const float* x, int share = 1) {
     if (!pre) { a.rowbias = rowbias; a.rb_stride = rb_stride; a.rowvar = c->row_variant; a.row0 = r.row0; }
     CK(r.gemm(a));
     if (pre) LAUNCH(c, r.s, CAT_ROW, 0, launch_expand_rows(c->t_ln, k.a_z1, R, share, m.L, D, rowbias, rb_stride, c->row_variant, r.row0, r.s));
+    if (r.use_ffx(k, M)) {      // LN3 -> FF1 -> GEGLU -> FF2 -> + z1 in one launch, nothing but the stash and z2 written
+      CK(r.ffx(k, false, k.a_z1, k.a_z1, k.a_z2, M));
+      zin = k.a_z2;
+      continue;
+    }
     LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(k.a_z1, k.ln3_g, k.ln3_b, c->t_ln, M, r.s));
     GemmArgs u = lin(c->t_ln, D, k.w1_pk, k.b1_pk, k.a_ag, 2048, M, 2048, D);
     u.epi = EPI_GEGLU_FWD; u.aux_out = c->t_hg; u.ld_aux = 1024;        // writes ag (stash) and hg = a * gelu(g)
@@ -552,6 +583,9 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx, int s
   for (int b = 1; b >= 0; --b) {
     STBlock& k = m.blk[b];
     const float* zin = (b == 0) ? m.a_z0 : m.blk[0].a_z2;
+    if (r.use_ffx(k, M)) {      // dz1 = dz + LN3bwd(W1^T (d(hg) (.) stash)), d(hg) = W2^T dz: one launch
+      CK(r.ffx(k, true, dz, k.a_z1, dz1, M));
+    } else {
     if (c->gemm_mode >= 1 && c->x6_pipe) {
       // d(hg) only (1024 wide); d(ag) = [d(hg) s1 | d(hg) s2] is formed by the next GEMM's operand loader from the
       // forward stash: the 2048-wide d(ag) never goes to HBM (saves a 2048-float write and a 2048-float read per token)
@@ -566,6 +600,7 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx, int s
       CK(r.gemm(lin(c->t_dag, 2048, k.w1_b, nullptr, c->t_dln, D, M, D, 2048)));        // d(ln3)
     }
     LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, k.a_z1, k.ln3_g, dz, dz1, M, r.s));         // dz1
+    }
     const bool pre = share > 1 && b == 0;
     const int Rb = pre ? Rp : R, Mb = Rb * m.L;
     if (pre) {      // the rows of a trajectory meet again: dz (free now) <- sum_j comb_j dz1[row j]
@@ -898,7 +933,44 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
   auto* c = new ramp_ctx();
   c->cfg = *cfg;
   RAMP_HIP_CHECK(hipGetDevice(&c->device));
+  {   // the environment only supplies DEFAULTS of the launch plan / arithmetic mode, read here and nowhere below
+    const char* env = getenv("RAMP_GEMM_MODE");
+    c->gemm_mode = cfg->gemm_mode == 1 ? 0 : cfg->gemm_mode == 2 ? 1 : cfg->gemm_mode == 3 ? 2
+                 : (env && std::string(env) == "fp16x3") ? 2 : (env && std::string(env) == "bf16x6") ? 1
+                 : (env && std::string(env) == "fp32") ? 0 : RAMP_DEFAULT_GEMM_MODE;
+    const char* pe = getenv("RAMP_X6_PIPE");
+    c->x6_pipe = !(pe && pe[0] == '0');
+    const char* fe = getenv("RAMP_FF_FUSED");
+    if (fe) c->ff_fused = atoi(fe);
+    const char* xe = getenv("RAMP_FFX");
+    if (xe) c->ffx_min_rows = atoi(xe);
+    const char* se = getenv("RAMP_SHARE_PREFIX");
+    if (se) c->share_prefix = atoi(se) != 0;
+    const char* te = getenv("RAMP_X6_THREE");
+    if (te) c->three_blocks = te[0] != '0';
+    c->prof_dump = getenv("RAMP_PROFILE_DUMP") != nullptr;
+  }
   *out = c;
+  return 0;
+}
+
+int ramp_get_launch_plan(ramp_ctx* c, ramp_launch_plan* out) {
+  RAMP_REQUIRE(c && out, "null argument");
+  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, {0, 0, 0}};
+  return 0;
+}
+int ramp_set_launch_plan(ramp_ctx* c, const ramp_launch_plan* p) {
+  RAMP_REQUIRE(c && p, "null argument");
+  RAMP_REQUIRE(p->ff_fused_rows >= 0 && p->ffx_rows >= 0, "row thresholds must be >= 0");
+  RAMP_REQUIRE(!c->finalized || (p->x6_pipe != 0) == (c->x6_pipe != 0), "x6_pipe is fixed once the weights are packed (ramp_finalize_weights)");
+  const bool changed = p->ff_fused_rows != c->ff_fused || p->ffx_rows != c->ffx_min_rows || (p->share_prefix != 0) != (c->share_prefix != 0) ||
+                       (p->three_blocks != 0) != (c->three_blocks != 0);
+  c->ff_fused = p->ff_fused_rows; c->ffx_min_rows = p->ffx_rows; c->share_prefix = p->share_prefix != 0;
+  c->three_blocks = p->three_blocks != 0; c->x6_pipe = p->x6_pipe != 0;
+  if (changed && c->finalized) {   // other kernels from here on: captured graphs and kept calibrations belong to the old plan
+    c->graph_key.clear(); c->r_key.clear();
+    c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false;
+  }
   return 0;
 }
 
@@ -926,16 +998,6 @@ int ramp_load_weight(ramp_ctx* c, const char* name, const float* data, const int
 int ramp_finalize_weights(ramp_ctx* c) {
   RAMP_REQUIRE(c && !c->finalized, "bad context state");
   {
-    const char* env = getenv("RAMP_GEMM_MODE");
-    c->gemm_mode = c->cfg.gemm_mode == 1 ? 0 : c->cfg.gemm_mode == 2 ? 1 : c->cfg.gemm_mode == 3 ? 2
-                 : (env && std::string(env) == "fp16x3") ? 2 : (env && std::string(env) == "bf16x6") ? 1
-                 : (env && std::string(env) == "fp32") ? 0 : RAMP_DEFAULT_GEMM_MODE;
-    const char* pe = getenv("RAMP_X6_PIPE");
-    c->x6_pipe = !(pe && pe[0] == '0');
-    const char* fe = getenv("RAMP_FF_FUSED");
-    if (fe) c->ff_fused = atoi(fe);
-    const char* se = getenv("RAMP_SHARE_PREFIX");
-    if (se) c->share_prefix = atoi(se) != 0;
     c->geglu_group = (c->gemm_mode >= 1 && c->x6_pipe) ? 32 : 64;
   }
   const int nl = c->cfg.n_levels, S = c->cfg.state_dim, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim;
@@ -1079,6 +1141,27 @@ int ramp_finalize_weights(ramp_ctx* c) {
         CK(reg(k.w1_pk, 2048ul * 256, 256)); CK(reg(k.w1_b, 2048ul * 256, 2048));
         CK(reg(k.w2_f, 1024ul * 256, 1024)); CK(reg(k.w2_b, 1024ul * 256, 256));
       }
+    }
+    if (c->gemm_mode == 2 && c->x6_pipe && c->geglu_group == 32) {
+      // weight streams of the token-owning fused feed-forward: first products from the fragment planes the tile kernels use,
+      // second products re-packed with the k order of the first one's accumulator rows (ffx_pack_second)
+      float* tmp; CK(dev_alloc(c, &tmp, 2048 * 256));
+      unsigned short *p2f, *p2b;
+      { float* q; CK(dev_alloc(c, &q, 256 * 1024 + 4)); p2f = reinterpret_cast<unsigned short*>(q); }
+      { float* q; CK(dev_alloc(c, &q, 256 * 2048 + 4)); p2b = reinterpret_cast<unsigned short*>(q); }
+      for (auto& st : c->sts)
+        for (auto& k : st.blk) {
+          const auto& e1 = c->x6.at(k.w1_pk); const auto& e1b = c->x6.at(k.w1_b);
+          const auto& e2 = c->x6.at(k.w2_f); const auto& e2b = c->x6.at(k.w2_b);
+          RAMP_REQUIRE(e1.packed3 && e2b.packed3 && e1.w_scale_inv == e1b.w_scale_inv && e2.w_scale_inv == e2b.w_scale_inv, "ffx: weight planes missing");
+          float *sf, *sb; CK(dev_alloc(c, &sf, 96 * 8192 + 4)); CK(dev_alloc(c, &sb, 96 * 8192 + 4));
+          k.ffx_f = reinterpret_cast<unsigned short*>(sf); k.ffx_b = reinterpret_cast<unsigned short*>(sb);
+          CK(ffx_pack_second(k.w2_f, 256, 1024, 0, 1.f / e2.w_scale_inv, tmp, p2f, 0));
+          CK(ffx_build_stream(e1.packed3, p2f, k.ffx_f, false, 0));
+          CK(ffx_pack_second(k.w1_b, 256, 2048, 1, 1.f / e1.w_scale_inv, tmp, p2b, 0));
+          CK(ffx_build_stream(e2b.packed3, p2b, k.ffx_b, true, 0));
+          k.ffx_wsi_w1 = e1.w_scale_inv; k.ffx_wsi_w2 = e2.w_scale_inv;
+        }
     }
     for (auto& d : c->downs) { CK(reg(d.w_f, 3ul * d.C * d.C, d.C)); CK(reg(d.w_b, 3ul * d.C * d.C, d.C)); }
     for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C, u.C)); CK(reg(u.w_b, 4ul * u.C * u.C, u.C)); }
@@ -2028,7 +2111,7 @@ int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
     RAMP_HIP_CHECK(hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
     ms[c->prof_cat[i]] += t; flops[c->prof_cat[i]] += c->prof_flops[i]; count[c->prof_cat[i]]++;
   }
-  if (getenv("RAMP_PROFILE_DUMP")) {      // per-shape GEMM table on stderr
+  if (c->prof_dump) {      // per-shape GEMM table on stderr
     std::map<std::array<int, 4>, std::pair<double, int>> agg;
     for (size_t i = 0; i < c->prof_cat.size(); ++i) {
       if (c->prof_cat[i] != CAT_GEMM) continue;

@@ -93,6 +93,15 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4& hi, 
   hi = u32x4{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
   lo = u32x4{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1), __builtin_bit_cast(unsigned, l2), __builtin_bit_cast(unsigned, l3)};
 }
+// four scaled floats -> two dwords of each plane
+__device__ __forceinline__ void split4(const f32x4 a, unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
+  const half2v x0 = __builtin_convertvector(f32x2{a[0], a[1]}, half2v), x1 = __builtin_convertvector(f32x2{a[2], a[3]}, half2v);
+  const f32x2 r0 = __builtin_convertvector(x0, f32x2), r1 = __builtin_convertvector(x1, f32x2);
+  const half2v y0 = __builtin_convertvector(f32x2{a[0] - r0[0], a[1] - r0[1]}, half2v);
+  const half2v y1 = __builtin_convertvector(f32x2{a[2] - r1[0], a[3] - r1[1]}, half2v);
+  h0 = __builtin_bit_cast(unsigned, x0); h1 = __builtin_bit_cast(unsigned, x1);
+  l0 = __builtin_bit_cast(unsigned, y0); l1 = __builtin_bit_cast(unsigned, y1);
+}
 __device__ __forceinline__ float amax4(const f32x4 v, float m) {
   m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), m);
   return fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), m);
@@ -245,11 +254,11 @@ void ffx_kernel(FfxArgs f, int n_mt) {
       // issue order hints: 2 reads | MFMA + up to 7 vector instructions, five times, the other 2 reads after the second MFMA
       // (at most two fragment reads per MFMA gap: a third saturates the LDS array)
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 12, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     ++g;
@@ -330,60 +339,60 @@ void ffx_kernel(FfxArgs f, int n_mt) {
     // take one at a time (E_step): forward 16 elements (one GEGLU each; a quad's stash rows leave with its last element)
     // and 2 plane packs, backward 4 quads and 4 packs.
     f32x4 hq[BWD ? 8 : 4];                                   // forward: h quads; backward: [da quads | dg quads]
-    f32x4 ba, bg;                                            // forward: b1 of the quad whose stage 0 comes next
+    f32x4 ba[2], bg[2];                                      // forward: b1 of quad q in [q & 1], read a stage ahead
     // forward: GEGLU of one quad (four independent dependency chains: a lone wave has nothing else to fill the vector
     // latencies with) in three stages of ~30 vector instructions, one stage per macro-step
     // (the bias quad of the NEXT stage 0 is read during stage 1: read where it is used, the fma behind it exposes the LDS latency)
-    f32x4 qa, qg, qt, qp;                                    // the quad in progress: a, g, t = 1 / (1 + p |g|) then Phi(g), phi(g)
+    f32x4 qa[2], qg[2], qt[2], qp[2], s1q, s2q;              // the quad in progress [q & 1]: a, g, t = 1 / (1 + p |g|) then Phi(g), phi(g)
     auto bias_load = [&](int u, int q) __attribute__((always_inline)) {
       if constexpr (!BWD) {
-        ba = *reinterpret_cast<const f32x4*>(b1s + (2 * u) * 32 + 8 * q + 4 * h);
-        bg = *reinterpret_cast<const f32x4*>(b1s + (2 * u + 1) * 32 + 8 * q + 4 * h);
+        ba[q & 1] = *reinterpret_cast<const f32x4*>(b1s + (2 * u) * 32 + 8 * q + 4 * h);
+        bg[q & 1] = *reinterpret_cast<const f32x4*>(b1s + (2 * u + 1) * 32 + 8 * q + 4 * h);
       }
     };
     bias_load(0, 0);
-    auto geglu_stage = [&](int u, int par, int q, int st) __attribute__((always_inline)) {
+    auto geglu_stage = [&](int u, int par, int q, int st, int hf) __attribute__((always_inline)) {      // elements 2 hf, 2 hf + 1 of quad q
       if constexpr (!BWD) {
         if (ABL & 128) {                                     // diagnostic: two instructions per element instead of ~30
           if (st == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hq[q][e] = fmaf(acc1[par][0][4 * q + e], os1, acc1[par][1][4 * q + e]) * s_2;
+            for (int e = 2 * hf; e < 2 * hf + 2; ++e) hq[q][e] = fmaf(acc1[par][0][4 * q + e], os1, acc1[par][1][4 * q + e]) * s_2;
           }
           return;
         }
         if (st == 0) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            qa[e] = fmaf(acc1[par][0][4 * q + e], os1, ba[e]);
-            qg[e] = fmaf(acc1[par][1][4 * q + e], os1, bg[e]);
-            qt[e] = __builtin_amdgcn_rcpf(fmaf(0.2316419f, fabsf(qg[e]), 1.f));
-            qp[e] = __builtin_amdgcn_exp2f(qg[e] * qg[e] * -0.72134752044448170368f) * 0.39894228040143267794f;
+          for (int e = 2 * hf; e < 2 * hf + 2; ++e) {
+            qa[q & 1][e] = fmaf(acc1[par][0][4 * q + e], os1, ba[q & 1][e]);
+            qg[q & 1][e] = fmaf(acc1[par][1][4 * q + e], os1, bg[q & 1][e]);
+            qt[q & 1][e] = __builtin_amdgcn_rcpf(fmaf(0.2316419f, fabsf(qg[q & 1][e]), 1.f));
+            qp[q & 1][e] = __builtin_amdgcn_exp2f(qg[q & 1][e] * qg[q & 1][e] * -0.72134752044448170368f) * 0.39894228040143267794f;
           }
         } else if (st == 1) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float poly = fmaf(1.330274429f, qt[e], -1.821255978f);
-            poly = fmaf(poly, qt[e], 1.781477937f);
-            poly = fmaf(poly, qt[e], -0.356563782f);
-            poly = fmaf(poly, qt[e], 0.319381530f);
-            const float qq = qp[e] * (poly * qt[e]);
-            qt[e] = qg[e] >= 0.f ? 1.f - qq : qq;            // Phi(g)
+          for (int e = 2 * hf; e < 2 * hf + 2; ++e) {
+            const float t = qt[q & 1][e];
+            float poly = fmaf(1.330274429f, t, -1.821255978f);
+            poly = fmaf(poly, t, 1.781477937f);
+            poly = fmaf(poly, t, -0.356563782f);
+            poly = fmaf(poly, t, 0.319381530f);
+            const float qq = qp[q & 1][e] * (poly * t);
+            qt[q & 1][e] = qg[q & 1][e] >= 0.f ? 1.f - qq : qq;      // Phi(g)
           }
-          if (q < 3) bias_load(u, q + 1); else bias_load(u < 31 ? u + 1 : 31, 0);
+          if (hf == 1) { if (q < 3) bias_load(u, q + 1); else bias_load(u < 31 ? u + 1 : 31, 0); }
         } else {
-          f32x4 s1, s2;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            s1[e] = qg[e] * qt[e];                            // gelu(g)
-            s2[e] = qa[e] * fmaf(qg[e], qp[e], qt[e]);        // a * gelu'(g)
-            const float hv = qa[e] * s1[e];                   // a * gelu(g)
+          for (int e = 2 * hf; e < 2 * hf + 2; ++e) {
+            s1q[e] = qg[q & 1][e] * qt[q & 1][e];                            // gelu(g)
+            s2q[e] = qa[q & 1][e] * fmaf(qg[q & 1][e], qp[q & 1][e], qt[q & 1][e]);   // a * gelu'(g)
+            const float hv = qa[q & 1][e] * s1q[e];                          // a * gelu(g)
             amax2 = fmaxf(fabsf(hv), amax2);
             hq[q][e] = hv * s_2;
           }
-          if (!(ABL & 2)) {
+          if (hf == 1 && !(ABL & 2)) {
             float* p = stash_w + (long)u * 8192;
-            *reinterpret_cast<f32x4*>(p + (2 * q) * 256) = s1;
-            *reinterpret_cast<f32x4*>(p + (2 * q + 1) * 256) = s2;
+            *reinterpret_cast<f32x4*>(p + (2 * q) * 256) = s1q;
+            *reinterpret_cast<f32x4*>(p + (2 * q + 1) * 256) = s2q;
           }
         }
       }
@@ -397,6 +406,11 @@ void ffx_kernel(FfxArgs f, int n_mt) {
       }
     };
     auto pack1 = [&](int t) __attribute__((always_inline)) { split8(hq[2 * t], hq[2 * t + 1], HB[t][0], HB[t][1]); };
+    auto pack_half = [&](int t, int hf) __attribute__((always_inline)) {
+      unsigned h0, h1, l0, l1;
+      split4(hq[2 * t + hf], h0, h1, l0, l1);
+      HB[t][0][2 * hf] = h0; HB[t][0][2 * hf + 1] = h1; HB[t][1][2 * hf] = l0; HB[t][1][2 * hf + 1] = l1;
+    };
     // step idx of n: forward items = the quads' stages and the two packs (a pack not before step `pack_from`: the second
     // product still reads HB),
     // backward items q0..q3 [stash prefetch of unit u + 1] P0..P3, the packs not before step `pack_from`
@@ -404,15 +418,14 @@ void ffx_kernel(FfxArgs f, int n_mt) {
       if (ABL & 4) return;
       if constexpr (!BWD) {
 #pragma unroll
-        for (int it = 0; it < 14; ++it) {                    // q0 s0..s2, q1 s0..s2, P0, q2 s0..s2, q3 s0..s2, P1
-          const bool is_pack = it == 6 || it == 13;
-          int at = it * n / 14;
+        for (int it = 0; it < 28; ++it) {                    // q0: s0 h0, s0 h1, s1 h0, .. s2 h1; q1: ..; P0 h0, P0 h1; q2; q3; P1 h0, P1 h1
+          const bool is_pack = (it >= 12 && it < 14) || it >= 26;
+          int at = it * n / 28;
           if (is_pack && at < pack_from) at = pack_from;
           if (at > n - 1) at = n - 1;
           if (at != idx) continue;
-          if (it == 6) pack1(0);
-          else if (it == 13) pack1(1);
-          else { const int j = it < 6 ? it : it - 1; geglu_stage(u, par, j / 3, j % 3); }
+          if (is_pack) pack_half(it >= 26 ? 1 : 0, it & 1);
+          else { const int j = it < 12 ? it : it - 2; geglu_stage(u, par, j / 6, (j % 6) >> 1, j & 1); }
         }
       } else {
 #pragma unroll

@@ -1302,7 +1302,7 @@ static int launch_x6(const GemmArgs& a, hipStream_t s) {
   // row-variant prefetch registers: 168 VGPRs without a spill) from four tiles per block up, +4..9 %; the A-multiplier kernel
   // only where it turns two rounds into one (+13 %).  Fewer tiles per block lose more to the un-amortised prologue than the
   // third block hides (-1..-40 %).
-  static const bool three_auto = [] { const char* e = getenv("RAMP_X6_THREE"); return !(e && e[0] == '0'); }();   // launch-plan knob
+  const bool three_auto = a.three_ok != 0;                // launch-plan knob (ramp_launch_plan.three_blocks)
   const bool plain = three_auto && EPI == EPI_LINEAR && wide && !a.Amul && !a.resid && !a.rowbias;
   const bool three = a.wx_packed == 2 && (!a.Amul || wide) &&
                      (EPI == EPI_GEGLU_FWD || a.tile_pref == 3 ||

@@ -16,7 +16,7 @@ def t(M, mode, flags=0, iters=4):
 
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 393216
-names = {64: "stamped", 66: "stamped, no stash", 192: "stamped, light E (no stash)"}
+names = {0: "full", 64: "stamped", 66: "stamped, no stash"}
 fl = 2.0 * M * (256 * 2048 + 1024 * 256) / 1e12
 for mode, nm in ((6, "fwd"),):
     for ab, what in names.items():

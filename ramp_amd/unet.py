@@ -27,7 +27,7 @@ class TemporalUnetInference(nn.Module):
     def __init__(self, n_support_points=None, state_dim=None, unet_input_dim=32, dim_mults=(1, 2, 4, 8),
                  time_emb_dim=32, self_attention=False, conditioning_embed_dim=4, conditioning_type='attention',
                  attention_num_heads=4, attention_dim_head=64, obstacle_3d=False, max_rows: int = 8192,
-                 debug_taps: bool = False, gemm_mode: str = "default", **kwargs):
+                 debug_taps: bool = False, gemm_mode: str = "default", launch_plan: Optional[dict] = None, **kwargs):
         super().__init__()
         if self_attention:
             raise NotImplementedError("self_attention=True (LinearAttention) is never used by the reference drivers")
@@ -48,6 +48,9 @@ class TemporalUnetInference(nn.Module):
         self.max_rows = int(max_rows)
         self.debug_taps = bool(debug_taps)
         self.gemm_mode = {"default": 0, "fp32": 1, "bf16x6": 2, "fp16x3": 3}[gemm_mode]
+        # performance knobs of the HIP engine (ramp_launch_plan: ff_fused_rows, ffx_rows, share_prefix, three_blocks,
+        # x6_pipe); None keeps the library defaults.  Every plan meets the same parity bar.
+        self.launch_plan = dict(launch_plan or {})
         self._unet_keys = [k for k in unet_param_shapes(self.spec, with_scene_encoder=False)]
         self._unet_shapes = unet_param_shapes(self.spec, with_scene_encoder=False)
         self._weights: "OrderedDict[str, torch.Tensor]" = OrderedDict()   # host fp32 copies (checkpoint truth)
@@ -123,6 +126,8 @@ class TemporalUnetInference(nn.Module):
                                   self.gemm_mode)
             h = C.c_void_p()
             _lib.check(lib.ramp_create(C.byref(cfg), C.byref(h)), "ramp_create")
+            if self.launch_plan:
+                self._apply_plan(h, self.launch_plan)
             for k in self._unet_keys:
                 w = self._weights[k]
                 shape = (C.c_int64 * w.dim())(*w.shape)
@@ -138,6 +143,30 @@ class TemporalUnetInference(nn.Module):
             _lib.check(lib.ramp_finalize_weights(h), "ramp_finalize_weights")
         self._ctx = h
         return h
+
+    @staticmethod
+    def _apply_plan(h, kw: dict):
+        lib = _lib.load()
+        plan = _lib.RampLaunchPlan()
+        _lib.check(lib.ramp_get_launch_plan(h, C.byref(plan)), "ramp_get_launch_plan")
+        for k, v in kw.items():
+            if k not in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe"):
+                raise KeyError(f"unknown launch-plan field {k!r}")
+            setattr(plan, k, int(v))
+        _lib.check(lib.ramp_set_launch_plan(h, C.byref(plan)), "ramp_set_launch_plan")
+
+    def set_launch_plan(self, **kw):
+        """Change performance knobs of the engine (see ``include/ramp_hip.h``, ramp_launch_plan); takes effect at the next
+        evaluation (captured graphs and kept fp16x3 calibrations of the old plan are dropped)."""
+        self.launch_plan.update(kw)
+        if self._ctx is not None:
+            with torch.cuda.device(self._device()):
+                self._apply_plan(self._ctx, kw)
+
+    def get_launch_plan(self) -> dict:
+        plan = _lib.RampLaunchPlan()
+        _lib.check(_lib.load().ramp_get_launch_plan(self.ctx(), C.byref(plan)), "ramp_get_launch_plan")
+        return {k: getattr(plan, k) for k in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe")}
 
     def prepare_time_table(self, T: int):
         if T > self._T_table:

@@ -368,3 +368,44 @@ def test_fp16x3_dynamic_range_sweep(kind, wkind):
     assert excess.max() <= 1.0
     _, flag = _lib.op_gemm(dA, dW, None, None, o16, M, N, K, 1, 0, 0, 1, mode="fp16x3", a_absmax_prev=amax / 2048.0)
     assert flag != 0
+
+
+@pytest.mark.parametrize("M", [128, 293, 4173])
+def test_ffx_fused_feed_forward_against_float64_autograd(M):
+    """The token-owning fused feed-forward kernels (ffx.hip) through the C ABI (ramp_op_ffx): forward
+    z2 = z1 + W2 (a gelu(g)) + b2, [a | g] = W1 LN(z1) + b1 (layers_attention_mini.py:38-45, 147) and its input gradient
+    dz1 = dz + J^T dz (LayerNorm backward included), against float64 torch autograd; M not a multiple of the 128-token
+    tile; the operand maxima each launch records are the true ones, and scaling from them leaves the result unchanged to
+    rounding; a stale maximum (operand 2^12 larger than assumed) raises the range flag."""
+    import ctypes as C
+    from ramp_amd import _lib
+    gen = torch.Generator(device="cpu").manual_seed(M)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).cuda()
+    z1, dz = r(M, 256, sc=1.3), r(M, 256, sc=0.7)
+    W1, b1, W2, b2 = r(2048, 256, sc=1 / 16), r(2048, sc=0.1), r(256, 1024, sc=1 / 32), r(256, sc=0.1)
+    g, b = 1 + r(256, sc=0.1), r(256, sc=0.1)
+    zz = z1.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(zz, (256,), g.double(), b.double(), 1e-5)
+    ag = y @ W1.double().T + b1.double()
+    hg = ag[:, :1024] * torch.nn.functional.gelu(ag[:, 1024:])
+    z2r = zz + hg @ W2.double().T + b2.double()
+    (dz1r,) = torch.autograd.grad(z2r, zz, dz.double())
+    z2r = z2r.detach()
+    true_max = [y.detach().abs().max().item(), hg.detach().abs().max().item(), dz.abs().max().item()]
+    z2, dz1 = torch.empty_like(z1), torch.empty_like(z1)
+    out, flag = (C.c_float * 4)(), C.c_int32(0)
+
+    def go(prev):
+        _lib.check(_lib.load().ramp_op_ffx(_lib.ptr(z1), _lib.ptr(dz), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+                                           _lib.ptr(g), _lib.ptr(b), M, (C.c_float * 4)(*prev), _lib.ptr(z2), _lib.ptr(dz1), out,
+                                           C.byref(flag), None), "ramp_op_ffx")
+        return rel(z2.double().cpu().numpy(), z2r.cpu().numpy()), rel(dz1.double().cpu().numpy(), dz1r.cpu().numpy())
+
+    e = go([0.0, 0.0, 0.0, 0.0])                              # unscaled operands (the first, calibrating use of a call site)
+    assert max(e) < 3e-6 and flag.value == 0, (e, flag.value)
+    rec = list(out)
+    assert all(abs(rec[i] - true_max[i]) <= 1e-6 * true_max[i] for i in range(3)), (rec, true_max)
+    e2 = go(rec)                                              # delayed scaling from the recorded maxima
+    assert max(e2) < 3e-6 and flag.value == 0, (e2, flag.value)
+    go([rec[0] / 4096.0, rec[1], rec[2], rec[3]])             # LN output 2^12 larger than the scale assumes: overflow guard
+    assert flag.value == 1, flag.value

@@ -8,14 +8,15 @@ import torch
 
 from oracle import ramp_oracle as O
 from ramp_amd import synth
+import util
 from util import GOLDEN, NoiseInjector, build_unet, dev, rel, weights
 
 pytestmark = pytest.mark.gpu
 
 
-def make_static(T, use_apf=False, sampler="ddpm", use_graph=True, max_rows=64, gemm_mode="default"):
+def make_static(T, use_apf=False, sampler="ddpm", use_graph=True, max_rows=64, gemm_mode="default", launch_plan=None):
     from ramp_amd.models import StaticGaussianDiffusionModel
-    u = build_unet(4, 48, False, max_rows=max_rows, gemm_mode=gemm_mode)
+    u = build_unet(4, 48, False, max_rows=max_rows, gemm_mode=gemm_mode, launch_plan=launch_plan)
     dm = StaticGaussianDiffusionModel(model=u, variance_schedule="exponential", n_diffusion_steps=T,
                                       predict_epsilon=True, compose=False, use_apf=use_apf, sampler=sampler,
                                       use_graph=use_graph)
@@ -50,34 +51,33 @@ def test_ddpm_chain_free_running(tag, nwn, graph):
     assert np.array_equal(chain[:, :, 47], np.broadcast_to(synth.default_hard_conds(4, 48)[47], chain[:, :, 47].shape))
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "fp16x3", "fp16x3-fusedff"])
-def test_ddpm_chain_every_gemm_mode(mode, monkeypatch):
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "fp16x3", "fp16x3-fusedff", "fp16x3-ffx"])
+def test_ddpm_chain_every_gemm_mode(mode):
     """The same reference chain in each GEMM mode: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bf16x6 (three bf16 planes,
     six products) and fp16x3 (two scaled fp16 planes, three products; its first evaluation calibrates in bf16x6),
-    the last one also with every feed-forward through the fused FF1 -> GEGLU -> FF2 kernel (by default only launches
-    of 150000 rows and more take it)."""
+    the last one also with every feed-forward through the fused FF1 -> GEGLU -> FF2 kernel, and through the token-owning
+    fused forward + backward pair of ffx.hip (by default only the large launches take them; forced through the launch plan)."""
     g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
-    monkeypatch.setenv("RAMP_FF_FUSED", "1" if mode.endswith("-fusedff") else "0")
-    mode = mode.split("-")[0]
-    chain, _ = run(make_static(25, gemm_mode=mode), g, 4)
+    mode, plan = util.split_mode(mode)
+    chain, _ = run(make_static(25, gemm_mode=mode, launch_plan=plan), g, 4)
     err = np.abs(chain - g["chain"]).max()
     print(f"ddpm plain {mode} mode: max {err:.2e}")
     assert err < 1e-4
 
 
 @pytest.mark.parametrize("fixture", ["chain_ddpm_plain", "chain_ddim_apf"])
-def test_shared_prefix_against_row_by_row_evaluation(fixture, monkeypatch):
+def test_shared_prefix_against_row_by_row_evaluation(fixture):
     """Inside a sampling job the CFG rows of a trajectory share the part of the network they have in common (level-0
     residual blocks, first transformer down to its first cross-attention constant) and its input gradient is taken once,
-    on the weighted sum of the rows' gradients (engine.hip, net_forward / net_backward).  RAMP_SHARE_PREFIX=0 evaluates
+    on the weighted sum of the rows' gradients (engine.hip, net_forward / net_backward).  share_prefix=0 in the launch plan evaluates
     every row on its own like the reference does: both meet the reference chain, and they agree with each other to
     rounding."""
     g = np.load(f"{GOLDEN}/{fixture}.npz")
     ddim = "ddim" in fixture
     out = {}
     for share in ("1", "0"):
-        monkeypatch.setenv("RAMP_SHARE_PREFIX", share)
-        dm = make_static(100 if ddim else 25, use_apf=ddim, sampler="ddim" if ddim else "ddpm")
+        dm = make_static(100 if ddim else 25, use_apf=ddim, sampler="ddim" if ddim else "ddpm",
+                         launch_plan=dict(share_prefix=int(share)))
         if ddim:
             out[share] = step_teacher_forced(dm, g, True)
         else:

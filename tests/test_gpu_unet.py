@@ -6,6 +6,7 @@ import torch
 
 from oracle import ramp_oracle as O
 from ramp_amd import synth
+import util
 from util import GOLDEN, build_unet, dev, rel, weights
 
 pytestmark = pytest.mark.gpu
@@ -13,19 +14,19 @@ pytestmark = pytest.mark.gpu
 CASES = [("2d_h48", 4, 48, False), ("3d_h48", 6, 48, True), ("3d_h64", 6, 64, True)]
 
 
-@pytest.mark.parametrize("gemm_mode", ["fp16x3", "fp16x3-fusedff", "bf16x6", "fp32"])
+@pytest.mark.parametrize("gemm_mode", ["fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "bf16x6", "fp32"])
 @pytest.mark.parametrize("tag,S,H,o3", CASES)
-def test_score_against_reference_fixture(tag, S, H, o3, gemm_mode, monkeypatch):
+def test_score_against_reference_fixture(tag, S, H, o3, gemm_mode):
     """forward_no_energy, eps and every per-module output / output-gradient tap of the reference
     (UnetInference.py:157-224), through the reference-style forward(x, time, context, obstacle_pts=...), in every
     arithmetic mode.  fp16x3 (the default, and what the bench times): the first evaluation after a scene change
     calibrates the delayed operand scales on the bf16x6 kernels, so the compared evaluations are the ones after it
-    (checked through ramp_score_mode).  "fp16x3-fusedff" forces the one-launch FF1 -> GEGLU -> FF2 kernel, which by
-    default only takes launches of 150000 rows and more (the full-size tests), onto these small ones."""
+    (checked through ramp_score_mode).  "fp16x3-fusedff" forces the one-launch FF1 -> GEGLU -> FF2 kernel and "fp16x3-ffx" the
+    token-owning fused feed-forward pair (forward + backward, LayerNorm-3 folded in; ffx.hip) onto these small launches
+    through the launch plan (ramp_set_launch_plan); by default they only take the large ones (the full-size tests)."""
     g = np.load(f"{GOLDEN}/unet{tag}.npz")
-    monkeypatch.setenv("RAMP_FF_FUSED", "1" if gemm_mode.endswith("-fusedff") else "0")
-    gemm_mode = gemm_mode.split("-")[0]
-    m = build_unet(S, H, o3, max_rows=8, debug=True, gemm_mode=gemm_mode)
+    gemm_mode, plan = util.split_mode(gemm_mode)
+    m = build_unet(S, H, o3, max_rows=8, debug=True, gemm_mode=gemm_mode, launch_plan=plan)
     N = g["x"].shape[0]
     x = dev(g["x"]); t = torch.from_numpy(g["t"]).cuda()
     pts = dev(g["cloud"])[None].repeat(N, 1, 1, 1)
@@ -157,3 +158,33 @@ def test_scene_encoders_hip_against_reference_fixture():
         assert lat.shape == (256,) and rel(lat, g["lat" + k]) < 5e-6, k
     two = m2.encode_scene(dev(np.stack([g["cloud2d_6x64"], g["cloud2d_6x64"][::-1].copy()])))
     assert two.shape == (2, 320) and rel(two[0].cpu().numpy(), g["lat2d_6x64"]) < 5e-6
+
+
+def test_two_contexts_with_different_launch_plans_in_one_process():
+    """The launch plan is per-context state set through the ABI (ramp_set_launch_plan), not process-wide environment:
+    two contexts in one process run different kernels for the same feed-forward pairs -- the tile GEMMs with stand-alone
+    LayerNorms in one, the token-owning fused forward + backward kernels (ffx.hip) in the other -- and agree with each
+    other and with the reference fixture; switching a live context's plan takes effect at the next evaluation."""
+    g = np.load(f"{GOLDEN}/unet2d_h48.npz")
+    N = g["x"].shape[0]
+    x = dev(g["x"]); t = torch.from_numpy(g["t"]).cuda()
+    pts = dev(g["cloud"])[None].repeat(N, 1, 1, 1)
+    a = build_unet(4, 48, False, max_rows=8, gemm_mode="fp16x3", launch_plan=dict(ff_fused_rows=0, ffx_rows=0))
+    b = build_unet(4, 48, False, max_rows=8, gemm_mode="fp16x3", launch_plan=dict(ff_fused_rows=0, ffx_rows=1))
+    assert a.get_launch_plan()["ffx_rows"] == 0 and b.get_launch_plan()["ffx_rows"] == 1
+    out = {}
+    for name, m in (("tiles", a), ("ffx", b)):
+        m(x, t, None, obstacle_pts=pts); m(x, t, None, obstacle_pts=pts)      # forward + backward call sites calibrated
+        out[name] = m(x, t, None, obstacle_pts=pts).cpu().numpy()
+        assert m.score_mode() == "fp16x3"
+        assert rel(out[name], g["eps"]) < 5e-5, name
+    assert not np.array_equal(out["tiles"], out["ffx"])                  # different kernels, different summation orders
+    assert rel(out["tiles"], out["ffx"]) < 2e-5
+    a(x, t, None, obstacle_pts=pts); per_eval_tiles = a.launch_count()   # (kernel launches of the last call)
+    a.set_launch_plan(ffx_rows=1)                                         # live switch: recalibrates, then the fused kernels
+    a(x, t, None, obstacle_pts=pts); a(x, t, None, obstacle_pts=pts)
+    got = a(x, t, None, obstacle_pts=pts).cpu().numpy()
+    per_eval_ffx = a.launch_count()
+    assert a.score_mode() == "fp16x3" and np.array_equal(got, out["ffx"])
+    # 8 transformers x 2 blocks: LN + FF1 + FF2 (3 launches) -> 1 forward, d(hg) + FF1-dX + LN-backward (3) -> 1 backward
+    assert per_eval_tiles - per_eval_ffx == 16 * 4, (per_eval_tiles, per_eval_ffx)

@@ -28,11 +28,24 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def build_unet(S, H, o3, max_rows=64, debug=False, gemm_mode="default"):
+PLANS = {   # launch plans the parity tests force onto the small fixtures (ramp_launch_plan; row thresholds: 0 never, 1 always)
+    "": dict(ff_fused_rows=0, ffx_rows=0),
+    "fusedff": dict(ff_fused_rows=1, ffx_rows=0),          # FF1 -> GEGLU -> FF2 forward in one launch (gemm.hip, ff_fwd_kernel)
+    "ffx": dict(ff_fused_rows=0, ffx_rows=1),              # token-owning fused feed-forward, forward and backward (ffx.hip)
+}
+
+
+def split_mode(mode):
+    """'fp16x3-ffx' -> ('fp16x3', launch plan)"""
+    base, _, plan = mode.partition("-")
+    return base, PLANS[plan]
+
+
+def build_unet(S, H, o3, max_rows=64, debug=False, gemm_mode="default", launch_plan=None):
     from ramp_amd.models import TemporalUnetInference
     from ramp_amd.unet import load_numpy_state_dict
     m = TemporalUnetInference(n_support_points=H, state_dim=S, obstacle_3d=o3, max_rows=max_rows, debug_taps=debug,
-                              gemm_mode=gemm_mode)
+                              gemm_mode=gemm_mode, launch_plan=launch_plan)
     load_numpy_state_dict(m, weights(S, H, o3))
     return m.eval().to("cuda")
 
