@@ -55,6 +55,9 @@ def parse():
                     help="every job's first evaluation calibrates (bf16x6) instead of continuing from the previous job's maxima")
     ap.add_argument("--cpu-sample", type=int, default=256, help="trajectories in the PyTorch-CPU baseline sample (halved "
                                                                   "until the projected chain time is <= 40 s)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch trajectories PER GPU (the driver's default); strong: --batch trajectories in TOTAL, sharded "
+                         "contiguously over the ranks (ramp_amd.dist.shard_counts)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based): 2 = headline Maze2D B=4096 H=48 T=25 (default); "
                          "3 = Maze3D B=4096 H=48 T=25 4k-pt cloud; 4 = Maze2D dynamic replanning B=8192 (10 high-level DDIM steps "
@@ -100,8 +103,8 @@ def build_model(B, device, gemm_mode="default"):
     return dm, sd
 
 
-def run_job(dm, B, cloud, hard_conds, world, x_all=None):
-    """One step = one run_inference of B trajectories + the final all-gather."""
+def run_job(dm, B, cloud, hard_conds, world, n_total=None, want_local=False):
+    """One step = one run_inference of this rank's B trajectories + the final all-gather to n_total (default B * world)."""
     import torch
     from ramp_amd import dist as rdist
     if WL.get("dynamic"):
@@ -115,13 +118,14 @@ def run_job(dm, B, cloud, hard_conds, world, x_all=None):
         hc = {k: v.unsqueeze(0).expand(B, -1).contiguous() for k, v in hard_conds.items()}
         x, _chain, _obs, _start = dm.ddim_p_sample_loop((B, WL["H"], WL["S"]), hc, context=ctx, return_chain=False,
                                                         obstacle_pts=cloud, max_iteration=WL["replans"])
-        return x
+        return (x, x) if want_local else x
     x = dm.run_inference(None, hard_conds, n_samples=B, horizon=WL["H"], return_chain=False, traj_normalized=None,
                          obstacle_pts=cloud, sample_fn=None, guide=None, n_guide_steps=1, t_start_guide=7,
                          noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=0)
+    local = x
     if world > 1:
-        x = rdist.all_gather_trajectories(x.contiguous(), B * world)
-    return x
+        x = rdist.all_gather_trajectories(x.contiguous(), n_total if n_total is not None else B * world)
+    return (x, local) if want_local else x
 
 
 def profile_gemm(dm, B, cloud, hard_conds):
@@ -278,7 +282,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the RAMP sampler has no CPU path")
     device = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(device)
-    B = args.batch
+    strong = args.scaling == "strong"
+    n_total = args.batch if strong else args.batch * world       # trajectories of the whole job
+    B = rdist.shard_counts(n_total, world)[rank]                  # this rank's share (weak: --batch on every rank)
+    if B == 0:
+        raise SystemExit(f"bench.py: --scaling strong with --batch {args.batch} leaves rank {rank} of {world} without work")
     torch.manual_seed(1234 + rank)
 
     dm, sd = build_model(B, device)
@@ -295,11 +303,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        run_job(dm, B, cloud, hard_conds, world)
+        run_job(dm, B, cloud, hard_conds, world, n_total)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = run_job(dm, B, cloud, hard_conds, world)
+        out, out_local = run_job(dm, B, cloud, hard_conds, world, n_total, want_local=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -308,18 +316,29 @@ def main():
         dt = float(tt.item())
     if WL.get("dynamic"):
         assert out.shape == (WL["H"], WL["S"]) and bool(torch.isfinite(out).all())
+        gather_check = {"world": dist.get_world_size() if world > 1 else 1, "note": "planner: the ranks' candidates are merged at "
+                        "every selection (ramp_amd.dist.select_best_sharded), the product is one (H, S) plan"}
+        if world > 1:      # every rank must hold the same executed plan
+            ref = out.clone(); dist.broadcast(ref, src=0)
+            gather_check["same_plan_on_every_rank"] = bool(torch.equal(ref, out))
+            if not gather_check["same_plan_on_every_rank"]:
+                raise SystemExit("bench.py: the ranks executed different plans")
     else:
-        assert out.shape == (B * world, WL["H"], WL["S"]) and bool(torch.isfinite(out).all())
+        assert out.shape == (n_total, WL["H"], WL["S"]) and bool(torch.isfinite(out).all())
+        # outside the timed region: a second REAL collective proves how many ranks the gathered block came from
+        gather_check = rdist.verify_gather(out_local.contiguous(), out, n_total)
+        if gather_check["world"] != args.gpus or not gather_check["checksum_ok"] or gather_check["ranks_seen"] != list(range(args.gpus)):
+            raise SystemExit(f"bench.py: the all-gather does not show {args.gpus} ranks: {gather_check}")
 
-    value = world * B * args.steps / dt
+    value = n_total * args.steps / dt
     ms_per_step = dt / args.steps * 1e3
     flop_row = {2: 1.324e9, 3: 1.323e9, 4: 1.324e9, 5: 1.773e9}[args.config]          # SURVEY.md §8(d), reduced count
-    e2e_tflops_per_gpu = B * 2 * WL.get("evals", WL["T"]) * flop_row / (dt / args.steps) / 1e12
+    e2e_tflops_per_gpu = (n_total / world) * 2 * WL.get("evals", WL["T"]) * flop_row / (dt / args.steps) / 1e12
 
     result = {
         "metric": f"sampled trajectories/sec (H={WL['H']}, T={WL['T']})", "value": value, "unit": "trajectories/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32-emulated (2 x fp16 planes per operand, fp32 accumulate)", "data": "synthetic",
         "gemm_mode": "fp16x3 (default): every fp32 operand is scaled by a power of two and split into 2 fp16 planes (22 "
                      "significand bits), 3 fp16 MFMA products accumulated in fp32; the scales of an evaluation come from the operand "
@@ -341,7 +360,8 @@ def main():
         "e2e_algorithmic_tflops_per_gpu": e2e_tflops_per_gpu,
         "e2e_frac_of_fp16x3_ceiling": e2e_tflops_per_gpu * FP16_PRODUCTS_PER_FP32 / PEAK_FP16_MFMA_TFLOPS,
         "e2e_frac_of_fp32_mfma_peak": e2e_tflops_per_gpu / PEAK_FP32_MFMA_TFLOPS,
-        "n_ranks_rccl": world,
+        "n_ranks_rccl": gather_check["world"], "gather_check": gather_check,
+        "trajectories_total": n_total,
         "workspace_gb": dm.model.workspace_bytes() / 2 ** 30,
     }
 

@@ -230,6 +230,14 @@ int ramp_replan(ramp_ctx* ctx, const ramp_replan_params* p, const ramp_replan_st
 int ramp_select_best(const float* traj, int32_t B, int32_t H, int32_t S, const float* cloud, int32_t n_points, float threshold,
                      float w_smooth, float w_len, int32_t* mask, float* path_len, float* smooth, float* best_out,
                      int32_t* result_dev, void* stream);
+/* Multi-GPU planning (the candidates are sharded over the ranks, the selection needs the global batch): the
+ * per-candidate collision mask / path length / smoothness of the context's LAST ramp_replan (device arrays of B), to be
+ * all-gathered, and the selection of compute_trajectory_costs (cost.py:56-88; min-max normalisation over ALL collision-free
+ * candidates, first minimum) on the gathered arrays: result_dev device int32[4] = {n_free, best_rank, best_row, 0}; the rank
+ * that owns best_row broadcasts the trajectory (reference call sites: diffusion_model_dynamic.py:547, 592-608). */
+int ramp_replan_costs(ramp_ctx* ctx, int32_t B, int32_t* mask_out, float* path_len_out, float* smooth_out, void* stream);
+int ramp_select_from_costs(const int32_t* mask, const float* path_len, const float* smooth, int32_t B, float w_smooth,
+                           float w_len, int32_t* result_dev, void* stream);
 
 /* ---- kernel-level entry points (same kernels the loops use; exported for parity tests) ---- */
 /* avoidance(trajectories, ObstacleField(cloud, thr), window, strength) in place (APFhelper.py:37-104) */

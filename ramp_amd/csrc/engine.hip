@@ -1652,6 +1652,21 @@ int ramp_select_best(const float* traj, int32_t B, int32_t H, int32_t S, const f
   return launch_replan_select(traj, mask, path_len, smooth, w_smooth, w_len, best_out, result_dev, B, H, S, s);
 }
 
+int ramp_select_from_costs(const int32_t* mask, const float* path_len, const float* smooth, int32_t B, float w_smooth, float w_len,
+                           int32_t* result_dev, void* stream) {
+  RAMP_REQUIRE(mask && path_len && smooth && result_dev && B > 0, "bad arguments");
+  return launch_replan_select(nullptr, mask, path_len, smooth, w_smooth, w_len, nullptr, result_dev, B, 1, 1, as_stream(stream));
+}
+
+int ramp_replan_costs(ramp_ctx* c, int32_t B, int32_t* mask_out, float* path_len_out, float* smooth_out, void* stream) {
+  RAMP_REQUIRE(c && c->r_mask && mask_out && path_len_out && smooth_out && B > 0 && (size_t)B <= c->r_cap_B, "no replan of this size has run on the context");
+  hipStream_t s = as_stream(stream);
+  RAMP_HIP_CHECK(hipMemcpyAsync(mask_out, c->r_mask, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  RAMP_HIP_CHECK(hipMemcpyAsync(path_len_out, c->r_plen, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  RAMP_HIP_CHECK(hipMemcpyAsync(smooth_out, c->r_smooth, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
 // ---- kernel-level entry points ---------------------------------------------------------------------
 // The context-free entry points take small HOST arrays (window weights, waypoint indices).  They are staged through a
 // per-thread ring of device slots allocated once, so a call neither allocates nor synchronises; a slot is reused after

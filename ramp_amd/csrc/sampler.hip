@@ -360,6 +360,7 @@ __global__ __launch_bounds__(1024) void replan_select_kernel(const float* __rest
   if (lane == 0) r_cnt[wave] = rank;
   __syncthreads();
   if (tid == 0) { int r = 0; for (int w = 0; w < 16; ++w) r += r_cnt[w]; result[0] = s_free; result[1] = r; result[2] = bb; }
+  if (traj == nullptr) return;                            // selection from gathered costs only (multi-GPU merge): the winner's owner holds the row
   for (int e = tid; e < H * S; e += 1024) {
     float v = traj[(long)bb * H * S + e];
     if (e < S && e >= 2) v = 0.f;

@@ -605,11 +605,17 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
         its re-sampled sphere cloud (numpy RNG, same call order as the reference) and the termination test.
         ``self.replan_log`` (a list, optional) receives every batch handed to a selection, for the parity tests."""
         from .apf_dynamic import generate_sphere_points
+        from . import dist as rdist
+        import torch.distributed as tdist
         device = self._device()
         B, H, S = shape
         lib = _lib.load()
         m = self.model
         log = getattr(self, 'replan_log', None)
+        # several GPUs: `shape[0]` is THIS rank's share of the candidates; every selection merges the ranks' candidates
+        # (12 bytes per candidate all-gathered, the winner's owner broadcasts its trajectory: ramp_amd.dist.select_best_sharded),
+        # so all ranks execute the same plan and feed the same environment (SURVEY 8(e))
+        sharded = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
         env = context['dataset'].env
         fixed = env.obj_fixed_list[0].fields[0]
         context['static_obstacle_centers'] = fixed.centers.cpu().numpy()[:4]
@@ -638,9 +644,12 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
         n_free, rank, _row, _ = (int(v) for v in res_dev.cpu())
         if log is not None:
             log.append(dict(batch=xb.clone(), npts=cost_cloud.shape[0], idx=rank if n_free else -1, free=(mask == 0).clone()))
+        if sharded:
+            x_plan, n_free, _row = rdist.select_best_sharded(xb, mask, plen, smooth, 0.1, 0.9, zero_start=False)
         if n_free == 0:
             raise RuntimeError("no collision-free high-level plan (the reference dereferences None here)")
-        x_plan = xb[_row].clone()       # (the selection kernel zeroes x[0, 2:] as the replans need; the high-level winner stays as is)
+        if not sharded:
+            x_plan = xb[_row].clone()   # (the selection kernel zeroes x[0, 2:] as the replans need; the high-level winner stays as is)
         high_plan = x_plan.clone()
         hist_dev = torch.zeros((H, S), device=device)
         hist_dev[0] = x_plan[0]
@@ -675,7 +684,7 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
         p.use_graph = int(self.use_graph)
         x_clean = x_plan.contiguous()
         stepp = 0
-        batch = torch.empty((B, H, S), device=device) if log is not None else None
+        batch = torch.empty((B, H, S), device=device) if (log is not None or sharded) else None
         for k in range(max_iteration):
             noise = torch.randn_like(xb)                           # q_sample's randn_like(x_start)
             field = self._obstacle_field(context)
@@ -701,14 +710,22 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
             res = _lib.RampReplanResult()
             with torch.cuda.device(device):
                 _lib.check(lib.ramp_replan(m.ctx(), C.byref(p), C.byref(st), _lib.ptr(best), _lib.ptr(batch),
-                                           _lib.ptr(mask) if log is not None else None, C.byref(res), _lib.current_stream()),
+                                           _lib.ptr(mask) if (log is not None or sharded) else None, C.byref(res), _lib.current_stream()),
                            "ramp_replan")
             if res.fell_back:
                 warnings.warn(f"fp16x3 range guard tripped at GEMM call site {res.fell_back - 1}: replan repeated in bf16x6")
             if log is not None:
                 log.append(dict(batch=batch.clone(), npts=cost_cloud.shape[0] + (64 if near else 0),
                                 idx=res.best_rank if res.n_free else -1, free=(mask == 0).clone()))
-            if res.n_free == 0:
+            n_free_all = res.n_free
+            if sharded:                                            # the local winner is only a candidate: merge over the ranks
+                with torch.cuda.device(device):
+                    _lib.check(lib.ramp_replan_costs(m.ctx(), B, _lib.ptr(mask), _lib.ptr(plen), _lib.ptr(smooth),
+                                                     _lib.current_stream()), "ramp_replan_costs")
+                merged, n_free_all, _ = rdist.select_best_sharded(batch, mask, plen, smooth, 0.1, 0.9)
+                if merged is not None:
+                    best.copy_(merged)
+            if n_free_all == 0:
                 # no candidate survived: the reference re-plans from scratch until one does (:591-605), eager path
                 from .cost import compute_trajectory_costs
                 xs = None
@@ -721,6 +738,8 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
                     xs, _, _, _, _ = compute_trajectory_costs(xs, cost_cloud, collision_threshold=thr_low)
                 xs = xs.clone(); xs[0, 2:] = 0.0
                 best.copy_(xs)
+                if sharded:
+                    tdist.broadcast(best, src=0)                   # every rank re-planned on its own noise: rank 0's plan is executed
             x_cur = best.clone()
             best_host = x_cur.cpu().numpy()
             x_clean = x_cur

@@ -76,6 +76,84 @@ def sample_sharded(sample_local: Callable[[int, int], torch.Tensor], n_total: in
     return all_gather_trajectories(local, n_total) if gather else local
 
 
+def verify_gather(local: torch.Tensor, gathered: torch.Tensor, n_total: int) -> Dict[str, object]:
+    """Proof that a gathered block really came from ``world`` ranks: every rank contributes (rank, float64 checksum of its
+    local shard) through a second, real all-gather; the block must contain exactly those shards in rank order.  Returns
+    {"world": size read back from the initialised process group, "ranks_seen": [...], "checksum_ok": bool}.
+    A silent single-rank run (WORLD_SIZE lost, a launcher that started one process) cannot produce world > 1 here."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        ok = bool(torch.equal(local, gathered))
+        return {"world": 1, "ranks_seen": [0], "checksum_ok": ok}
+    world, rank = dist.get_world_size(), dist.get_rank()
+    tag = torch.tensor([float(rank), float(local.double().sum().item())], dtype=torch.float64, device=local.device)
+    tags = torch.empty(world * 2, dtype=torch.float64, device=local.device)      # (concatenation along dim 0: the form every backend takes)
+    dist.all_gather_into_tensor(tags, tag)
+    tags = tags.reshape(world, 2).cpu()
+    counts = shard_counts(n_total, world)
+    ok, start = True, 0
+    for r in range(world):
+        part = gathered[start:start + counts[r]].double().sum().item()
+        ref = float(tags[r, 1])
+        ok = ok and abs(part - ref) <= 1e-9 * max(1.0, abs(ref))
+        start += counts[r]
+    return {"world": world, "ranks_seen": [int(v) for v in tags[:, 0].tolist()], "checksum_ok": bool(ok)}
+
+
+def select_best_sharded(batch_local: torch.Tensor, mask_local: torch.Tensor, plen_local: torch.Tensor,
+                        smooth_local: torch.Tensor, w_smooth: float, w_len: float,
+                        select_fn: Optional[Callable] = None, zero_start: bool = True):
+    """The planner's selection (compute_trajectory_costs, cost.py:56-88: min-max normalised 0.1 smoothness + 0.9 length
+    over the collision-free candidates, first minimum) when the candidates are sharded over the ranks: all-gather the three
+    per-candidate scalars (12 bytes per candidate), run the SAME selection on the gathered arrays on every rank, and let the
+    rank that owns the winner broadcast its (H, S) trajectory.  Returns (best, n_free, global_row); best is None when no
+    candidate is collision-free.  select_fn(mask, plen, smooth, w_smooth, w_len) -> (n_free, best_rank, best_row); the
+    default is the HIP selection kernel (ramp_select_from_costs), the CPU tests pass the oracle's restatement."""
+    if select_fn is None:
+        select_fn = _select_hip
+    sharded = dist.is_initialized() and dist.get_world_size() > 1
+    world, rank = (dist.get_world_size(), dist.get_rank()) if sharded else (1, 0)
+    n_local = int(mask_local.shape[0])
+    if sharded:
+        cnt = torch.tensor([n_local], dtype=torch.int64, device=mask_local.device)
+        cnts = torch.empty(world, dtype=torch.int64, device=mask_local.device)
+        dist.all_gather_into_tensor(cnts, cnt)
+        counts = [int(v) for v in cnts.cpu()]
+        pad = max(counts)
+        pack = torch.zeros((pad, 3), dtype=torch.float32, device=mask_local.device)
+        pack[:n_local, 0] = mask_local.to(torch.float32); pack[:n_local, 1] = plen_local; pack[:n_local, 2] = smooth_local
+        allp = torch.empty((world * pad, 3), dtype=torch.float32, device=mask_local.device)
+        dist.all_gather_into_tensor(allp, pack)
+        allp = allp.reshape(world, pad, 3)
+        parts = torch.cat([allp[r, :counts[r]] for r in range(world)], dim=0)
+        mask_all = parts[:, 0].to(torch.int32).contiguous(); plen_all = parts[:, 1].contiguous(); smooth_all = parts[:, 2].contiguous()
+    else:
+        counts = [n_local]
+        mask_all, plen_all, smooth_all = mask_local.to(torch.int32).contiguous(), plen_local.contiguous(), smooth_local.contiguous()
+    n_free, _best_rank, row = select_fn(mask_all, plen_all, smooth_all, w_smooth, w_len)
+    if n_free == 0:
+        return None, 0, -1
+    owner, start = 0, 0
+    while row >= start + counts[owner]:
+        start += counts[owner]; owner += 1
+    best = batch_local[row - start].clone() if owner == rank else torch.empty_like(batch_local[0])
+    if sharded:
+        dist.broadcast(best, src=owner)
+    if zero_start:
+        best[0, 2:] = 0.0                                     # diffusion_model_dynamic.py:607
+    return best, int(n_free), int(row)
+
+
+def _select_hip(mask, plen, smooth, w_smooth, w_len):
+    from . import _lib
+    res = torch.zeros(4, dtype=torch.int32, device=mask.device)
+    with torch.cuda.device(mask.device):
+        _lib.check(_lib.load().ramp_select_from_costs(_lib.ptr(mask), _lib.ptr(plen), _lib.ptr(smooth), int(mask.shape[0]),
+                                                      float(w_smooth), float(w_len), _lib.ptr(res), _lib.current_stream()),
+                   "ramp_select_from_costs")
+    n_free, best_rank, row, _ = (int(v) for v in res.cpu())
+    return n_free, best_rank, row
+
+
 def _free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -85,7 +163,7 @@ def _free_port() -> int:
 
 
 def launch_local_ranks(argv: List[str], world: int, extra_env: Optional[Dict[str, str]] = None,
-                       timeout: Optional[float] = None) -> int:
+                       timeout: Optional[float] = 3600.0) -> int:
     """Start ``world`` copies of ``python argv...`` on this node, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT set the way torchrun sets them, and wait for all of them.  The caller is a parent that has
     NOT initialised the GPU (it only spawns children and relays rank 0's stdout).  Returns 0 only if every rank exited
@@ -105,19 +183,28 @@ def launch_local_ranks(argv: List[str], world: int, extra_env: Optional[Dict[str
     import time
     t0 = time.time()
     live = list(procs)
-    while live:
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for q in live:
-                    q.terminate()
-        if timeout is not None and time.time() - t0 > timeout and live:
-            for q in live:
+    try:
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:
+                        q.terminate()
+            if timeout is not None and time.time() - t0 > timeout and live:
+                rc = 124                                       # a rank hung (e.g. in a rendezvous with too few GPUs)
+                break
+            time.sleep(0.05)
+    finally:                                                   # also on KeyboardInterrupt / SIGTERM of the parent: no orphan ranks
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except Exception:                                  # noqa: BLE001
                 q.kill()
-            return 124
-        time.sleep(0.05)
     return rc

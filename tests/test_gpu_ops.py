@@ -235,6 +235,30 @@ def test_costs_against_reference_fixture():
     assert np.array_equal(best.cpu().numpy(), g["best"])
 
 
+def test_selection_from_gathered_costs_matches_the_unsharded_selection():
+    """Multi-GPU planning merges the ranks' candidates through their per-candidate scalars (ramp_select_from_costs, used by
+    ramp_amd.dist.select_best_sharded): on the reference fixture's batch the selection from the (mask, length, smoothness)
+    arrays -- whole, and cut into two uneven shards re-joined the way the all-gather joins them -- picks the reference's
+    winner (cost.py:56-88), like the one-GPU selection does."""
+    from ramp_amd import dist as rdist
+    g = np.load(f"{GOLDEN}/cost_cases.npz")
+    tr, cl = dev(g["trajs"]), dev(g["cloud"]).reshape(-1, 2).contiguous()
+    B, H, Sd = tr.shape
+    mask = torch.empty(B, dtype=torch.int32, device="cuda"); plen = torch.empty(B, device="cuda"); smooth = torch.empty(B, device="cuda")
+    best = torch.empty((H, Sd), device="cuda"); res = torch.zeros(4, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.load().ramp_select_best(_lib.ptr(tr), B, H, Sd, _lib.ptr(cl), cl.shape[0], 0.05, 0.1, 0.9, _lib.ptr(mask),
+                                            _lib.ptr(plen), _lib.ptr(smooth), _lib.ptr(best), _lib.ptr(res), S()))
+    n_free, rank, row, _ = (int(v) for v in res.cpu())
+    assert rank == int(g["best_index"]) and n_free == int(g["free_mask"].sum())
+    got, nf, grow = rdist.select_best_sharded(tr, mask, plen, smooth, 0.1, 0.9)          # one rank: the gathered arrays ARE the local ones
+    assert nf == n_free and grow == row and torch.equal(got, best)
+    cut = B // 3                                                                          # two shards, joined in rank order
+    m2 = torch.cat([mask[:cut], mask[cut:]]); p2 = torch.cat([plen[:cut], plen[cut:]]); s2 = torch.cat([smooth[:cut], smooth[cut:]])
+    assert rdist._select_hip(m2.contiguous(), p2.contiguous(), s2.contiguous(), 0.1, 0.9) == (n_free, rank, row)
+    none, nf0, _ = rdist.select_best_sharded(tr, torch.ones_like(mask), plen, smooth, 0.1, 0.9)
+    assert none is None and nf0 == 0
+
+
 def test_hard_conditioning_and_cfg_mean():
     from ramp_amd.sample_functions import apply_hard_conditioning
     g = rng(5)
