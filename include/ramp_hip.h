@@ -29,7 +29,7 @@ typedef struct ramp_ctx ramp_ctx;
 /* Architecture of TemporalUnetInference.__init__ (UnetInference.py:42-56, 93-145). */
 typedef struct ramp_config {
   int32_t state_dim;       /* S: 4 (Maze2D) or 6 (Maze3D)                              */
-  int32_t horizon;         /* H = n_support_points: 48 or 64 (attention kernels)       */
+  int32_t horizon;         /* H = n_support_points: any multiple of 8 in [8, 64]       */
   int32_t unet_input_dim;  /* 32                                                       */
   int32_t n_levels;        /* len(dim_mults) = 4 for UNET_DIM_MULTS[1] = (1,2,4,8)      */
   int32_t context_dim;     /* 320 (2-D scene encoder) or 256 (3-D)                     */

@@ -17,6 +17,7 @@ What is captured:
   chain_ddpm_*.npz            full T=25 DDPM chains, B=4, with / without APF, with extra no-noise steps
   chain_ddim_*.npz            DDIM-5 of T=100 chains, with / without APF
   chain3d_ddpm.npz            3-D DDPM T=25: B independent n_samples=1 runs stacked
+  unet2d_h40.npz / chain_ddpm_h40.npz   a horizon other than 48 / 64 (levels 40, 20, 10, 5): taps and a DDPM chain
   chain3d_h64_t50.npz         3-D DDPM, H=64, T=50 (the shape of BASELINE config 5): B independent n_samples=1 runs stacked
   chain_c2.npz / chain_c3.npz the clouds of BASELINE configs 2 and 3 (16x64 2-D with the APF hook; 20x200 3-D), B = 4 / 2 golden
                               trajectories that the full-size GPU tests embed in their B = 4096 batches
@@ -286,6 +287,18 @@ def gen_chain3d_h64(m3b, sp3b):
     chain = np.concatenate(chains, axis=1)
     assert chain.shape == (T + 1, B, H, S)
     save("chain3d_h64_t50.npz", chain=chain, noise=noise, cloud=cloud, latent=latent, T=T, w=5.75)
+
+
+def gen_horizon40(m40, sp40):
+    """A horizon other than the drivers' 48 / 64: n_support_points = 40 (levels of 40, 20, 10 and 5 tokens) -- the
+    reference takes any multiple of 8 (UnetInference.py:42-56).  One tapped score evaluation and a free-running DDPM chain."""
+    cloud = synth.make_cloud(6, 64, 2, seed=42)
+    gen_unet("2d_h40", m40, sp40, cloud, 4, 11, seed=13)
+    T, B = 25, 3
+    noise = synth.make_noise((T + 1, B, 40, 4), seed=14)
+    chain, used = run_static(m40, sp40, T, B, cloud, noise, ddim=False, use_apf=False)
+    assert used == T + 1
+    save("chain_ddpm_h40.npz", chain=chain, noise=noise, cloud=cloud, T=T)
 
 
 def gen_fullsize_seeds(m2, sp2, m3, sp3):
@@ -684,6 +697,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "config5":
         m3b, sp3b, _ = build_unet(6, 64, True)
         gen_chain3d_h64(m3b, sp3b); return
+    if len(sys.argv) > 1 and sys.argv[1] == "h40":
+        m40, sp40, _ = build_unet(4, 40, False)
+        gen_horizon40(m40, sp40); return
     if len(sys.argv) > 1 and sys.argv[1] == "cost":
         gen_cost(); return
     if len(sys.argv) > 1 and sys.argv[1] == "apf":
@@ -709,6 +725,7 @@ def main():
     print("replan"); gen_replan(m2, sp2)
     print("metrics"); gen_metrics()
     print("compat"); gen_compat()
+    print("horizon 40"); m40, sp40, _ = build_unet(4, 40, False); gen_horizon40(m40, sp40)
     print("done")
 
 

@@ -268,15 +268,14 @@ template <int L> static int attn2_set_attr() {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return 0;
 }
+// every token count a level of a horizon H = 8, 16, ..., 64 can have (H, H/2, H/4, H/8): the reference takes any
+// n_support_points divisible by 8 (UnetInference.py:42-56); the kernels mask rows >= L inside tiles of 16
+#define RAMP_ATTN_LENGTHS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(10) X(12) X(14) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56) X(64)
 int init_attention_attributes() {
-  if (int e = attn2_set_attr<6>()) return e;
-  if (int e = attn2_set_attr<8>()) return e;
-  if (int e = attn2_set_attr<12>()) return e;
-  if (int e = attn2_set_attr<16>()) return e;
-  if (int e = attn2_set_attr<24>()) return e;
-  if (int e = attn2_set_attr<32>()) return e;
-  if (int e = attn2_set_attr<48>()) return e;
-  return attn2_set_attr<64>();
+#define RAMP_ATTN_ATTR(LV) if (int e = attn2_set_attr<LV>()) return e;
+  RAMP_ATTN_LENGTHS(RAMP_ATTN_ATTR)
+#undef RAMP_ATTN_ATTR
+  return 0;
 }
 
 template <int L> static int fwd_launch(const float* qkv, float* o, int R, hipStream_t s) {
@@ -293,28 +292,18 @@ template <int L> static int bwd_launch(const float* qkv, const float* dout, floa
   return 0;
 }
 
-#define RAMP_ATTN_DISPATCH(FN, ...)                      \
-  switch (L) {                                           \
-    case 6: return FN<6>(__VA_ARGS__);                   \
-    case 8: return FN<8>(__VA_ARGS__);                   \
-    case 12: return FN<12>(__VA_ARGS__);                 \
-    case 16: return FN<16>(__VA_ARGS__);                 \
-    case 24: return FN<24>(__VA_ARGS__);                 \
-    case 32: return FN<32>(__VA_ARGS__);                 \
-    case 48: return FN<48>(__VA_ARGS__);                 \
-    case 64: return FN<64>(__VA_ARGS__);                 \
-    default: break;                                      \
-  }
+#define RAMP_ATTN_CASE_F(LV) case LV: return fwd_launch<LV>(qkv, o, R, s);
+#define RAMP_ATTN_CASE_B(LV) case LV: return bwd_launch<LV>(qkv, dout, dqkv, R, s);
 
 int launch_attn_fwd(const float* qkv, float* o, int R, int L, hipStream_t s) {
   RAMP_REQUIRE(R > 0, "empty attention");
-  RAMP_ATTN_DISPATCH(fwd_launch, qkv, o, R, s)
-  RAMP_REQUIRE(false, "attention kernel instantiated for L in {6,8,12,16,24,32,48,64} only");
+  switch (L) { RAMP_ATTN_LENGTHS(RAMP_ATTN_CASE_F) default: break; }
+  RAMP_REQUIRE(false, "attention kernels cover the level lengths of horizons 8, 16, ..., 64 only");
 }
 int launch_attn_bwd(const float* qkv, const float* dout, float* dqkv, int R, int L, hipStream_t s) {
   RAMP_REQUIRE(R > 0, "empty attention");
-  RAMP_ATTN_DISPATCH(bwd_launch, qkv, dout, dqkv, R, s)
-  RAMP_REQUIRE(false, "attention kernel instantiated for L in {6,8,12,16,24,32,48,64} only");
+  switch (L) { RAMP_ATTN_LENGTHS(RAMP_ATTN_CASE_B) default: break; }
+  RAMP_REQUIRE(false, "attention kernels cover the level lengths of horizons 8, 16, ..., 64 only");
 }
 
 }  // namespace ramp

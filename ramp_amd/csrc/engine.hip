@@ -924,7 +924,7 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
   RAMP_REQUIRE(cfg->state_dim >= 2 && cfg->state_dim <= 16, "state_dim out of range");
   RAMP_REQUIRE(cfg->n_levels == 4, "only UNET_DIM_MULTS[1] = (1,2,4,8) is built");
   RAMP_REQUIRE(cfg->unet_input_dim == 32, "unet_input_dim must be 32");
-  RAMP_REQUIRE(cfg->horizon == 48 || cfg->horizon == 64, "horizon must be 48 or 64 (attention kernel instantiations)");
+  RAMP_REQUIRE(cfg->horizon >= 8 && cfg->horizon <= 64 && cfg->horizon % 8 == 0, "horizon (n_support_points) must be a multiple of 8 in [8, 64] (three stride-2 levels; attention tiles of at most 64 tokens)");
   RAMP_REQUIRE(cfg->context_dim > 0 && cfg->context_dim <= 512, "context_dim out of range");
   RAMP_REQUIRE(cfg->max_rows >= 1, "max_rows must be positive");
   int ndev = 0;

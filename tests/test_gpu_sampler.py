@@ -534,3 +534,20 @@ def test_fp16x3_range_guard_trips_inside_ramp_sample(how):
     assert flag.value == 0
     assert np.abs(plain - g0["chain"]).max() < 1e-4
     assert not np.array_equal(plain, run(make_static(25, gemm_mode="bf16x6"), g0, 4)[0])   # the modes round differently
+
+
+def test_ddpm_chain_at_another_horizon():
+    """n_support_points = 40 (levels of 40, 20, 10 and 5 tokens): the reference takes any multiple of 8
+    (UnetInference.py:42-56) and so does the engine; free-running 25-step DDPM chain against a run of the reference."""
+    from ramp_amd.models import StaticGaussianDiffusionModel
+    g = np.load(f"{GOLDEN}/chain_ddpm_h40.npz")
+    u = build_unet(4, 40, False, max_rows=64)
+    dm = StaticGaussianDiffusionModel(model=u, variance_schedule="exponential", n_diffusion_steps=25, predict_epsilon=True,
+                                      compose=False, use_apf=False, sampler="ddpm", use_graph=True).eval().to("cuda")
+    chain, used = run(dm, g, g["chain"].shape[1])
+    assert used == g["noise"].shape[0] and chain.shape == g["chain"].shape
+    err = np.abs(chain - g["chain"]).max()
+    print(f"ddpm H=40: max {err:.2e}")
+    assert err < 1e-4
+    with pytest.raises(Exception):
+        build_unet(4, 44, False, max_rows=8).ctx()            # not a multiple of 8: refused at ramp_create, like the reference's shapes

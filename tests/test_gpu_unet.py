@@ -11,7 +11,7 @@ from util import GOLDEN, build_unet, dev, rel, weights
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("2d_h48", 4, 48, False), ("3d_h48", 6, 48, True), ("3d_h64", 6, 64, True)]
+CASES = [("2d_h48", 4, 48, False), ("3d_h48", 6, 48, True), ("3d_h64", 6, 64, True), ("2d_h40", 4, 40, False)]
 
 
 @pytest.mark.parametrize("gemm_mode", ["fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "bf16x6", "fp32"])

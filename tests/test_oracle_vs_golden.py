@@ -41,7 +41,7 @@ def test_schedule(T):
         assert rel(s[k], g[k]) < tol, k
 
 
-@pytest.mark.parametrize("tag,S,H,o3", [("2d_h48", 4, 48, False), ("3d_h48", 6, 48, True), ("3d_h64", 6, 64, True)])
+@pytest.mark.parametrize("tag,S,H,o3", [("2d_h48", 4, 48, False), ("3d_h48", 6, 48, True), ("3d_h64", 6, 64, True), ("2d_h40", 4, 40, False)])
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_unet_forward_and_score(tag, S, H, o3, dt):
     g = np.load(f"{G}/unet{tag}.npz")
