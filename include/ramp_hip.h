@@ -78,6 +78,9 @@ int ramp_finalize_weights(ramp_ctx* ctx);
  * these inside each forward; t is identical across the batch (make_timesteps,
  * diffusion_model_static.py:16-18) so they are tabulated once. */
 int ramp_prepare_time_table(ramp_ctx* ctx, int32_t T, void* stream);
+/* the TimeEncoder output itself for timestep t (SinusoidalPosEmb(32) -> Linear 32->128 -> Mish -> Linear 128->32,
+ * layers.py:233-259) as the table holds it: out32 device, 32 floats.  Parity tests compare it with the reference's. */
+int ramp_time_embedding(ramp_ctx* ctx, int32_t t, float* out32, void* stream);
 
 /* cache_scene_encoding + latent masking + attn2 (UnetInference.py:146-156,190-197;
  * layers_attention_mini.py:101-127): `latents` (n_variants, context_dim); an unconditional

@@ -78,6 +78,7 @@ PROTOTYPES = {
     "ramp_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, c_f32p, c_i64p, C.c_int32]),
     "ramp_finalize_weights": (C.c_int, [C.c_void_p]),
     "ramp_prepare_time_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ramp_time_embedding": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ramp_set_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_i32p, C.c_int32, C.c_void_p]),
     "ramp_encode_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ramp_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -243,6 +243,7 @@ struct TimeTableArgs {
   const float* w1; const float* b1; const float* w2; const float* b2;   // time_mlp
   const float* const* cond_w; const float* const* cond_b; const int* couts; const int* offs; int n_rtb;
   float* table; int stride; int T;
+  float* temb;          // optional (T, 32): the TimeEncoder output itself (layers.py:233-259), kept for ramp_time_embedding
 };
 int launch_time_table(const TimeTableArgs& a, hipStream_t s);
 // cross-attention bias: out[v][blk][256] = Wo_blk (Wv_blk lat[v]) + bo_blk

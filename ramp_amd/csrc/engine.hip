@@ -144,7 +144,7 @@ struct ramp_ctx {
   float *g_a = nullptr, *g_b = nullptr, *g_t1 = nullptr, *g_t2 = nullptr, *g_tr = nullptr;
   std::vector<float*> skip_grad;   // per level
   // time table / scene
-  float* time_table = nullptr; int tt_stride = 0, tt_T = 0;
+  float* time_table = nullptr; int tt_stride = 0, tt_T = 0; float* time_temb = nullptr;
   float* cross_bias = nullptr; int n_variants = 0; int* row_variant = nullptr; int row_variant_cap = 0;
   int n_blocks_total = 0;
   // device pointer tables for setup kernels
@@ -1195,7 +1195,7 @@ int ramp_prepare_time_table(ramp_ctx* c, int32_t T, void* stream) {
   std::memcpy(h.data() + 2 * n * sizeof(void*), couts.data(), n * sizeof(int));
   std::memcpy(h.data() + 2 * n * sizeof(void*) + n * sizeof(int), offs.data(), n * sizeof(int));
   RAMP_HIP_CHECK(hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice));
-  if (T > c->tt_T) { CK(dev_alloc(c, &c->time_table, (size_t)T * c->tt_stride)); }
+  if (T > c->tt_T) { CK(dev_alloc(c, &c->time_table, (size_t)T * c->tt_stride)); CK(dev_alloc(c, &c->time_temb, (size_t)T * 32)); }
   TimeTableArgs a;
   a.w1 = c->raw["time_mlp.encoder.1.weight"].first; a.b1 = c->raw["time_mlp.encoder.1.bias"].first;
   a.w2 = c->raw["time_mlp.encoder.3.weight"].first; a.b2 = c->raw["time_mlp.encoder.3.bias"].first;
@@ -1203,12 +1203,18 @@ int ramp_prepare_time_table(ramp_ctx* c, int32_t T, void* stream) {
   a.cond_b = reinterpret_cast<const float* const*>(d + n * sizeof(void*));
   a.couts = reinterpret_cast<const int*>(d + 2 * n * sizeof(void*));
   a.offs = reinterpret_cast<const int*>(d + 2 * n * sizeof(void*) + n * sizeof(int));
-  a.n_rtb = n; a.table = c->time_table; a.stride = c->tt_stride; a.T = T;
+  a.n_rtb = n; a.table = c->time_table; a.stride = c->tt_stride; a.T = T; a.temb = c->time_temb;
   int rc = launch_time_table(a, s);
   RAMP_HIP_CHECK(hipStreamSynchronize(s));
   RAMP_HIP_CHECK(hipFree(d));
   if (rc) return rc;
   c->tt_T = T;
+  return 0;
+}
+
+int ramp_time_embedding(ramp_ctx* c, int32_t t, float* out32, void* stream) {
+  RAMP_REQUIRE(c && out32 && c->time_temb && t >= 0 && t < c->tt_T, "time table not prepared for this t (ramp_prepare_time_table)");
+  RAMP_HIP_CHECK(hipMemcpyAsync(out32, c->time_temb + (size_t)t * 32, 32 * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
   return 0;
 }
 

@@ -526,6 +526,7 @@ __global__ __launch_bounds__(128) void time_table_kernel(TimeTableArgs a) {
     float acc = 0.f;
     for (int k = 0; k < 128; ++k) acc += hid[k] * a.w2[tid * 128 + k];
     const float te = acc + a.b2[tid];
+    if (a.temb) a.temb[(long)t * 32 + tid] = te;
     st[tid] = te / (1.f + expf(-te));           // SiLU feeding every cond_mlp (layers.py:340-344)
   }
   __syncthreads();

@@ -175,6 +175,15 @@ class TemporalUnetInference(nn.Module):
                            "ramp_prepare_time_table")
             self._T_table = int(T)
 
+    def time_embedding(self, t: int) -> torch.Tensor:
+        """The TimeEncoder output for timestep t (layers.py:233-259) as the engine's time table holds it, (32,)."""
+        self.prepare_time_table(int(t) + 1)
+        out = torch.empty(32, device=self._device(), dtype=torch.float32)
+        with torch.cuda.device(self._device()):
+            _lib.check(_lib.load().ramp_time_embedding(self.ctx(), int(t), _lib.ptr(out), _lib.current_stream()),
+                       "ramp_time_embedding")
+        return out
+
     # ------------------------------------------------------------------ scene
     @torch.no_grad()
     def encode_scene(self, cloud: torch.Tensor) -> torch.Tensor:

@@ -459,6 +459,39 @@ def test_dynamic_replanning_loop_against_reference_run(impl):
     assert np.abs(sphere.centers.numpy() - g["pursuer_final"]).max() < 1e-4
 
 
+def test_dynamic_replanning_reference_run_embedded_in_a_large_batch():
+    """The planner's numerics at a batch the large-launch kernels serve (B = 768 candidates: 73728 tokens at the first
+    level, the token-owning fused feed-forward path): the six candidates of the reference run (replan_chain.npz) tiled 128
+    times.  Replicas tie with their originals and the selection takes the FIRST minimum (torch.argmin), so the plan evolves
+    exactly as in the reference run: every ranked batch's first six rows, every selected index, every collision mask."""
+    from ramp_amd.models import DynamicGaussianDiffusionModel
+    from util import NoiseInjector, StopReplan, make_fake_pursuit_env
+    g = np.load(f"{GOLDEN}/replan_chain.npz")
+    K = int(g["n_iter"]); B0, H, S = g["noise"].shape[1:]
+    rep = 128; B = B0 * rep
+    u = build_unet(4, 48, False, max_rows=2 * B)
+    dm = DynamicGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True, use_graph=True).eval().to("cuda")
+    log_env = []
+    dataset, sphere = make_fake_pursuit_env(stop_at=K, log=log_env)
+    hard = {0: dev(g["hard0"]).repeat(B, 1), H - 1: dev(g["hardN"]).repeat(B, 1)}
+    np.random.seed(23)
+    dm.replan_log = []
+    with NoiseInjector([np.tile(n, (rep, 1, 1)) for n in g["noise"]]):
+        with pytest.raises(StopReplan):
+            dm.ddim_p_sample_loop((B, H, S), hard, context={'dataset': dataset}, return_chain=True, obstacle_pts=dev(g["cloud"]))
+    assert len(dm.replan_log) == int(g["n_cost"]) and len(log_env) == int(g["n_env"])
+    errs = []
+    for j, e in enumerate(dm.replan_log):
+        tr = e["batch"].cpu().numpy()
+        errs.append(float(np.abs(tr[:B0] - g[f"cost{j}/trajs"]).max()))
+        assert float(np.abs(tr.reshape(rep, B0, H, S) - tr[:B0]).max()) < 1e-5          # replicas stay with their originals
+        assert e["idx"] == int(g[f"cost{j}/idx"]), (j, e["idx"])                        # rank among the free ones: the winner is an original
+        assert np.array_equal(e["free"].cpu().numpy(), np.tile(g[f"cost{j}/free"], rep)), j
+    print("large-batch replan errs", errs)
+    assert errs[0] < 1e-4 and max(errs) < 2e-4
+    assert np.abs(sphere.centers.numpy() - g["pursuer_final"]).max() < 1e-4
+
+
 def test_dynamic_run_inference_terminates_and_respects_constraints():
     """run_inference end to end with the fake env: start near the goal so the loop ends on its own; the returned
     chain / chain_obs / chain_start have the reference's shapes and the executed history is inpainted."""

@@ -45,6 +45,8 @@ def test_score_against_reference_fixture(tag, S, H, o3, gemm_mode):
     assert m.score_mode() == gemm_mode
     # tolerance stated by BASELINE.json: 1e-4 relative fp32; measured headroom is ~30x
     assert rel(m.cached_scene_latents[0].cpu().numpy(), g["latent"]) < 5e-6
+    # the time embedding itself (TimeEncoder, layers.py:233-259), not only its effect through the residual blocks
+    assert rel(m.time_embedding(int(g["t"][0])).cpu().numpy(), g["temb"][0]) < 5e-6
     assert rel(f, g["f"]) < 2e-5
     assert rel(eps, g["eps"]) < 5e-5
     worst = 0.0
