@@ -147,7 +147,11 @@ def profile_gemm(dm, B, cloud, hard_conds):
     return {n: {"ms": ms[i], "flops": fl[i], "launches": int(cnt[i])} for i, n in enumerate(names)}
 
 
-PMC_FILE = "profiles/r02_pmc_traffic.json"
+PMC_FILE = "profiles/r03_pmc_traffic.json"
+SUSTAINED_FP32EQ_TFLOPS = 510.0        # profiles/r02_power_clocks.txt: the bare fp16x3 MFMA + LDS-read loop sustains 491-530 TFLOP/s (fp32-
+                                       # equivalent) at the 1.4 kW socket limit, i.e. 0.59-0.64 of the 833.3 nominal ceiling
+STASH_BYTES_PER_ROW_EVAL = 4.0e6       # what ONE score evaluation must keep per network row for the input
+                                       # gradient (conv outputs, norm statistics, per block-token z, qkv, z1, GEGLU stash)
 
 
 def pmc_traffic(klass):
@@ -161,6 +165,16 @@ def pmc_traffic(klass):
         return float(d[klass]["hbm_bytes_per_launch"]), f"{PMC_FILE} ({d.get('collected', 'separate rocprofv3 --pmc passes')})"
     except Exception:
         return None, "no PMC summary committed for this round"
+
+
+def pmc_total():
+    """HBM bytes of one whole score evaluation (all kernel classes) from the committed PMC summary, or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)
+    try:
+        with open(path) as fh:
+            return float(json.load(fh)["total_hbm_bytes_per_evaluation"])
+    except Exception:
+        return None
 
 
 def host_cores():
@@ -403,6 +417,15 @@ def main():
             "launches_per_step": g["launches"], "avg_launch_us": avg_us,
             "algorithmic_gflop_per_launch": g["flops"] / max(g["launches"], 1) / 1e9,
             "share_of_kernel_time": g["ms"] / total_ms,
+            # the waste, visible in the line: what the design must move per step (every row's stash written once and read
+            # once, 2 x 4.0 MB per network row and evaluation) against what the PMC counters saw it move
+            "algorithmic_bytes_per_step": 2 * STASH_BYTES_PER_ROW_EVAL * (2 * B) * WL["T"],
+            "traffic_bytes_per_step": (pmc_total() or 0.0) * WL["T"] * (2 * B / 8192.0) or None,
+            "traffic_ratio": ((pmc_total() or 0.0) * (2 * B / 8192.0)) / (2 * STASH_BYTES_PER_ROW_EVAL * 2 * B) if pmc_total() else None,
+            "sustained_ceiling_tflops": SUSTAINED_FP32EQ_TFLOPS,
+            "frac_of_sustained": achieved / SUSTAINED_FP32EQ_TFLOPS,
+            "class_note": "the GEMM class mixes fp16x3 launches (833.3 ceiling) with the exact-fp32 N = 32 layers (157.3 ceiling, ~2 % of "
+                          "its time) and, in a job that calibrates, bf16x6 launches: frac is a lower bound for the fp16x3 kernels",
             "kernel_time_ms_by_class": {k: round(v["ms"], 3) for k, v in prof.items()},
         }
     elif rank == 0:

@@ -305,6 +305,12 @@ int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* 
  * 32 force 3 blocks per CU. */
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream);
+/* stress form of the micro-benchmark (tests): `iters` back-to-back launches of the kernel `mode` / `flags` name on the same
+ * operands, every launch's output compared bit for bit with the first one's on the device (*mismatching_words: 32-bit words
+ * that ever differed; a deterministic kernel gives 0), and -- modes 1..4, rel_err_vs_fp32 non-NULL -- the first output
+ * against the exact-fp32 MFMA kernel's on the same operands (max |diff| / max |ref|; -1 where there is no fp32 twin). */
+int ramp_stress_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags, int32_t iters,
+                     int64_t* mismatching_words, float* rel_err_vs_fp32, void* stream);
 int ramp_op_groupnorm(const float* x, const float* gamma, const float* beta, const float* tbias,
                       const float* resid, float* y, float* stats, int32_t R, int32_t L, int32_t C,
                       float eps, int32_t mish, void* stream);

@@ -1620,7 +1620,9 @@ int ramp_replan(ramp_ctx* c, const ramp_replan_params* p, const ramp_replan_stat
     RAMP_HIP_CHECK(hipGraphLaunch(c->r_graph[which], s));
     return 0;
   };
-  CK(run(h3 && !c->r_calibrated));
+  // a one-step replan has no second table to carry its maxima in (its only evaluation reads and clears table 2): it always
+  // calibrates, on the bf16x6 kernels, instead of running fp16x3 from an empty table
+  CK(run(h3 && (!c->r_calibrated || p->n_steps == 1)));
   // ---- the one read-back of a replan: {n_free, rank, row} + the range flag
   int back[4] = {0, 0, 0, 0};
   RAMP_HIP_CHECK(hipMemcpyAsync(back, c->r_result, 12, hipMemcpyDeviceToHost, s));
@@ -1680,14 +1682,29 @@ int ramp_replan_costs(ramp_ctx* c, int32_t B, int32_t* mask_out, float* path_len
 namespace {
 struct HostArgRing {
   static constexpr int RING = 64, SLOT = 1024;       // bytes per slot: 129 window weights or 256 indices
-  char* base = nullptr; int next = 0; int device = -1;
+  // one ring per device (a thread that alternates devices keeps both); every slot carries the event recorded behind the
+  // kernel that reads it, on whatever stream that was: before a slot is reused the event is waited for, so calls on
+  // different streams cannot overwrite an array an earlier kernel has not read yet (normally complete long ago: 63 calls)
+  struct PerDevice { char* base = nullptr; int next = 0; hipEvent_t ev[RING] = {}; bool used[RING] = {}; };
+  std::map<int, PerDevice> rings;
+  int cur_dev = -1, cur_slot = -1;
   int stage(const void* host, size_t bytes, hipStream_t s, void** out) {
     RAMP_REQUIRE(bytes <= (size_t)SLOT, "host argument array too long");
     int dev = 0; RAMP_HIP_CHECK(hipGetDevice(&dev));
-    if (!base || dev != device) { RAMP_HIP_CHECK(hipMalloc(&base, (size_t)RING * SLOT)); device = dev; next = 0; }
-    char* p = base + (size_t)(next++ % RING) * SLOT;
+    PerDevice& r = rings[dev];
+    if (!r.base) RAMP_HIP_CHECK(hipMalloc(&r.base, (size_t)RING * SLOT));
+    const int slot = r.next++ % RING;
+    if (r.used[slot]) RAMP_HIP_CHECK(hipEventSynchronize(r.ev[slot]));
+    else { RAMP_HIP_CHECK(hipEventCreateWithFlags(&r.ev[slot], hipEventDisableTiming)); r.used[slot] = true; }
+    char* p = r.base + (size_t)slot * SLOT;
     RAMP_HIP_CHECK(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, s));
-    *out = p;
+    *out = p; cur_dev = dev; cur_slot = slot;
+    return 0;
+  }
+  // after the kernel that reads the staged array has been launched on `s`
+  int done(hipStream_t s) {
+    if (cur_slot >= 0) RAMP_HIP_CHECK(hipEventRecord(rings[cur_dev].ev[cur_slot], s));
+    cur_slot = -1;
     return 0;
   }
 };
@@ -1703,7 +1720,7 @@ int ramp_apf(float* traj, int32_t B, int32_t H, int32_t S, const ramp_apf_params
   ApfArgs a; a.traj = traj; a.cloud = p->cloud; a.window = static_cast<const float*>(w); a.B = B; a.H = H; a.S = S;
   a.P = p->n_points; a.win = p->window; a.thr = p->threshold; a.strength = p->strength;
   for (int q = 0; q < std::max(1, p->passes); ++q) CK(launch_apf(a, s));
-  return 0;
+  return g_ring.done(s);
 }
 
 int ramp_apf_dynamic(float* traj, int32_t B, int32_t H, int32_t S, const double* points, int32_t n_points,
@@ -1726,7 +1743,8 @@ int ramp_hard_cond(float* x, int32_t B, int32_t H, int32_t S, int32_t n, const i
   void* d = nullptr;
   CK(g_ring.stage(idx_host, (size_t)n * 4, s, &d));
   HardConds hc; hc.idx = static_cast<const int*>(d); hc.val = val; hc.n = n;
-  return launch_hard_cond(x, hc, B, H, S, s);
+  CK(launch_hard_cond(x, hc, B, H, S, s));
+  return g_ring.done(s);
 }
 
 int ramp_traj_costs(const float* traj, int32_t B, int32_t H, int32_t S, const float* cloud, int32_t n_points,
@@ -1912,6 +1930,50 @@ __global__ void fill_uniform_kernel(float* p, long n, unsigned seed, float scale
     p[i] = ((float)(h >> 8) * (1.f / 8388608.f) - 1.f) * scale;
   }
 }
+// ---- stress hook of the micro-benchmark: every launch's output against the first one's, bit for bit ------------------------
+namespace {
+__global__ void stress_cmp_kernel(const unsigned* __restrict__ a, const unsigned* __restrict__ b, long n, unsigned long long* mism) {
+  unsigned long long c = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) c += a[i] != b[i];
+  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(mism, c);
+}
+__global__ void stress_err_kernel(const float* __restrict__ a, const float* __restrict__ ref, long n, unsigned* out /* [max |a - ref|, max |ref|] as float bits */) {
+  float e = 0.f, r = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { e = fmaxf(e, fabsf(a[i] - ref[i])); r = fmaxf(r, fabsf(ref[i])); }
+  for (int m = 32; m >= 1; m >>= 1) { e = fmaxf(e, __shfl_xor(e, m)); r = fmaxf(r, __shfl_xor(r, m)); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(out, __builtin_bit_cast(unsigned, e)); atomicMax(out + 1, __builtin_bit_cast(unsigned, r)); }
+}
+struct StressHook {
+  bool capture_ref = false;      // this run only provides the reference output (the exact-fp32 kernel)
+  float* first = nullptr; float* ref = nullptr; long n = 0; long launches = 0;
+  unsigned long long* mism = nullptr; unsigned* err = nullptr;
+  // after a launch that wrote `out` (n floats)
+  int check(const float* out, long nf, hipStream_t s) {
+    if (capture_ref) {
+      if (!ref) { RAMP_HIP_CHECK(hipMalloc(&ref, nf * 4)); n = nf; }
+      RAMP_HIP_CHECK(hipMemcpyAsync(ref, out, nf * 4, hipMemcpyDeviceToDevice, s));
+      return 0;
+    }
+    if (!mism) { RAMP_HIP_CHECK(hipMalloc(&mism, 16)); RAMP_HIP_CHECK(hipMemsetAsync(mism, 0, 16, s)); err = reinterpret_cast<unsigned*>(mism) + 2; }
+    if (!first) {
+      RAMP_HIP_CHECK(hipMalloc(&first, nf * 4));
+      RAMP_HIP_CHECK(hipMemcpyAsync(first, out, nf * 4, hipMemcpyDeviceToDevice, s));
+      if (ref && n == nf) hipLaunchKernelGGL(stress_err_kernel, dim3(2048), dim3(256), 0, s, out, ref, nf, err);
+    } else {
+      hipLaunchKernelGGL(stress_cmp_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const unsigned*>(out),
+                         reinterpret_cast<const unsigned*>(first), nf, mism);
+    }
+    ++launches;
+    RAMP_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  ~StressHook() { if (first) (void)hipFree(first); if (ref) (void)hipFree(ref); if (mism) (void)hipFree(mism); }
+};
+thread_local StressHook* g_stress = nullptr;
+#define STRESS(ptr_, n_, s_) do { if (g_stress) CK(g_stress->check((ptr_), (long)(n_), (s_))); } while (0)
+}  // namespace
+
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
   RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 7, "bad arguments");
@@ -1943,7 +2005,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
     RAMP_HIP_CHECK(hipEventRecord(e0, s6));
     int rc6 = 0;
-    for (int i = 0; i < iters && rc6 == 0; ++i) rc6 = go6();
+    for (int i = 0; i < iters && rc6 == 0; ++i) { rc6 = go6(); if (rc6 == 0) STRESS(out, (size_t)M * 256, s6); }
     RAMP_HIP_CHECK(hipEventRecord(e1, s6));
     RAMP_HIP_CHECK(hipEventSynchronize(e1));
     float ms6 = 0.f;
@@ -1987,7 +2049,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
     RAMP_HIP_CHECK(hipEventRecord(e0, s5));
     int rc5 = 0;
-    for (int i = 0; i < iters && rc5 == 0; ++i) rc5 = launch_ff_fwd(g1, g2, s5);
+    for (int i = 0; i < iters && rc5 == 0; ++i) { rc5 = launch_ff_fwd(g1, g2, s5); if (rc5 == 0) STRESS(z2, (size_t)M * 256, s5); }
     RAMP_HIP_CHECK(hipEventRecord(e1, s5));
     RAMP_HIP_CHECK(hipEventSynchronize(e1));
     float ms5 = 0.f;
@@ -2056,7 +2118,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
   RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
   RAMP_HIP_CHECK(hipEventRecord(e0, s));
   int rc = 0;
-  for (int i = 0; i < iters && rc == 0; ++i) rc = go();
+  for (int i = 0; i < iters && rc == 0; ++i) { rc = go(); if (rc == 0) STRESS(C, (size_t)M * N, s); }
   RAMP_HIP_CHECK(hipEventRecord(e1, s));
   RAMP_HIP_CHECK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -2064,6 +2126,34 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *avg_us = ms * 1e3f / iters;
   return rc;
+}
+
+int ramp_stress_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags, int32_t iters,
+                     int64_t* mismatching_words, float* rel_err_vs_fp32, void* stream) {
+  RAMP_REQUIRE(mismatching_words && iters >= 2, "bad arguments");
+  StressHook hook;
+  float us = 0.f;
+  g_stress = &hook;
+  int rc = 0;
+  if (rel_err_vs_fp32 && mode >= 1 && mode <= 4) {     // the same operands (seeded fills) on the exact-fp32 MFMA kernel first
+    hook.capture_ref = true;
+    rc = ramp_bench_gemm(M, N, K, taps, L, 0, flags & 0xff, 0, 1, &us, stream);
+    hook.capture_ref = false;
+  }
+  if (rc == 0) rc = ramp_bench_gemm(M, N, K, taps, L, mode, flags, 0, iters, &us, stream);
+  g_stress = nullptr;
+  if (rc != 0) return rc;
+  unsigned long long h[2] = {0, 0};
+  RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  if (hook.mism) RAMP_HIP_CHECK(hipMemcpy(h, hook.mism, 16, hipMemcpyDeviceToHost));
+  RAMP_REQUIRE(hook.launches == iters, "stress hook did not see every launch");
+  *mismatching_words = (int64_t)h[0];
+  if (rel_err_vs_fp32) {
+    const unsigned e = (unsigned)(h[1] & 0xffffffffu), r = (unsigned)(h[1] >> 32);
+    const float ef = __builtin_bit_cast(float, e), rf = __builtin_bit_cast(float, r);
+    *rel_err_vs_fp32 = (hook.ref && rf > 0.f) ? ef / rf : -1.f;
+  }
+  return 0;
 }
 
 int ramp_op_groupnorm(const float* x, const float* gamma, const float* beta, const float* tbias, const float* resid,

@@ -150,13 +150,22 @@ class _GaussianDiffusionBase(nn.Module):
             # recycled by the caching allocator for the next same-shaped cloud
             key = (tuple(obstacle_pts.shape), tuple(pattern))
             ref = getattr(m, '_scene_ref', None)
-            if (getattr(m, '_scene_key', None) == key and ref is not None and ref.device == obstacle_pts.device
-                    and ref.dtype == obstacle_pts.dtype and torch.equal(ref, obstacle_pts)):
-                return
+            if obstacle_pts.device != self._device():        # a CPU-resident cloud is compared (and encoded) on the device
+                obstacle_pts = obstacle_pts.to(self._device())
+            if getattr(m, '_scene_key', None) == key and ref is not None and ref.dtype == obstacle_pts.dtype:
+                # fast path: the very tensor seen last time, unmodified since (no device reduction, no host sync)
+                ident = (obstacle_pts.data_ptr(), obstacle_pts._version, id(obstacle_pts))
+                if getattr(m, '_scene_ident', None) == ident and getattr(m, '_scene_src', None) is obstacle_pts:
+                    return
+                if torch.equal(ref, obstacle_pts):
+                    m._scene_ident, m._scene_src = ident, obstacle_pts
+                    return
             lat = torch.cat([m.encode_scene(obstacle_pts), zero])
         m.set_scene(lat, pattern)
         m._scene_key = None if self.compose else key
         m._scene_ref = None if self.compose else obstacle_pts.detach().clone()
+        m._scene_ident = None if self.compose else (obstacle_pts.data_ptr(), obstacle_pts._version, id(obstacle_pts))
+        m._scene_src = None if self.compose else obstacle_pts       # (kept alive: its id / data_ptr cannot be recycled)
         m.cached_batch_size = None          # the compat forward() cache is keyed differently
 
     @staticmethod

@@ -433,3 +433,36 @@ def test_ffx_fused_feed_forward_against_float64_autograd(M):
     assert max(e2) < 3e-6 and flag.value == 0, (e2, flag.value)
     go([rec[0] / 4096.0, rec[1], rec[2], rec[3]])             # LN output 2^12 larger than the scale assumes: overflow guard
     assert flag.value == 1, flag.value
+
+
+STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, compare with the exact-fp32 kernel?
+    ("fp16x3 bias-only 768x256 (QKV; third resident block)", 393216, 768, 256, 1, 1, 3, 1, True),
+    ("fp16x3 residual 256x256 (out-proj, 64x256 tile)", 393216, 256, 256, 1, 1, 3, 3, True),
+    ("fp16x3 1024x256 (d(hg))", 393216, 1024, 256, 1, 1, 3, 1, True),
+    ("fp16x3 256x768 (d(ln1))", 393216, 256, 768, 1, 1, 3, 1, True),
+    ("fp16x3 A-multiplier 256x2048 (FF1 dX)", 393216, 256, 2048, 1, 1, 3, 8, False),   # (no exact-fp32 twin of the fused operand)
+    ("fp16x3 GEGLU-forward epilogue 2048x256", 393216, 2048, 256, 1, 1, 3, 1 | 4, False),
+    ("fp16x3 5-tap convolution 64x64, L=48", 393216, 64, 64, 5, 48, 3, 1, True),
+    ("fp16x3 5-tap convolution 128x128, L=24", 196608, 128, 128, 5, 24, 3, 1, True),
+    ("bf16x6 residual 256x256", 393216, 256, 256, 1, 1, 1, 3, True),
+    ("fused FF1->GEGLU->FF2 forward (ff_fwd_kernel)", 393216, 2048, 256, 1, 1, 5, 0, False),
+    ("token-owning fused feed-forward, forward (ffx)", 393216, 2048, 256, 1, 1, 6, 0, False),
+    ("token-owning fused feed-forward, backward (ffx)", 393216, 2048, 256, 1, 1, 7, 0, False),
+]
+
+
+@pytest.mark.parametrize("name,M,N,K,taps,L,mode,flags,vs_fp32", STRESS_CASES, ids=[c[0].split(" (")[0].replace(" ", "-") for c in STRESS_CASES])
+def test_gemm_variants_are_bitwise_stable_under_stress(name, M, N, K, taps, L, mode, flags, vs_fp32):
+    """Every shipped GEMM variant at full size, 300 back-to-back launches on the same operands: each launch's output is
+    compared BIT FOR BIT with the first one's on the device (hand-pipelined loaders with register stages across tile
+    boundaries, LDS rings filled by DMA, wave-private epilogues: a latent ordering hazard shows up as a sporadic stale
+    operand row, i.e. a handful of differing words in one launch out of many), and the first output sits within fp32
+    rounding of the exact-fp32 MFMA kernel's on the same operands."""
+    import ctypes as C
+    mism, err = C.c_int64(-1), C.c_float(-2.0)
+    _lib.check(_lib.load().ramp_stress_gemm(M, N, K, taps, L, mode, flags, 300, C.byref(mism), C.byref(err) if vs_fp32 else None, None),
+               "ramp_stress_gemm")
+    print(f"{name}: 300 launches, {mism.value} differing words" + (f", first launch vs exact fp32: {err.value:.2e}" if vs_fp32 else ""))
+    assert mism.value == 0, name
+    if vs_fp32:
+        assert 0.0 <= err.value < 5e-6, (name, err.value)
