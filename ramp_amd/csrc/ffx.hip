@@ -47,7 +47,8 @@ namespace {
 constexpr int FX_SLAB = 32 * 1024;                      // bytes per ring slot: 8 macro-steps x 4 fragments x 1 KB
 constexpr int FX_R = 4;                                 // ring slots
 constexpr int FX_B1 = FX_R * FX_SLAB;                   // forward: the packed b1 (2048 floats) behind the ring
-constexpr size_t FX_LDS = (size_t)FX_R * FX_SLAB + 2048 * 4;
+constexpr int FX_LN = FX_B1 + 2048 * 4;                   // LayerNorm-3 gamma (256) and beta (256) behind b1
+constexpr size_t FX_LDS = (size_t)FX_R * FX_SLAB + 2048 * 4 + 512 * 4;
 constexpr int FX_SLABS = 96;                            // slabs per 128-token tile (32 units x 3)
 static_assert(FX_LDS <= 160 * 1024, "LDS budget");
 
@@ -270,12 +271,19 @@ void ffx_kernel(FfxArgs f, int n_mt) {
     float* b1s = reinterpret_cast<float*>(smem + FX_B1);
     for (int i = tid; i < 512; i += 256) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(f.b1)[i];
   }
+  {   // gamma | beta through LDS: 64 broadcast reads per tile and lane that would otherwise be vector-memory loads
+    float* lns = reinterpret_cast<float*>(smem + FX_LN);
+    if (tid < 64) reinterpret_cast<f32x4*>(lns)[tid] = reinterpret_cast<const f32x4*>(f.ln_g)[tid];
+    else if (tid < 128 && f.ln_b) reinterpret_cast<f32x4*>(lns)[tid] = reinterpret_cast<const f32x4*>(f.ln_b)[tid - 64];
+  }
   issue_slab(); issue_slab(); issue_slab();
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // slab 0 (my share)
   __syncthreads();                                           // (also publishes b1 in LDS)
   read_macro(F[0], 0, 0); read_macro(F[1], 0, 1);
 
   const float* b1s = reinterpret_cast<const float*>(smem + FX_B1);
+  const float* lng = reinterpret_cast<const float*>(smem + FX_LN);
+  const float* lnb = lng + 256;
 
   for (int ti = 0; ti < n_my; ++ti) {
     const int mt = (int)blockIdx.x + ti * (int)gridDim.x;
@@ -309,7 +317,7 @@ void ffx_kernel(FfxArgs f, int n_mt) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
           const int k = 16 * (i >> 1) + 8 * h + 4 * (i & 1);
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(f.ln_g + k), bt = *reinterpret_cast<const f32x4*>(f.ln_b + k);
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(lng + k), bt = *reinterpret_cast<const f32x4*>(lnb + k);
 #pragma unroll
           for (int e = 0; e < 4; ++e) xv[i][e] = (xv[i][e] - mean) * rstd * gm[e] + bt[e];
         }
@@ -520,7 +528,7 @@ void ffx_kernel(FfxArgs f, int n_mt) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 32; ++i) {                          // i = 4 nb + q
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(f.ln_g + 8 * i + 4 * h);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(lng + 8 * i + 4 * h);
         f32x4 gq = quad(acc2[i >> 2], i & 3) * os2 * gm;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -540,6 +548,11 @@ void ffx_kernel(FfxArgs f, int n_mt) {
         if (tok_ok) *reinterpret_cast<f32x4*>(orow + 8 * i) = o;
       }
     }
+    // A wave must not carry more than 63 vector-memory operations (vmcnt is a 6-bit counter: beyond it the waits hipcc
+    // computes can release early -- the cause of the sporadic stale operand rows of round 2's LayerNorm-in-the-loader GEGLU
+    // variant, 70 in flight).  Here: 32 epilogue stores + up to 16 LDS-DMA pieces + the next tile's 32 row loads; retiring
+    // all but the youngest 24 before the next tile bounds the count at 56.
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   }
 #undef FX_PIECE
 #undef FX_MAC_HEAD
