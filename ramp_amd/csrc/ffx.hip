@@ -652,17 +652,8 @@ int launch_ffx(const FfxArgs& f, bool bwd, hipStream_t s) {
   if (f.ablate == 0) { if (bwd) FX_GO(true, 0); else FX_GO(false, 0); }
   else if (f.ablate == 1) { if (bwd) FX_GO(true, 1); else FX_GO(false, 1); }
   else if (f.ablate == 2) { if (bwd) FX_GO(true, 2); else FX_GO(false, 2); }
-  else if (f.ablate == 4) { if (bwd) FX_GO(true, 4); else FX_GO(false, 4); }
-  else if (f.ablate == 7) { if (bwd) FX_GO(true, 7); else FX_GO(false, 7); }
-  else if (f.ablate == 16) { if (bwd) FX_GO(true, 16); else FX_GO(false, 16); }
-  else if (f.ablate == 32) { if (bwd) FX_GO(true, 32); else FX_GO(false, 32); }
-  else if (f.ablate == 40) { if (bwd) FX_GO(true, 40); else FX_GO(false, 40); }
   else if (f.ablate == 64) { if (bwd) FX_GO(true, 64); else FX_GO(false, 64); }
   else if (f.ablate == 66) { if (bwd) FX_GO(true, 66); else FX_GO(false, 66); }
-  else if (f.ablate == 68) { if (bwd) FX_GO(true, 68); else FX_GO(false, 68); }
-  else if (f.ablate == 65) { if (bwd) FX_GO(true, 65); else FX_GO(false, 65); }
-  else if (f.ablate == 67) { if (bwd) FX_GO(true, 67); else FX_GO(false, 67); }
-  else if (f.ablate == 192) { if (bwd) FX_GO(true, 192); else FX_GO(false, 192); }
   else RAMP_REQUIRE(false, "ffx: ablation variant not built");
 #undef FX_GO
   RAMP_HIP_CHECK(hipGetLastError());
@@ -671,9 +662,7 @@ int launch_ffx(const FfxArgs& f, bool bwd, hipStream_t s) {
 
 int init_ffx_attributes() {
 #define FX_ATTR(B, A) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffx_kernel<B, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS))
-  FX_ATTR(false, 0); FX_ATTR(true, 0); FX_ATTR(false, 1); FX_ATTR(true, 1); FX_ATTR(false, 2); FX_ATTR(true, 2);
-  FX_ATTR(false, 4); FX_ATTR(true, 4); FX_ATTR(false, 7); FX_ATTR(true, 7); FX_ATTR(false, 16); FX_ATTR(true, 16);
-  FX_ATTR(false, 32); FX_ATTR(true, 32); FX_ATTR(false, 40); FX_ATTR(true, 40); FX_ATTR(false, 64); FX_ATTR(true, 64); FX_ATTR(false, 65); FX_ATTR(true, 65); FX_ATTR(false, 67); FX_ATTR(true, 67); FX_ATTR(false, 192); FX_ATTR(true, 192); FX_ATTR(false, 66); FX_ATTR(true, 66); FX_ATTR(false, 68); FX_ATTR(true, 68);
+  FX_ATTR(false, 0); FX_ATTR(true, 0); FX_ATTR(false, 1); FX_ATTR(true, 1); FX_ATTR(false, 2); FX_ATTR(true, 2); FX_ATTR(false, 64); FX_ATTR(true, 64); FX_ATTR(false, 66); FX_ATTR(true, 66);
 #undef FX_ATTR
   return 0;
 }
