@@ -57,7 +57,9 @@ typedef struct ramp_launch_plan {
   int32_t share_prefix;   /* sampling jobs: the CFG rows of a trajectory share the network prefix (0 / 1) */
   int32_t three_blocks;   /* a third resident block for the bias-only linears where it measured faster (0 / 1) */
   int32_t x6_pipe;        /* fragment-packed weights + pipelined split-precision kernels (1) or LDS-staged weights (0) */
-  int32_t reserved[3];
+  int32_t tkl_rows;       /* K = 256 transformer linears (LayerNorm-1 -> QKV with the norm folded in, attention out-projection, its
+                           * input gradient) on the token-owning kernel (tkl.hip) from this many tokens: 0 never, 1 always */
+  int32_t reserved[2];
 } ramp_launch_plan;
 int ramp_get_launch_plan(ramp_ctx* ctx, ramp_launch_plan* out);
 int ramp_set_launch_plan(ramp_ctx* ctx, const ramp_launch_plan* plan);
@@ -298,6 +300,16 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
 int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
                 const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
                 float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
+/* Token-owning linear layer with K = 256 (tkl.hip; the product path uses it for LayerNorm-1 -> QKV, the attention output
+ * projection and its input gradient -- reference layers_attention_mini.py:60-120, 130-149):
+ *   Y[m][n] = sum_k pro(X)[m][k] W[n][k] + bias[n] + rowbias[rowvar[m / L]][n] + resid[m][n],  pro = LayerNorm(256) when ln_g
+ * is given, identity otherwise.  X (M, 256), W (N, 256) with N a multiple of 32 (<= 768), Y / resid (M, N), rowbias
+ * (n_var, N) with N == 256, all device fp32; bias / resid / rowbias / ln_g, ln_b may be NULL.  absmax_prev: the operand
+ * maximum the delayed fp16 scaling assumes (0 = unscaled); *absmax_out_host the maximum recorded, *range_flag_out_host the
+ * range guard.  Packs the weight on every call (tests). */
+int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
+                const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
+                float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
 /* micro-benchmark (profiling tools only): one GEMM shape on the kernel `mode` names (as ramp_op_gemm_mode), operands
  * allocated and filled inside, weights packed once, `warmup` untimed then `iters` timed back-to-back launches on `stream`
  * between two HIP events; *avg_us = microseconds per launch.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue

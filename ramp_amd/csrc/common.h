@@ -117,6 +117,24 @@ int ffx_pack_second(const float* W, int rows, int cols, int mode, float scale, f
 int ffx_build_stream(const unsigned short* p1, const unsigned short* p2, unsigned short* out, bool bwd, hipStream_t s);
 int init_ffx_attributes();
 
+// Token-owning linear layer with K = 256 (tkl.hip): Y[m][n] = sum_k pro(X)[m][k] W[n][k] (+ bias[n]) (+ rowbias[rowvar[row0 + m / L]][n])
+// (+ resid[m][n]); pro = identity or LayerNorm(256).  fp16x3 products, delayed scale / maxima / range guard of ONE call site.
+struct TklArgs {
+  int M = 0, N = 0;                    // tokens; output features (multiple of 32, <= 768)
+  const float* X = nullptr;            // [M][256]
+  float* Y = nullptr; int ldy = 0;
+  const unsigned short* W = nullptr;   // fp16 fragment planes of W [N][256] as launch_pack_h3 writes them (= the weight stream: 32 KB per 32 features)
+  const float* bias = nullptr;
+  const float* resid = nullptr; int ldr = 0;
+  const float* rowbias = nullptr; const int* rowvar = nullptr; int row0 = 0, rb_stride = 0, L = 1, n_var = 0;   // N == 256 only
+  const float* ln_g = nullptr; const float* ln_b = nullptr;     // LayerNorm over X's 256 columns first (eps 1e-5)
+  const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;
+  int* range_flag = nullptr;
+  int ablate = 0;                      // diagnostic (ramp_bench_gemm only)
+};
+int launch_tkl(const TklArgs& a, hipStream_t s);
+int init_tkl_attributes();
+
 // ---- row-wise ops (rowops.hip) --------------------------------------------------------------
 // GroupNorm over (L, C/8) per (row, group) [+ Mish] [+ per-channel time bias] [+ residual]
 struct GnArgs {

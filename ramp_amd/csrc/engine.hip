@@ -188,6 +188,9 @@ struct ramp_ctx {
   int three_blocks = 1;              // launch plan: third resident block for the bias-only linears
   int ffx_min_rows = 65536;          // fp16x3 evaluations: feed-forward pairs with at least this many tokens run the token-owning fused
                                      // kernels of ffx.hip, forward and backward (RAMP_FFX: 0 never, n that threshold)
+  int tkl_min_rows = 0;              // fp16x3 evaluations: K = 256 transformer linears (LN1 -> QKV, out-proj, d(o)) with at least this many
+                                     // tokens run the token-owning kernel of tkl.hip (RAMP_TKL: 0 never, n that threshold).  Off by
+                                     // default: measured slower than the tile kernels it replaces
   int share_prefix = 1;              // sampling jobs: rows of one trajectory share the network prefix (RAMP_SHARE_PREFIX=0: off)
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
@@ -414,6 +417,27 @@ struct Run {
     c->launches++;
     return rc;
   }
+  // a K = 256 linear on the token-owning kernel (tkl.hip), optionally with LayerNorm folded into its operand; consumes the
+  // call site of the tile-kernel launch it replaces (same operand, same maxima)
+  bool use_tkl(const GemmArgs& a) const {
+    return c->tkl_min_rows > 0 && a.M >= c->tkl_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe && a.K == 256 && a.lda == 256 &&
+           a.taps == 1 && a.N % 32 == 0 && a.N <= 768 && !a.A2 && !a.Amul && !a.resid2 && !a.C2 && a.epi == EPI_LINEAR;
+  }
+  int tkl(const GemmArgs& a, const float* ln_g, const float* ln_b) {
+    prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K, {a.M, a.N, a.K, ln_g ? -1 : 1});
+    GemmArgs b = a;
+    const int kind = prep(b);
+    if (kind < 0) return kind;
+    RAMP_REQUIRE(kind == 2, "tkl: weight without fp16 fragment planes");
+    TklArgs t; t.M = a.M; t.N = a.N; t.X = a.A; t.Y = a.C; t.ldy = a.ldc; t.W = b.Wx; t.bias = a.bias; t.resid = a.resid; t.ldr = a.ldr;
+    t.rowbias = a.rowbias; t.rowvar = a.rowvar; t.row0 = a.row0; t.rb_stride = a.rb_stride; t.L = a.L; t.n_var = a.rowbias ? c->n_variants : 0;
+    t.ln_g = ln_g; t.ln_b = ln_b; t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.wsi = b.w_scale_inv; t.site = b.site_id;
+    t.range_flag = b.range_flag;
+    int rc = launch_tkl(t, s);
+    prof_post(c, s);
+    c->launches++;
+    return rc;
+  }
   // FF1 -> GEGLU -> FF2 of one transformer block (layers_attention_mini.py:38-45, 147): one fused launch in the fp16x3
   // evaluations (the 1024-wide hidden stays in LDS), two launches otherwise.  Either way the two call sites are
   // numbered in the same order, so calibration and fused evaluations read each other's maxima.
@@ -538,14 +562,22 @@ int st_forward(Run& r, ST& m, const float* x, int share = 1) {
     STBlock& k = m.blk[b];
     const bool pre = share > 1 && b == 0;
     const int Rb = pre ? Rp : R, Mb = Rb * m.L;
-    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(zin, k.ln1_g, k.ln1_b, c->t_ln, Mb, r.s));
-    CK(r.gemm(lin(c->t_ln, D, k.wqkv_f, nullptr, k.a_qkv, 768, Mb, 768, D)));
+    {
+      GemmArgs q = lin(c->t_ln, D, k.wqkv_f, nullptr, k.a_qkv, 768, Mb, 768, D);
+      if (r.use_tkl(q)) {      // LayerNorm-1 on the operand registers of the token-owning QKV kernel: no ln_fwd, no t_ln round trip
+        q.A = zin;
+        CK(r.tkl(q, k.ln1_g, k.ln1_b));
+      } else {
+        LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_fwd(zin, k.ln1_g, k.ln1_b, c->t_ln, Mb, r.s));
+        CK(r.gemm(q));
+      }
+    }
     LAUNCH(c, r.s, CAT_ATTN, 16.0 * Rb * m.L * m.L * 64, launch_attn_fwd(k.a_qkv, c->t_o, Rb, m.L, r.s));
     GemmArgs a = lin(c->t_o, D, k.wo_f, k.bo, pre ? c->t_ln : k.a_z1, D, Mb, D, D);
     a.resid = zin; a.ldr = D; a.L = m.L;
     const float* rowbias = c->cross_bias + (size_t)(m.blk0 + b) * D; const int rb_stride = c->n_blocks_total * D;
     if (!pre) { a.rowbias = rowbias; a.rb_stride = rb_stride; a.rowvar = c->row_variant; a.row0 = r.row0; }
-    CK(r.gemm(a));
+    if (r.use_tkl(a) && (!a.rowbias || c->n_variants <= 4)) CK(r.tkl(a, nullptr, nullptr)); else CK(r.gemm(a));
     if (pre) LAUNCH(c, r.s, CAT_ROW, 0, launch_expand_rows(c->t_ln, k.a_z1, R, share, m.L, D, rowbias, rb_stride, c->row_variant, r.row0, r.s));
     if (r.use_ffx(k, M)) {      // LN3 -> FF1 -> GEGLU -> FF2 -> + z1 in one launch, nothing but the stash and z2 written
       CK(r.ffx(k, false, k.a_z1, k.a_z1, k.a_z2, M));
@@ -607,7 +639,10 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx, int s
       LAUNCH(c, r.s, CAT_ROW, 0, launch_combine_rows(dz1, dz, Rp, share, m.L, D, comb, r.s));
       std::swap(dz, dz1);
     }
-    CK(r.gemm(lin(dz1, D, k.wo_b, nullptr, c->t_o, D, Mb, D, D)));                      // d(o)
+    {
+      GemmArgs o = lin(dz1, D, k.wo_b, nullptr, c->t_o, D, Mb, D, D);                   // d(o)
+      if (r.use_tkl(o)) CK(r.tkl(o, nullptr, nullptr)); else CK(r.gemm(o));
+    }
     LAUNCH(c, r.s, CAT_ATTN, 32.0 * Rb * m.L * m.L * 64, launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, Rb, m.L, r.s));
     CK(r.gemm(lin(c->t_dqkv, 768, k.wqkv_b, nullptr, c->t_dln, D, Mb, D, 768)));        // d(ln1)
     LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, zin, k.ln1_g, dz1, dz, Mb, r.s));           // dz (block input)
@@ -944,6 +979,8 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
     if (fe) c->ff_fused = atoi(fe);
     const char* xe = getenv("RAMP_FFX");
     if (xe) c->ffx_min_rows = atoi(xe);
+    const char* ke = getenv("RAMP_TKL");
+    if (ke) c->tkl_min_rows = atoi(ke);
     const char* se = getenv("RAMP_SHARE_PREFIX");
     if (se) c->share_prefix = atoi(se) != 0;
     const char* te = getenv("RAMP_X6_THREE");
@@ -956,16 +993,16 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
 
 int ramp_get_launch_plan(ramp_ctx* c, ramp_launch_plan* out) {
   RAMP_REQUIRE(c && out, "null argument");
-  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, {0, 0, 0}};
+  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, c->tkl_min_rows, {0, 0}};
   return 0;
 }
 int ramp_set_launch_plan(ramp_ctx* c, const ramp_launch_plan* p) {
   RAMP_REQUIRE(c && p, "null argument");
-  RAMP_REQUIRE(p->ff_fused_rows >= 0 && p->ffx_rows >= 0, "row thresholds must be >= 0");
+  RAMP_REQUIRE(p->ff_fused_rows >= 0 && p->ffx_rows >= 0 && p->tkl_rows >= 0, "row thresholds must be >= 0");
   RAMP_REQUIRE(!c->finalized || (p->x6_pipe != 0) == (c->x6_pipe != 0), "x6_pipe is fixed once the weights are packed (ramp_finalize_weights)");
   const bool changed = p->ff_fused_rows != c->ff_fused || p->ffx_rows != c->ffx_min_rows || (p->share_prefix != 0) != (c->share_prefix != 0) ||
-                       (p->three_blocks != 0) != (c->three_blocks != 0);
-  c->ff_fused = p->ff_fused_rows; c->ffx_min_rows = p->ffx_rows; c->share_prefix = p->share_prefix != 0;
+                       (p->three_blocks != 0) != (c->three_blocks != 0) || p->tkl_rows != c->tkl_min_rows;
+  c->ff_fused = p->ff_fused_rows; c->ffx_min_rows = p->ffx_rows; c->tkl_min_rows = p->tkl_rows; c->share_prefix = p->share_prefix != 0;
   c->three_blocks = p->three_blocks != 0; c->x6_pipe = p->x6_pipe != 0;
   if (changed && c->finalized) {   // other kernels from here on: captured graphs and kept calibrations belong to the old plan
     c->graph_key.clear(); c->r_key.clear();
@@ -1171,6 +1208,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
   CK(init_attention_attributes());
   CK(init_ffx_attributes());
+  CK(init_tkl_attributes());
   c->finalized = true;
   return 0;
 }
@@ -1921,6 +1959,40 @@ int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* 
   return rc;
 }
 
+int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
+                const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
+                float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  RAMP_REQUIRE(X && W && Y && M > 0 && N >= 32 && N % 32 == 0 && N <= 768, "bad arguments");
+  hipStream_t s = as_stream(stream);
+  DevArena ar;
+  std::vector<float> hw((size_t)N * 256);
+  RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
+  float mx = 0.f;
+  for (float v : hw) mx = std::max(mx, std::fabs(v));
+  float sc = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
+  unsigned short* planes = reinterpret_cast<unsigned short*>(ar.alloc((size_t)N * 256 + 4));
+  float* slots = ar.alloc(4);
+  RAMP_REQUIRE(planes && slots, "hipMalloc failed");
+  CK(launch_pack_h3(W, planes, N, 256, sc, s));
+  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
+  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
+  TklArgs a; a.M = M; a.N = N; a.X = X; a.Y = Y; a.ldy = N; a.W = planes; a.bias = bias; a.resid = resid; a.ldr = N;
+  a.rowbias = rowbias; a.rowvar = rowvar; a.row0 = 0; a.rb_stride = N; a.L = L > 0 ? L : 1; a.n_var = n_var;
+  a.ln_g = ln_g; a.ln_b = ln_b; a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
+  a.range_flag = reinterpret_cast<int*>(slots + 2);
+  int rc = launch_tkl(a, s);
+  hipError_t e = hipStreamSynchronize(s);
+  float back[4] = {0, 0, 0, 0};
+  if (rc == 0 && e == hipSuccess) {
+    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
+    if (absmax_out_host) *absmax_out_host = back[1];
+    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
+  }
+  RAMP_HIP_CHECK(e);
+  return rc;
+}
+
 // micro-benchmark of one GEMM shape on a named kernel: packs once, `warmup` + `iters` back-to-back launches on `stream`,
 // HIP events around the timed ones.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue (N = 2F, writes the F-wide
 // product too), 8 A-multiplier operand (K = 2 * period).  Operands are allocated and filled here (uniform [-1, 1)).
@@ -1976,7 +2048,7 @@ thread_local StressHook* g_stress = nullptr;
 
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 7, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 8, "bad arguments");
   if (mode == 6 || mode == 7) {                        // ffx.hip: fused feed-forward with token-owning waves, forward / backward
     hipStream_t s6 = as_stream(stream);
     DevArena ar6;
@@ -2022,6 +2094,38 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
               sm[0] / slabs, sm[1] / slabs, sm[2] / slabs, sm[3] / slabs, nw);
     }
     return rc6;
+  }
+  if (mode == 8) {                                     // tkl.hip: token-owning linear, K = 256; flags: 1 LayerNorm first, 2 bias + residual, >> 8 ablation
+    hipStream_t s8 = as_stream(stream);
+    DevArena ar8;
+    RAMP_REQUIRE(K == 256 && N % 32 == 0 && N <= 768, "mode 8: K = 256, N a multiple of 32 up to 768");
+    float* X8 = ar8.alloc((size_t)M * 256); float* Y8 = ar8.alloc((size_t)M * N); float* R8 = ar8.alloc((size_t)M * N);
+    float* W8 = ar8.alloc((size_t)N * 256); float* b8 = ar8.alloc(N); float* lg = ar8.alloc(256); float* lb = ar8.alloc(256); float* sl = ar8.alloc(4);
+    unsigned short* p8 = reinterpret_cast<unsigned short*>(ar8.alloc((size_t)N * 256 + 4));
+    RAMP_REQUIRE(X8 && Y8 && R8 && W8 && b8 && lg && lb && sl && p8, "hipMalloc failed");
+    auto fill8 = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s8, p, (long)n, seed, sc); };
+    fill8(X8, (size_t)M * 256, 1u, 1.f); fill8(R8, (size_t)M * N, 4u, 1.f); fill8(W8, (size_t)N * 256, 2u, 1.f / 16.f); fill8(b8, N, 5u, 1.f);
+    fill8(lg, 256, 8u, 1.f); fill8(lb, 256, 9u, 1.f);
+    CK(launch_pack_h3(W8, p8, N, 256, 16384.f, s8));
+    const float one[4] = {(flags & 1) ? 4.f : 1.f, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, s8));
+    TklArgs a; a.M = M; a.N = N; a.X = X8; a.Y = Y8; a.ldy = N; a.W = p8; a.amax_in = sl; a.amax_out = sl + 1; a.wsi = 1.f / 16384.f;
+    a.range_flag = reinterpret_cast<int*>(sl + 2); a.ablate = (flags >> 8) & 255;
+    if (flags & 1) { a.ln_g = lg; a.ln_b = lb; }
+    if (flags & 2) { a.bias = b8; a.resid = R8; a.ldr = N; }
+    for (int i = 0; i < warmup; ++i) CK(launch_tkl(a, s8));
+    hipEvent_t e0, e1;
+    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+    RAMP_HIP_CHECK(hipEventRecord(e0, s8));
+    int rc8 = 0;
+    for (int i = 0; i < iters && rc8 == 0; ++i) { rc8 = launch_tkl(a, s8); if (rc8 == 0) STRESS(Y8, (size_t)M * N, s8); }
+    RAMP_HIP_CHECK(hipEventRecord(e1, s8));
+    RAMP_HIP_CHECK(hipEventSynchronize(e1));
+    float ms8 = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&ms8, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = ms8 * 1e3f / iters;
+    return rc8;
   }
   if (mode == 5) {                                     // the fused FF1 -> GEGLU -> FF2 kernel (N, K ignored: 256 -> 2 x 1024 -> 256)
     hipStream_t s5 = as_stream(stream);

@@ -48,7 +48,7 @@ class TemporalUnetInference(nn.Module):
         self.max_rows = int(max_rows)
         self.debug_taps = bool(debug_taps)
         self.gemm_mode = {"default": 0, "fp32": 1, "bf16x6": 2, "fp16x3": 3}[gemm_mode]
-        # performance knobs of the HIP engine (ramp_launch_plan: ff_fused_rows, ffx_rows, share_prefix, three_blocks,
+        # performance knobs of the HIP engine (ramp_launch_plan: ff_fused_rows, ffx_rows, tkl_rows, share_prefix, three_blocks,
         # x6_pipe); None keeps the library defaults.  Every plan meets the same parity bar.
         self.launch_plan = dict(launch_plan or {})
         self._unet_keys = [k for k in unet_param_shapes(self.spec, with_scene_encoder=False)]
@@ -150,7 +150,7 @@ class TemporalUnetInference(nn.Module):
         plan = _lib.RampLaunchPlan()
         _lib.check(lib.ramp_get_launch_plan(h, C.byref(plan)), "ramp_get_launch_plan")
         for k, v in kw.items():
-            if k not in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe"):
+            if k not in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe", "tkl_rows"):
                 raise KeyError(f"unknown launch-plan field {k!r}")
             setattr(plan, k, int(v))
         _lib.check(lib.ramp_set_launch_plan(h, C.byref(plan)), "ramp_set_launch_plan")
@@ -166,7 +166,7 @@ class TemporalUnetInference(nn.Module):
     def get_launch_plan(self) -> dict:
         plan = _lib.RampLaunchPlan()
         _lib.check(_lib.load().ramp_get_launch_plan(self.ctx(), C.byref(plan)), "ramp_get_launch_plan")
-        return {k: getattr(plan, k) for k in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe")}
+        return {k: getattr(plan, k) for k in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe", "tkl_rows")}
 
     def prepare_time_table(self, T: int):
         if T > self._T_table:

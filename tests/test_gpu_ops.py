@@ -435,6 +435,55 @@ def test_ffx_fused_feed_forward_against_float64_autograd(M):
     assert flag.value == 1, flag.value
 
 
+@pytest.mark.parametrize("M,N,ln,epi", [(128, 768, True, 0), (293, 256, False, 3), (4173, 768, True, 0), (4173, 256, False, 0),
+                                         (4173, 256, False, 1), (70000, 256, False, 3), (1000, 32, False, 1), (1000, 96, False, 1)])
+def test_tkl_token_owning_linear_against_float64(M, N, ln, epi):
+    """The token-owning K = 256 linear (tkl.hip; an opt-in launch plan, ramp_launch_plan.tkl_rows) through the C ABI
+    (ramp_op_tkl): LayerNorm(256) folded into the operand (LN1 -> QKV, layers_attention_mini.py:132), bias + residual +
+    per-row-variant constant (the attention output projection with the block's cross-attention constant, :133-135), odd
+    numbers of 32-feature blocks and M not a multiple of the 128-token tile, against float64; the recorded operand maximum is
+    the true one and scaling from it leaves the result unchanged to rounding; a stale maximum raises the range flag."""
+    import ctypes as C
+    from ramp_amd import _lib
+    gen = torch.Generator(device="cpu").manual_seed(M + N)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).cuda()
+    L, n_var = 6, 3
+    X, W = r(M, 256, sc=1.3) + 0.2, r(N, 256, sc=1 / 16)
+    bias = r(N, sc=0.3) if epi else None
+    resid = r(M, N) if epi & 1 else None
+    rowbias = r(n_var, N, sc=0.5) if epi & 2 else None
+    rowvar = (torch.arange((M + L - 1) // L, device="cuda") % n_var).to(torch.int32) if epi & 2 else None
+    g, b = (1 + r(256, sc=0.1), r(256, sc=0.1)) if ln else (None, None)
+    xd = X.double()
+    if ln:
+        xd = torch.nn.functional.layer_norm(xd, (256,), g.double(), b.double(), 1e-5)
+    ref = xd @ W.double().T
+    if bias is not None:
+        ref = ref + bias.double()
+    if resid is not None:
+        ref = ref + resid.double()
+    if rowbias is not None:
+        ref = ref + rowbias.double()[rowvar.long()[torch.arange(M, device="cuda") // L]]
+    xmax = xd.abs().max().item()
+    Y = torch.empty(M, N, device="cuda")
+    out, flag = C.c_float(0), C.c_int32(0)
+    p = lambda t_: _lib.ptr(t_) if t_ is not None else None
+
+    def go(prev):
+        Y.fill_(float("nan"))
+        _lib.check(_lib.load().ramp_op_tkl(p(X), p(W), p(bias), p(resid), p(rowbias), p(rowvar), n_var if epi & 2 else 0, L, p(g), p(b),
+                                           M, N, prev, p(Y), C.byref(out), C.byref(flag), None), "ramp_op_tkl")
+        return rel(Y.double().cpu().numpy(), ref.cpu().numpy())
+
+    e = go(0.0)
+    assert e < 3e-6 and flag.value == 0, (e, flag.value)
+    assert abs(out.value - xmax) <= 1e-6 * xmax, (out.value, xmax)
+    e2 = go(out.value)
+    assert e2 < 3e-6 and flag.value == 0, (e2, flag.value)
+    go(xmax / 4096.0)                                         # operand 2^12 larger than the scale assumes
+    assert flag.value == 1, flag.value
+
+
 STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, compare with the exact-fp32 kernel?
     ("fp16x3 bias-only 768x256 (QKV; third resident block)", 393216, 768, 256, 1, 1, 3, 1, True),
     ("fp16x3 residual 256x256 (out-proj, 64x256 tile)", 393216, 256, 256, 1, 1, 3, 3, True),
