@@ -16,7 +16,7 @@ def t(M, N, flags, iters=10):
 
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 393216
-names = {0: "full", 1: "no weight DMA", 2: "no stores", 3: "no DMA, no stores", 4: "one block per CU", 8: "no barrier"}
+names = {0: "full", 1: "no weight DMA", 2: "no stores", 3: "no DMA, no stores", 8: "no barrier"}
 for N, fl, what in ((768, 1, "LN -> QKV"), (256, 2, "out-proj"), (256, 0, "d(o)")):
     for ab, nm in names.items():
         us = min(t(M, N, fl | (ab << 8)) for _ in range(2))
