@@ -201,7 +201,7 @@ struct ramp_ctx {
   std::map<std::string, std::pair<float*, size_t>> dbg;
   int64_t launches = 0;
   // per-launch HIP-event profiler (eager mode only): category, algorithmic flops, start/stop events
-  bool prof_on = false, prof_dump = false;
+  bool prof_on = false, prof_dump = false; int ffx_ablate = 0;
   std::vector<hipEvent_t> prof_ev; size_t prof_used = 0;
   std::vector<int> prof_cat; std::vector<double> prof_flops; std::vector<std::array<int, 4>> prof_shape;
 };
@@ -411,6 +411,7 @@ struct Run {
     f.amax_in1 = c->obs_in + c->site; f.amax_out1 = c->obs_out + c->site; f.site1 = c->site;
     f.amax_in2 = c->obs_in + c->site + 1; f.amax_out2 = c->obs_out + c->site + 1; f.site2 = c->site + 1;
     f.wsi1 = bwd ? k.ffx_wsi_w2 : k.ffx_wsi_w1; f.wsi2 = bwd ? k.ffx_wsi_w1 : k.ffx_wsi_w2;
+    f.ablate = c->ffx_ablate;
     c->site += 2;
     int rc = launch_ffx(f, bwd, s);
     prof_post(c, s);
@@ -986,6 +987,8 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
     const char* te = getenv("RAMP_X6_THREE");
     if (te) c->three_blocks = te[0] != '0';
     c->prof_dump = getenv("RAMP_PROFILE_DUMP") != nullptr;
+    const char* ae = getenv("RAMP_FFX_ABLATE");              // diagnostic A/B of the fused feed-forward inside a whole job
+    if (ae) c->ffx_ablate = atoi(ae);
   }
   *out = c;
   return 0;

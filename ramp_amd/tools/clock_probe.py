@@ -26,7 +26,7 @@ def sampler():
         samples.append((time.time(), sc[:1], pw[:1]))
 
 
-def run(label, M, N, K, mode, flags, secs=4.0):
+def run(label, M, N, K, mode, flags, secs=4.0, flops=None):
     us = C.c_float()
     t0 = time.time(); n0 = len(samples); last = 0.0
     while time.time() - t0 < secs:
@@ -34,7 +34,8 @@ def run(label, M, N, K, mode, flags, secs=4.0):
         last = us.value
     got = samples[n0:]
     sc = [int(s[1][0]) for s in got[len(got) // 2:] if s[1]]; pw = [float(s[2][0]) for s in got[len(got) // 2:] if s[2]]
-    print(f"{label}: {last:.1f} us ({2.0 * M * N * K / last / 1e6:.0f} TF)  sclk {sum(sc) / max(1, len(sc)):.0f} MHz  "
+    fl = flops if flops is not None else 2.0 * M * N * K
+    print(f"{label}: {last:.1f} us ({fl / last / 1e6:.0f} TF)  sclk {sum(sc) / max(1, len(sc)):.0f} MHz  "
           f"power {sum(pw) / max(1, len(pw)):.0f} W  ({len(sc)} samples)", flush=True)
 
 
@@ -55,4 +56,11 @@ run("full 2048x2048", 65536, 2048, 2048, 3, 1)
 run("mfma+lds-reads only 2048x2048", 65536, 2048, 2048, 3, 1 | (15 << 8))
 run("bf16x6 2048x2048", 65536, 2048, 2048, 1, 1)
 run("fp32 2048x2048", 65536, 2048, 2048, 0, 1)
+ff = 2.0 * M * (2048 * 256 + 256 * 1024)
+run("token-owning fused feed-forward, forward (ffx)", M, 2048, 256, 6, 0, flops=ff)
+run("token-owning fused feed-forward, backward (ffx)", M, 2048, 256, 7, 0, flops=ff)
+run("ffx forward, no stash traffic", M, 2048, 256, 6, 2 << 8, flops=ff)
+run("ffx forward, no weight DMA", M, 2048, 256, 6, 1 << 8, flops=ff)
+run("token-owning LN -> QKV (tkl)", M, 768, 256, 8, 1)
+run("tkl LN -> QKV, no DMA, no stores", M, 768, 256, 8, 1 | (3 << 8))
 stop = True
