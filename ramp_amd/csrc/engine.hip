@@ -188,9 +188,8 @@ struct ramp_ctx {
   int three_blocks = 1;              // launch plan: third resident block for the bias-only linears
   int ffx_min_rows = 65536;          // fp16x3 evaluations: feed-forward pairs with at least this many tokens run the token-owning fused
                                      // kernels of ffx.hip, forward and backward (RAMP_FFX: 0 never, n that threshold)
-  int tkl_min_rows = 0;              // fp16x3 evaluations: K = 256 transformer linears (LN1 -> QKV, out-proj, d(o)) with at least this many
-                                     // tokens run the token-owning kernel of tkl.hip (RAMP_TKL: 0 never, n that threshold).  Off by
-                                     // default: measured slower than the tile kernels it replaces
+  int tkl_min_rows = 65536;          // fp16x3 evaluations: K = 256 transformer linears (LN1 -> QKV, out-proj, d(o)) with at least this many
+                                     // tokens run the token-owning kernel of tkl.hip (RAMP_TKL: 0 never, n that threshold)
   int share_prefix = 1;              // sampling jobs: rows of one trajectory share the network prefix (RAMP_SHARE_PREFIX=0: off)
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration

@@ -41,7 +41,8 @@ constexpr int FX_SLAB = 32 * 1024;                      // bytes per ring slot: 
 constexpr int FX_R = 4;                                 // ring slots
 constexpr int FX_B1 = FX_R * FX_SLAB;                   // forward: the packed b1 (2048 floats) behind the ring
 constexpr int FX_LN = FX_B1 + 2048 * 4;                   // LayerNorm-3 gamma (256) and beta (256) behind b1
-constexpr size_t FX_LDS = (size_t)FX_R * FX_SLAB + 2048 * 4 + 512 * 4;
+constexpr int FX_B2 = FX_LN + 512 * 4;                     // forward: b2 (256)
+constexpr size_t FX_LDS = (size_t)FX_R * FX_SLAB + 2048 * 4 + 512 * 4 + 256 * 4;
 constexpr int FX_SLABS = 96;                            // slabs per 128-token tile (32 units x 3)
 static_assert(FX_LDS <= 160 * 1024, "LDS budget");
 
@@ -203,6 +204,7 @@ void ffx_kernel(FfxArgs f, int n_mt) {
   if (!BWD) {
     float* b1s = reinterpret_cast<float*>(smem + FX_B1);
     for (int i = tid; i < 512; i += 256) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(f.b1)[i];
+    reinterpret_cast<float*>(smem + FX_B2)[tid] = f.b2[tid];
   }
   {   // gamma | beta in LDS for the backward epilogue.  (The forward prologue reads them from global memory: 64 L1-resident
       // loads per tile and lane that hipcc hoists above the row statistics; the same reads from LDS measured 2 % slower END TO
@@ -259,7 +261,8 @@ void ffx_kernel(FfxArgs f, int n_mt) {
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        amax1 = amax4(xv[2 * s], amax1); amax1 = amax4(xv[2 * s + 1], amax1);
+        amax_pin(amax1, xv[2 * s][0], xv[2 * s][1]); amax_pin(amax1, xv[2 * s][2], xv[2 * s][3]);      // (pinned: see tokmma.h)
+        amax_pin(amax1, xv[2 * s + 1][0], xv[2 * s + 1][1]); amax_pin(amax1, xv[2 * s + 1][2], xv[2 * s + 1][3]);
         split8(xv[2 * s] * s_1, xv[2 * s + 1] * s_1, XB[s][0], XB[s][1]);
       }
     }
@@ -329,9 +332,10 @@ void ffx_kernel(FfxArgs f, int n_mt) {
             s1q[e] = qg[q & 1][e] * qt[q & 1][e];                            // gelu(g)
             s2q[e] = qa[q & 1][e] * fmaf(qg[q & 1][e], qp[q & 1][e], qt[q & 1][e]);   // a * gelu'(g)
             const float hv = qa[q & 1][e] * s1q[e];                          // a * gelu(g)
-            amax2 = fmaxf(fabsf(hv), amax2);
-            hq[q][e] = hv * s_2;
+            hq[q][e] = hv;
           }
+          amax_pin(amax2, hq[q][2 * hf], hq[q][2 * hf + 1]);
+          hq[q][2 * hf] *= s_2; hq[q][2 * hf + 1] *= s_2;
           if (hf == 1 && !(ABL & 2)) {
             float* p = stash_w + (long)u * 8192;
             *reinterpret_cast<f32x4*>(p + (2 * q) * 256) = s1q;
@@ -344,7 +348,7 @@ void ffx_kernel(FfxArgs f, int n_mt) {
       if constexpr (BWD) {
         const f32x4 d = quad(acc1[par][0], q) * os1;
         const f32x4 da = d * st1[q], dg = d * st2[q];
-        amax2 = amax4(da, amax2); amax2 = amax4(dg, amax2);
+        amax_pin(amax2, da[0], da[1]); amax_pin(amax2, da[2], da[3]); amax_pin(amax2, dg[0], dg[1]); amax_pin(amax2, dg[2], dg[3]);
         hq[q] = da * s_2; hq[4 + q] = dg * s_2;
       }
     };
@@ -427,30 +431,41 @@ void ffx_kernel(FfxArgs f, int n_mt) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
     // ---- epilogue: lane (r, h) holds features n = 32 nb + 8 q + 4 h + i of token r --------------------------------------
+    // (the row addresses are recomputed from the tile index here -- opaque to hipcc, which otherwise carries them across the
+    // 96 slabs in spilled registers and reloads them one vmcnt(0) at a time)
+    int mt_e = mt;
+    asm volatile("" : "+s"(mt_e));
+    long tok_e = (long)mt_e * 128 + wave * 32 + r;
+    tok_e = tok_e < f.M ? tok_e : f.M - 1;
     if (!BWD) {
-      const float* zrow = f.Z1 + tokc * 256 + 4 * h;
-      float* orow = f.Y + tokc * 256 + 4 * h;
+      const float* zrow = f.Z1 + tok_e * 256 + 4 * h;
+      float* orow = f.Y + tok_e * 256 + 4 * h;
+      const float* b2s = reinterpret_cast<const float*>(smem + FX_B2) + 4 * h;
+      // all 32 residual quads first, every store unconditional (tokens past M recompute and rewrite row M - 1 with the same
+      // bits): with `if (tok_ok)` around each store hipcc put every quad's loads in their own basic block behind a vmcnt(0)
+      // -- eight serial memory round trips per tile here, thirty-two in the backward epilogue
+      f32x4 rz[32];
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        f32x4 rz[4];
+      for (int i = 0; i < 32; ++i) rz[i] = *reinterpret_cast<const f32x4*>(zrow + 8 * i);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rz[q] = *reinterpret_cast<const f32x4*>(zrow + 32 * nb + 8 * q);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b2 = *reinterpret_cast<const f32x4*>(f.b2 + 32 * nb + 8 * q + 4 * h);
-          const f32x4 v = quad(acc2[nb], q) * os2 + b2 + rz[q];
-          if (tok_ok) *reinterpret_cast<f32x4*>(orow + 32 * nb + 8 * q) = v;
-        }
+      for (int i = 0; i < 32; ++i) {                          // i = 4 nb + q
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(b2s + 8 * i);      // (LDS: a global load here would be waited for with vmcnt(0), one round trip per quad)
+        const f32x4 v = quad(acc2[i >> 2], i & 3) * os2 + b2 + rz[i];
+        *reinterpret_cast<f32x4*>(orow + 8 * i) = v;
       }
     } else {
       // dz1 = dz + LNbwd(d(ln3); z1, gamma)   (rowops.hip, ln_bwd_kernel)
-      const float* zrow = f.Z1 + tokc * 256 + 4 * h;
-      const float* drow = f.X + tokc * 256 + 4 * h;
-      float* orow = f.Y + tokc * 256 + 4 * h;
-      f32x4 xz[32];
+      const float* zrow = f.Z1 + tok_e * 256 + 4 * h;
+      const float* drow = f.X + tok_e * 256 + 4 * h;
+      float* orow = f.Y + tok_e * 256 + 4 * h;
+      f32x4 xz[32], add[32];
       float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) { xz[i] = *reinterpret_cast<const f32x4*>(zrow + 8 * i); sum += (xz[i][0] + xz[i][1]) + (xz[i][2] + xz[i][3]); }
+      for (int i = 0; i < 32; ++i) xz[i] = *reinterpret_cast<const f32x4*>(zrow + 8 * i);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) add[i] = *reinterpret_cast<const f32x4*>(drow + 8 * i);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) sum += (xz[i][0] + xz[i][1]) + (xz[i][2] + xz[i][3]);
       sum += __shfl_xor(sum, 32);
       const float mean = sum * (1.f / 256.f);
       float ss = 0.f;
@@ -476,11 +491,10 @@ void ffx_kernel(FfxArgs f, int n_mt) {
       const float m1 = t1 * (1.f / 256.f), m2 = t2 * (1.f / 256.f);
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        const f32x4 add = *reinterpret_cast<const f32x4*>(drow + 8 * i);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (acc2[i >> 2][4 * (i & 3) + e] - m1 - xz[i][e] * m2) * rstd + add[e];
-        if (tok_ok) *reinterpret_cast<f32x4*>(orow + 8 * i) = o;
+        for (int e = 0; e < 4; ++e) o[e] = (acc2[i >> 2][4 * (i & 3) + e] - m1 - xz[i][e] * m2) * rstd + add[i][e];
+        *reinterpret_cast<f32x4*>(orow + 8 * i) = o;            // (unconditional: see the forward epilogue)
       }
     }
     // Retire all but the youngest 24 vector-memory operations before the next tile queues its row loads behind this tile's 32

@@ -186,7 +186,8 @@ void tkl_kernel(TklArgs a, int n_mt) {
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        amax = amax4(xn[2 * s], amax); amax = amax4(xn[2 * s + 1], amax);
+        amax_pin(amax, xn[2 * s][0], xn[2 * s][1]); amax_pin(amax, xn[2 * s][2], xn[2 * s][3]);      // (pinned: see tokmma.h)
+        amax_pin(amax, xn[2 * s + 1][0], xn[2 * s + 1][1]); amax_pin(amax, xn[2 * s + 1][2], xn[2 * s + 1][3]);
         split8(xn[2 * s] * s_in, xn[2 * s + 1] * s_in, XB[s][0], XB[s][1]);
       }
     }

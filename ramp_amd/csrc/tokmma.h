@@ -70,6 +70,13 @@ __device__ __forceinline__ float amax4(const f32x4 v, float m) {
   m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), m);
   return fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), m);
 }
+// m = max(|a|, |b|, m), pinned where it is written.  A plain fmaxf chain whose result is only read at the end of the kernel
+// is sunk by hipcc past the 96-slab loop of the fused feed-forward: the 128 operand values of the tile prologue are SPILLED
+// to scratch, reloaded after the loop and reduced there, one scratch reload + vmcnt(0) at a time -- 30 serial memory round
+// trips per tile (every LDS-DMA piece in flight included in each wait).
+__device__ __forceinline__ void amax_pin(float& m, float a, float b) {
+  asm volatile("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ f32x16 mfma16(const u32x4 a, const u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }
