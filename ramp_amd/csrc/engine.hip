@@ -186,7 +186,7 @@ struct ramp_ctx {
   int ff_fused = 150000;             // fp16x3 evaluations: FF1 -> GEGLU -> FF2 as one launch for M >= this many rows
                                      // (RAMP_FF_FUSED: 0 never, 1 always, n > 1 that threshold)
   int three_blocks = 1;              // launch plan: third resident block for the bias-only linears
-  int ffx_min_rows = 65536;          // fp16x3 evaluations: feed-forward pairs with at least this many tokens run the token-owning fused
+  int ffx_min_rows = 32768;          // fp16x3 evaluations: feed-forward pairs with at least this many tokens run the token-owning fused
                                      // kernels of ffx.hip, forward and backward (RAMP_FFX: 0 never, n that threshold)
   int tkl_min_rows = 65536;          // fp16x3 evaluations: K = 256 transformer linears (LN1 -> QKV, out-proj, d(o)) with at least this many
                                      // tokens run the token-owning kernel of tkl.hip (RAMP_TKL: 0 never, n that threshold)
