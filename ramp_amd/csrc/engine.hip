@@ -2069,8 +2069,8 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     FfxArgs f; f.M = M; f.X = z1; f.Z1 = z1; f.Y = out; f.stash = stash; f.ln_g = lg; f.ln_b = lb; f.Wstream = pk.stream_f; f.b1 = pk.b1_pk; f.b2 = b2;
     f.amax_in1 = sl; f.amax_out1 = sl + 4; f.wsi1 = pk.wsi_w1; f.amax_in2 = sl + 1; f.amax_out2 = sl + 5; f.wsi2 = pk.wsi_w2; f.site2 = 1;
     f.range_flag = reinterpret_cast<int*>(sl + 8); f.ablate = (flags >> 8) & 255;
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ar6.alloc(256 * 4 * 4 * 2));
-    if (f.ablate & 64) { RAMP_REQUIRE(stamps, "hipMalloc failed"); RAMP_HIP_CHECK(hipMemsetAsync(stamps, 0, 256 * 4 * 4 * 8, s6)); f.stamps = stamps; }
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ar6.alloc(256 * 4 * 6 * 2));
+    if (f.ablate & 64) { RAMP_REQUIRE(stamps, "hipMalloc failed"); RAMP_HIP_CHECK(hipMemsetAsync(stamps, 0, 256 * 4 * 6 * 8, s6)); f.stamps = stamps; }
     FfxArgs g = f; g.X = dz; g.Wstream = pk.stream_b; g.amax_in1 = sl + 2; g.amax_out1 = sl + 6; g.wsi1 = pk.wsi_w2; g.amax_in2 = sl + 3; g.amax_out2 = sl + 7; g.wsi2 = pk.wsi_w1;
     CK(launch_ffx(f, false, s6));                        // the backward kernel reads this stash
     auto go6 = [&]() { return mode == 6 ? launch_ffx(f, false, s6) : launch_ffx(g, true, s6); };
@@ -2087,13 +2087,13 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_us = ms6 * 1e3f / iters;
     if (rc6 == 0 && (f.ablate & 64)) {                   // per-wave cycle sums of the LAST launch, averaged, on stderr
-      std::vector<unsigned long long> h(256 * 4 * 4);
+      std::vector<unsigned long long> h(256 * 4 * 6);
       RAMP_HIP_CHECK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
-      double sm[4] = {0, 0, 0, 0}; int nw = 0;
-      for (int w = 0; w < 1024; ++w) if (h[w * 4 + 3]) { ++nw; for (int j = 0; j < 4; ++j) sm[j] += (double)h[w * 4 + j]; }
+      double sm[6] = {0, 0, 0, 0, 0, 0}; int nw = 0;
+      for (int w = 0; w < 1024; ++w) if (h[w * 6 + 3]) { ++nw; for (int j = 0; j < 6; ++j) sm[j] += (double)h[w * 6 + j]; }
       const double slabs = std::max(1, nw) * 96.0 * (double)((mt + 255) / 256);
-      fprintf(stderr, "[ffx stamps] per slab (s_memtime ticks): vm wait %.0f, barrier %.0f, DMA issue %.0f, body %.0f (%d waves)\n",
-              sm[0] / slabs, sm[1] / slabs, sm[2] / slabs, sm[3] / slabs, nw);
+      fprintf(stderr, "[ffx stamps] per slab (s_memtime ticks): vm wait %.0f, barrier %.0f, DMA issue %.0f, body %.0f (%d waves); shader clock %.0f MHz\n",
+              sm[0] / slabs, sm[1] / slabs, sm[2] / slabs, sm[3] / slabs, nw, sm[5] > 0 ? sm[4] / sm[5] * 100.0 : 0.0);
     }
     return rc6;
   }

@@ -68,6 +68,7 @@ void ffx_kernel(FfxArgs f, int n_mt) {
   const float s_1 = scale_of(f.amax_in1), s_2 = scale_of(f.amax_in2);
   const float os1 = f.wsi1 / s_1, os2 = f.wsi2 / s_2;
   float amax1 = 0.f, amax2 = 0.f;
+  const unsigned long long t_start = (ABL & 64) ? __builtin_amdgcn_s_memtime() : 0, r_start = (ABL & 64) ? __builtin_amdgcn_s_memrealtime() : 0;
 
   // ---- weight ring: the tile's 96 slabs lie in consumption order in ONE 3 MB stream (ffx_build_stream), so a slab is one
   // pointer step: wave w copies bytes [8 w KB, 8 w KB + 8 KB) of it as 8 LDS-DMA pieces of 1 KB, one per macro-step.
@@ -111,11 +112,12 @@ void ffx_kernel(FfxArgs f, int n_mt) {
   // slab g, behind an MFMA (issued back to back at the slab top the eight pieces held the wave for ~700 cycles).  The pieces
   // are issued unconditionally: past the block's last slab they refill the free slot with bytes nobody reads.
   unsigned long long tk[4] = {0, 0, 0, 0}, tlast = 0;
-  auto slab_top = [&]() __attribute__((always_inline)) {
+  auto slab_top = [&](auto vm_c) __attribute__((always_inline)) {
+    constexpr int VM = decltype(vm_c)::value;               // 8; 16 where the eight stash loads of the backward sit between the pieces
     if (ABL & 64) {                                          // diagnostic: where a slab's cycles go (s_memtime perturbs the LDS waits a little)
       const unsigned long long t0 = __builtin_amdgcn_s_memtime();
       if (tlast) tk[3] += t0 - tlast;
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM) : "memory");
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();
       const unsigned long long t2 = __builtin_amdgcn_s_memtime();
@@ -124,7 +126,7 @@ void ffx_kernel(FfxArgs f, int n_mt) {
       tk[0] += t1 - t0; tk[1] += t2 - t1; tk[2] += tlast - t2;
       return;
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM) : "memory");
     if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
     dma_begin();
   };
@@ -150,9 +152,9 @@ void ffx_kernel(FfxArgs f, int n_mt) {
   // one slab = 8 macro-steps.  The fragment reads run TWO macro-steps ahead of the MFMAs (three buffers: the registers a
   // read overwrites were last used two steps ago, and its data has ~380 cycles to land): entering a slab, its macro 0 and 1
   // are already in F[FO % 3], F[(FO + 1) % 3]; leaving it, macro 0 and 1 of the NEXT slab are (8 = 2 mod 3: FO advances by 2).
-  auto slab = [&](auto kind_c, auto fo_c, int par, auto side) __attribute__((always_inline)) {
+  auto slab = [&](auto kind_c, auto fo_c, int par, auto side, auto vm_c) __attribute__((always_inline)) {
     constexpr int KIND = decltype(kind_c)::value, FO = decltype(fo_c)::value;
-    slab_top();
+    slab_top(vm_c);
     const int slot = g & (FX_R - 1), nslot = (g + 1) & (FX_R - 1);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -390,43 +392,44 @@ void ffx_kernel(FfxArgs f, int n_mt) {
     // ---- the 32 hidden units, software-pipelined: P2(k - 1), P1(k + 1) and E(k) share a group ---------------------------
     using KA = std::integral_constant<int, K_P1A>; using KB = std::integral_constant<int, K_P1B>;
     using KC = std::integral_constant<int, K_P2A>; using KD = std::integral_constant<int, K_P2B>;
+    using V8 = std::integral_constant<int, 8>; using V16 = std::integral_constant<int, 16>;
     // FO<x>: which fragment buffer holds the slab's macro-step 0 (every slab advances the ring by 8 = 2 mod 3)
     if constexpr (!BWD) {
-      slab(KA{}, FO<0>{}, 0, no_side); slab(KB{}, FO<2>{}, 0, no_side);
-      slab(KA{}, FO<1>{}, 1, [&](int m) __attribute__((always_inline)) { E_step(0, 0, m, 16, 0); });
-      slab(KB{}, FO<0>{}, 1, [&](int m) __attribute__((always_inline)) { E_step(0, 0, 8 + m, 16, 0); });
+      slab(KA{}, FO<0>{}, 0, no_side, V8{}); slab(KB{}, FO<2>{}, 0, no_side, V8{});
+      slab(KA{}, FO<1>{}, 1, [&](int m) __attribute__((always_inline)) { E_step(0, 0, m, 16, 0); }, V8{});
+      slab(KB{}, FO<0>{}, 1, [&](int m) __attribute__((always_inline)) { E_step(0, 0, 8 + m, 16, 0); }, V8{});
 #pragma unroll 1
       for (int kk = 1; kk <= 29; kk += 2) {
 #pragma unroll
         for (int o = 0; o < 2; ++o) {                        // k = kk + o: acc1 parity of E(k) is k & 1 = 1 - o
           const int k = kk + o, pe = 1 - o, pn = o;
-          slab(KC{}, FO<2>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, m, 24, 8); });
-          slab(KA{}, FO<1>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 8 + m, 24, 8); });
-          slab(KB{}, FO<0>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 16 + m, 24, 8); });
+          slab(KC{}, FO<2>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, m, 24, 8); }, V8{});
+          slab(KA{}, FO<1>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 8 + m, 24, 8); }, V8{});
+          slab(KB{}, FO<0>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 16 + m, 24, 8); }, V8{});
         }
       }
-      slab(KC{}, FO<2>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(31, 1, m, 9, 8); });      // P2(30) with E(31)
+      slab(KC{}, FO<2>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(31, 1, m, 9, 8); }, V8{});      // P2(30) with E(31)
       E_step(31, 1, 8, 9, 8);                                                                    // its packs, after P2(30)
-      slab(KC{}, FO<1>{}, 0, no_side);                                                                    // P2(31)
+      slab(KC{}, FO<1>{}, 0, no_side, V8{});                                                                    // P2(31)
     } else {
       stash_load(0);
-      slab(KA{}, FO<0>{}, 0, no_side);
-      slab(KA{}, FO<2>{}, 1, [&](int m) __attribute__((always_inline)) { E_step(0, 0, m, 8, 4); });
+      slab(KA{}, FO<0>{}, 0, no_side, V8{});
+      slab(KA{}, FO<2>{}, 1, [&](int m) __attribute__((always_inline)) { E_step(0, 0, m, 8, 4); }, V8{});
 #pragma unroll 1
       for (int kk = 1; kk <= 29; kk += 2) {
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
           const int k = kk + o, pe = 1 - o, pn = o;
-          slab(KC{}, FO<1>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, m, 24, 16); });
-          slab(KD{}, FO<0>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 8 + m, 24, 16); });
-          slab(KA{}, FO<2>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 16 + m, 24, 16); });
+          slab(KC{}, FO<1>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, m, 24, 16); }, V8{});
+          slab(KD{}, FO<0>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 8 + m, 24, 16); }, V8{});
+          slab(KA{}, FO<2>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 16 + m, 24, 16); }, V16{});   // (8 stash loads + 8 pieces younger)
         }
       }
-      slab(KC{}, FO<1>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(31, 1, m, 20, 16); });
-      slab(KD{}, FO<0>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(31, 1, 8 + m, 20, 16); });
+      slab(KC{}, FO<1>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(31, 1, m, 20, 16); }, V8{});
+      slab(KD{}, FO<0>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(31, 1, 8 + m, 20, 16); }, V8{});
 #pragma unroll
       for (int i = 16; i < 20; ++i) E_step(31, 1, i, 20, 16);
-      slab(KC{}, FO<2>{}, 0, no_side); slab(KD{}, FO<1>{}, 0, no_side);
+      slab(KC{}, FO<2>{}, 0, no_side, V8{}); slab(KD{}, FO<1>{}, 0, no_side, V8{});
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
@@ -508,8 +511,10 @@ void ffx_kernel(FfxArgs f, int n_mt) {
 #undef FX_MAC_MID
 #undef FX_MAC_TAIL
   if ((ABL & 64) && f.stamps && lane == 0) {
-    unsigned long long* o = f.stamps + ((long)blockIdx.x * 4 + wave) * 4;
+    unsigned long long* o = f.stamps + ((long)blockIdx.x * 4 + wave) * 6;
     o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3];
+    o[4] = __builtin_amdgcn_s_memtime() - t_start;          // shader cycles of the whole kernel ..
+    o[5] = __builtin_amdgcn_s_memrealtime() - r_start;      // .. over 100 MHz ticks: the clock it ran at
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the block
