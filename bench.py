@@ -148,7 +148,7 @@ def profile_gemm(dm, B, cloud, hard_conds):
 
 
 PMC_FILE = "profiles/r03_pmc_traffic.json"
-SUSTAINED_FP32EQ_TFLOPS = 510.0        # profiles/r02_power_clocks.txt: the bare fp16x3 MFMA + LDS-read loop sustains 491-530 TFLOP/s (fp32-
+SUSTAINED_FP32EQ_TFLOPS = 510.0        # profiles/r02_power_clocks.txt, r03_power_clocks.txt: the bare fp16x3 MFMA + LDS-read loop sustains 491-530 TFLOP/s (fp32-
                                        # equivalent) at the 1.4 kW socket limit, i.e. 0.59-0.64 of the 833.3 nominal ceiling
 STASH_BYTES_PER_ROW_EVAL = 4.0e6       # what ONE score evaluation must keep per network row for the input
                                        # gradient (conv outputs, norm statistics, per block-token z, qkv, z1, GEGLU stash)
@@ -407,8 +407,10 @@ def main():
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_source": traffic_src,
             "hbm_frac": (traffic / (avg_us * 1e-6) / 1e12 / PEAK_HBM_TBS) if traffic else None,
-            "kernel": "ramp::gemm_x6p_kernel<*, NP=2> (fp16x3; NP=3 = bf16x6 in the calibration evaluation) + gemm_kernel<*> "
-                      "(exact fp32, N = 32 layers): linears + k5/k1/stride-2 convs, forward and dX",
+            "kernel": "the split-precision GEMM class: ramp::ffx_kernel<fwd|bwd> (token-owning fused LN3 -> FF1 -> GEGLU -> FF2 and its "
+                      "input gradient, 45 % of the class's time), ramp::tkl_kernel<*> (token-owning LN1 -> QKV, out-projection, d(o)), "
+                      "ramp::gemm_x6p*_kernel<*, NP=2> (fp16x3 tile kernels: k5/k1/stride-2 convs, d(ln1), proj_in/out; NP=3 = bf16x6 "
+                      "in a calibration evaluation) + gemm_kernel<*> (exact fp32, N = 32 layers), forward and dX",
             "peak_note": "achieved = ALGORITHMIC fp32 FLOPs of the GEMM launches / their summed HIP-event time; peak = the pipe "
                          "the kernel executes on, fp16 dense MFMA 2500 TFLOP/s, divided by the 3 fp16 products it spends per "
                          "fp32 product (833.3); frac = executed fp16 FLOP/s / 2500",
