@@ -310,6 +310,11 @@ int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* 
 int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
                 const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
                 float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
+/* d(ln1) = d(qkv) Wqkv^T with the LayerNorm-1 backward in its epilogue (tkl.hip, tklb_kernel; the product path's replacement of
+ * the d(ln1) GEMM + ln_bwd pair, reference layers_attention_mini.py:132 differentiated): out = add + LNbwd(dqkv W^T; z, ln_g).
+ * dqkv (M, 768), W (256, 768) = [Wq | Wk | Wv]^T rows, z / add / out (M, 256), device fp32.  Scaling arguments as ramp_op_tkl. */
+int ramp_op_tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, int32_t M,
+                 float absmax_prev, float* out, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
 /* micro-benchmark (profiling tools only): one GEMM shape on the kernel `mode` names (as ramp_op_gemm_mode), operands
  * allocated and filled inside, weights packed once, `warmup` untimed then `iters` timed back-to-back launches on `stream`
  * between two HIP events; *avg_us = microseconds per launch.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue

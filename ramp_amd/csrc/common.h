@@ -134,6 +134,21 @@ struct TklArgs {
 };
 int launch_tkl(const TklArgs& a, hipStream_t s);
 int init_tkl_attributes();
+// Token-owning d(ln1) with LayerNorm-1 backward in its epilogue (tkl.hip): out = add + LNbwd(X W^T; z, gamma), X = d(qkv) (M, 768),
+// W = Wqkv^T as [256][768] (fp16 fragment planes, launch_pack_h3), z = the LayerNorm's input (M, 256), add = the gradient that
+// bypasses the block (M, 256).  One call site (the operand X).
+struct TklbArgs {
+  int M = 0;
+  const float* X = nullptr;            // [M][768]
+  const float* Z = nullptr;            // [M][256]
+  const float* add = nullptr;          // [M][256]
+  float* Y = nullptr;                  // [M][256]
+  const unsigned short* W = nullptr;   // planes of [256][768]: 96 KB per 32 output features
+  const float* ln_g = nullptr;
+  const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;
+  int* range_flag = nullptr;
+};
+int launch_tklb(const TklbArgs& a, hipStream_t s);
 
 // ---- row-wise ops (rowops.hip) --------------------------------------------------------------
 // GroupNorm over (L, C/8) per (row, group) [+ Mish] [+ per-channel time bias] [+ residual]

@@ -438,6 +438,24 @@ struct Run {
     c->launches++;
     return rc;
   }
+  // d(ln1) = d(qkv) Wqkv^T and the LayerNorm-1 backward behind it in one token-owning launch (tkl.hip, tklb_kernel); consumes
+  // the call site of the d(ln1) GEMM it replaces
+  bool use_tklb(int M) const {
+    return c->tkl_min_rows > 0 && M >= c->tkl_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe;
+  }
+  int tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, float* out, int M) {
+    prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 768, {M, 256, 768, -1});
+    GemmArgs b; b.A = dqkv; b.lda = 768; b.W = W; b.C = out; b.ldc = 256; b.M = M; b.N = 256; b.K = 768; b.taps = 1; b.L = 1;
+    const int kind = prep(b);
+    if (kind < 0) return kind;
+    RAMP_REQUIRE(kind == 2, "tklb: weight without fp16 fragment planes");
+    TklbArgs t; t.M = M; t.X = dqkv; t.Z = z; t.add = add; t.Y = out; t.W = b.Wx; t.ln_g = ln_g;
+    t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.wsi = b.w_scale_inv; t.site = b.site_id; t.range_flag = b.range_flag;
+    int rc = launch_tklb(t, s);
+    prof_post(c, s);
+    c->launches++;
+    return rc;
+  }
   // FF1 -> GEGLU -> FF2 of one transformer block (layers_attention_mini.py:38-45, 147): one fused launch in the fp16x3
   // evaluations (the 1024-wide hidden stays in LDS), two launches otherwise.  Either way the two call sites are
   // numbered in the same order, so calibration and fused evaluations read each other's maxima.
@@ -644,8 +662,12 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx, int s
       if (r.use_tkl(o)) CK(r.tkl(o, nullptr, nullptr)); else CK(r.gemm(o));
     }
     LAUNCH(c, r.s, CAT_ATTN, 32.0 * Rb * m.L * m.L * 64, launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, Rb, m.L, r.s));
-    CK(r.gemm(lin(c->t_dqkv, 768, k.wqkv_b, nullptr, c->t_dln, D, Mb, D, 768)));        // d(ln1)
-    LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, zin, k.ln1_g, dz1, dz, Mb, r.s));           // dz (block input)
+    if (r.use_tklb(Mb)) {      // d(ln1) and the LayerNorm-1 backward in one token-owning launch: dz = dz1 + LN1bwd(d(qkv) Wqkv^T)
+      CK(r.tklb(c->t_dqkv, k.wqkv_b, zin, k.ln1_g, dz1, dz, Mb));
+    } else {
+      CK(r.gemm(lin(c->t_dqkv, 768, k.wqkv_b, nullptr, c->t_dln, D, Mb, D, 768)));        // d(ln1)
+      LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, zin, k.ln1_g, dz1, dz, Mb, r.s));           // dz (block input)
+    }
   }
   CK(r.gemm(lin(dz, D, m.wpi_b, nullptr, c->t_xn, m.C, Mp, m.C, D)));                   // d(xn)
   GnBwdArgs g; g.dy = c->t_xn; g.x = x; g.stats = m.a_gst; g.gamma = m.gn_g; g.beta = m.gn_b; g.add = dy; g.dx = dx;
@@ -1995,6 +2017,38 @@ int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* 
   return rc;
 }
 
+int ramp_op_tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, int32_t M,
+                 float absmax_prev, float* out, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  RAMP_REQUIRE(dqkv && W && z && ln_g && add && out && M > 0, "bad arguments");
+  hipStream_t s = as_stream(stream);
+  DevArena ar;
+  std::vector<float> hw((size_t)256 * 768);
+  RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
+  float mx = 0.f;
+  for (float v : hw) mx = std::max(mx, std::fabs(v));
+  float sc = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
+  unsigned short* planes = reinterpret_cast<unsigned short*>(ar.alloc((size_t)256 * 768 + 4));
+  float* slots = ar.alloc(4);
+  RAMP_REQUIRE(planes && slots, "hipMalloc failed");
+  CK(launch_pack_h3(W, planes, 256, 768, sc, s));
+  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
+  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
+  TklbArgs a; a.M = M; a.X = dqkv; a.Z = z; a.add = add; a.Y = out; a.W = planes; a.ln_g = ln_g;
+  a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
+  a.range_flag = reinterpret_cast<int*>(slots + 2);
+  int rc = launch_tklb(a, s);
+  hipError_t e = hipStreamSynchronize(s);
+  float back[4] = {0, 0, 0, 0};
+  if (rc == 0 && e == hipSuccess) {
+    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
+    if (absmax_out_host) *absmax_out_host = back[1];
+    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
+  }
+  RAMP_HIP_CHECK(e);
+  return rc;
+}
+
 // micro-benchmark of one GEMM shape on a named kernel: packs once, `warmup` + `iters` back-to-back launches on `stream`,
 // HIP events around the timed ones.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue (N = 2F, writes the F-wide
 // product too), 8 A-multiplier operand (K = 2 * period).  Operands are allocated and filled here (uniform [-1, 1)).
@@ -2050,7 +2104,7 @@ thread_local StressHook* g_stress = nullptr;
 
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 8, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 9, "bad arguments");
   if (mode == 6 || mode == 7) {                        // ffx.hip: fused feed-forward with token-owning waves, forward / backward
     hipStream_t s6 = as_stream(stream);
     DevArena ar6;
@@ -2096,6 +2150,34 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
               sm[0] / slabs, sm[1] / slabs, sm[2] / slabs, sm[3] / slabs, nw, sm[5] > 0 ? sm[4] / sm[5] * 100.0 : 0.0);
     }
     return rc6;
+  }
+  if (mode == 9) {                                     // tkl.hip, tklb_kernel: d(ln1) + LayerNorm-1 backward (N, K ignored: 768 -> 256)
+    hipStream_t s9 = as_stream(stream);
+    DevArena ar9;
+    float* X9 = ar9.alloc((size_t)M * 768); float* Z9 = ar9.alloc((size_t)M * 256); float* A9 = ar9.alloc((size_t)M * 256); float* Y9 = ar9.alloc((size_t)M * 256);
+    float* W9 = ar9.alloc((size_t)256 * 768); float* lg = ar9.alloc(256); float* sl = ar9.alloc(4);
+    unsigned short* p9 = reinterpret_cast<unsigned short*>(ar9.alloc((size_t)256 * 768 + 4));
+    RAMP_REQUIRE(X9 && Z9 && A9 && Y9 && W9 && lg && sl && p9, "hipMalloc failed");
+    auto fill9 = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s9, p, (long)n, seed, sc); };
+    fill9(X9, (size_t)M * 768, 1u, 1.f); fill9(Z9, (size_t)M * 256, 3u, 1.f); fill9(A9, (size_t)M * 256, 4u, 1.f); fill9(W9, (size_t)256 * 768, 2u, 1.f / 16.f); fill9(lg, 256, 8u, 1.f);
+    CK(launch_pack_h3(W9, p9, 256, 768, 16384.f, s9));
+    const float one[4] = {1.f, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, s9));
+    TklbArgs a; a.M = M; a.X = X9; a.Z = Z9; a.add = A9; a.Y = Y9; a.W = p9; a.ln_g = lg; a.amax_in = sl; a.amax_out = sl + 1; a.wsi = 1.f / 16384.f;
+    a.range_flag = reinterpret_cast<int*>(sl + 2);
+    for (int i = 0; i < warmup; ++i) CK(launch_tklb(a, s9));
+    hipEvent_t e0, e1;
+    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+    RAMP_HIP_CHECK(hipEventRecord(e0, s9));
+    int rc9 = 0;
+    for (int i = 0; i < iters && rc9 == 0; ++i) { rc9 = launch_tklb(a, s9); if (rc9 == 0) STRESS(Y9, (size_t)M * 256, s9); }
+    RAMP_HIP_CHECK(hipEventRecord(e1, s9));
+    RAMP_HIP_CHECK(hipEventSynchronize(e1));
+    float ms9 = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&ms9, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = ms9 * 1e3f / iters;
+    return rc9;
   }
   if (mode == 8) {                                     // tkl.hip: token-owning linear, K = 256; flags: 1 LayerNorm first, 2 bias + residual, >> 8 ablation
     hipStream_t s8 = as_stream(stream);

@@ -267,6 +267,207 @@ void tkl_kernel(TklArgs a, int n_mt) {
   }
 }
 
+// ---- d(ln1) = d(qkv) Wqkv^T (K = 768) with LayerNorm-1 backward in the epilogue -----------------------------------------------
+// Same ring, same slab; the 768-deep product runs as three operand chunks of 256 columns: chunk c's planes sit in XB while its
+// eight slabs (one per 32 output features) accumulate into acc2[0..7].  The next chunk's columns cannot wait in registers
+// (accumulators 128 + operand planes 128 + fragment ring 64 + a raw chunk 128 spills ~200 values): they are TOUCHED during
+// the current chunk's slabs (one dword per 128-byte line, four per lane) so that the chunk's own loads hit the L2.  The weight planes [row / 32][k / 16][plane] hold a feature block's three
+// chunks 32 KB apart, so slab (c, nb) starts at nb * 96 KB + c * 32 KB.  Epilogue = ffx.hip's backward epilogue: lane (r, h)
+// holds features 32 nb + 8 q + 4 h + i of token r, LayerNorm statistics need one shuffle per row sum.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void tklb_kernel(TklbArgs a, int n_mt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int n_my = (n_mt - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+  const float s_in = scale_of(a.amax_in);
+  const float os = a.wsi / s_in;
+  float amax = 0.f;
+
+  const char* wsrc = reinterpret_cast<const char*>(a.W) + wave * 8192 + lane * 16;
+  int is_q = 0, is_g = 0;                                   // is_q: slab of the tile, 8 c + nb
+  const char* cur_src = wsrc; unsigned cur_dst = 0;
+  auto dma_begin = [&]() __attribute__((always_inline)) {
+    cur_src = wsrc + (long)(is_q & 7) * (3 * TK_SLAB) + (long)(is_q >> 3) * TK_SLAB;
+    cur_dst = (unsigned)(uintptr_t)(smem + (is_g & (TK_R - 1)) * TK_SLAB + wave * 8192);
+    is_q = is_q + 1 == 24 ? 0 : is_q + 1;
+    ++is_g;
+  };
+#define TK_PIECE(C) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" \
+                                 :: "v"(cur_src + ((C) >> 2) * 4096), "s"(cur_dst + ((C) >> 2) * 4096), "n"(((C) & 3) * 1024) : "memory", "m0")
+  auto dma_piece = [&](int c) __attribute__((always_inline)) {
+    switch (c) { case 0: TK_PIECE(0); break; case 1: TK_PIECE(1); break; case 2: TK_PIECE(2); break; case 3: TK_PIECE(3); break;
+                 case 4: TK_PIECE(4); break; case 5: TK_PIECE(5); break; case 6: TK_PIECE(6); break; default: TK_PIECE(7); break; }
+  };
+  auto issue_slab = [&]() __attribute__((always_inline)) {
+    dma_begin();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dma_piece(c);
+  };
+
+  u32x4 F[4][4];
+  int g = 0;
+  const char* rd = smem + lane * 16;
+  u32x4 XB[16][2];
+  f32x16 acc2[8];
+  float touch = 0.f, tch[4] = {0.f, 0.f, 0.f, 0.f};         // sink of the L2 touches
+
+  auto slab = [&](f32x16& ac, auto side) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dma_begin();
+    const int slot = g & (TK_R - 1), nslot = (g + 1) & (TK_R - 1);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      u32x4 (&FB)[4] = F[m & 3];
+      u32x4 (&FN)[4] = F[(m + 2) & 3];
+      const char* np = rd + (m < 6 ? slot * TK_SLAB + (m + 2) * 4096 : nslot * TK_SLAB + (m - 6) * 4096);
+      const int s = 2 * m;
+      __builtin_amdgcn_sched_barrier(0);
+      ac = mfma16(FB[1], XB[s][0], ac);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_piece(m);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) FN[i] = *reinterpret_cast<const u32x4*>(np + i * 1024);
+      ac = mfma16(FB[0], XB[s][1], ac); ac = mfma16(FB[0], XB[s][0], ac);
+      ac = mfma16(FB[3], XB[s + 1][0], ac);
+      ac = mfma16(FB[2], XB[s + 1][1], ac); ac = mfma16(FB[2], XB[s + 1][0], ac);
+      side(m);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 12, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ++g;
+  };
+
+  // one dword of line j (of 4) of this lane's half row of columns [256 c, 256 c + 256) of tile mt: brings the line into the L2
+  auto x_touch = [&](int mt, int c, int j) __attribute__((always_inline)) {
+    long tok = (long)mt * 128 + wave * 32 + r;
+    tok = tok < a.M ? tok : a.M - 1;
+    tch[j] = a.X[tok * 768 + 256 * c + 128 * h + 32 * j];   // (consumed after the chunk's slabs: no wait inside them)
+  };
+
+  reinterpret_cast<float*>(smem + TK_LN)[tid] = a.ln_g[tid];
+  issue_slab(); issue_slab(); issue_slab();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { F[0][i] = *reinterpret_cast<const u32x4*>(rd + i * 1024); F[1][i] = *reinterpret_cast<const u32x4*>(rd + 4096 + i * 1024); }
+  const float* lng = reinterpret_cast<const float*>(smem + TK_LN);
+
+  for (int ti = 0; ti < n_my; ++ti) {
+    const int mt = (int)blockIdx.x + ti * (int)gridDim.x;
+    const int mt_next = ti + 1 < n_my ? mt + (int)gridDim.x : mt;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+      {
+        long tok = (long)mt * 128 + wave * 32 + r;
+        tok = tok < a.M ? tok : a.M - 1;                    // (rows past M recompute row M - 1)
+        const float* xrow = a.X + tok * 768 + 256 * c + 8 * h;   // lane (r, h) holds k = 16 s + 8 h + i of token r
+        f32x4 xv[32];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          xv[2 * s] = *reinterpret_cast<const f32x4*>(xrow + 16 * s);
+          xv[2 * s + 1] = *reinterpret_cast<const f32x4*>(xrow + 16 * s + 4);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          amax_pin(amax, xv[2 * s][0], xv[2 * s][1]); amax_pin(amax, xv[2 * s][2], xv[2 * s][3]);
+          amax_pin(amax, xv[2 * s + 1][0], xv[2 * s + 1][1]); amax_pin(amax, xv[2 * s + 1][2], xv[2 * s + 1][3]);
+          split8(xv[2 * s] * s_in, xv[2 * s + 1] * s_in, XB[s][0], XB[s][1]);
+        }
+      }
+      const int nmt = c < 2 ? mt : mt_next, nc = c < 2 ? c + 1 : 0;
+#define TB_SLAB(NB, J) slab(acc2[NB], [&](int m) __attribute__((always_inline)) { if (J >= 0 && m == 0) x_touch(nmt, nc, J < 0 ? 0 : J); })
+      TB_SLAB(0, -1); TB_SLAB(1, -1); TB_SLAB(2, -1); TB_SLAB(3, 0); TB_SLAB(4, 1); TB_SLAB(5, 2); TB_SLAB(6, 3); TB_SLAB(7, -1);
+#undef TB_SLAB
+      touch += (tch[0] + tch[1]) + (tch[2] + tch[3]);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    // ---- epilogue: out = add + LNbwd(d(ln1); z, gamma)  (rowops.hip ln_bwd_kernel; ffx.hip's backward epilogue) ------------------
+    int mt_e = mt;
+    asm volatile("" : "+s"(mt_e));                          // (row addresses recomputed here, not carried across the slabs)
+    long tok_e = (long)mt_e * 128 + wave * 32 + r;
+    tok_e = tok_e < a.M ? tok_e : a.M - 1;                  // rows past M recompute and rewrite row M - 1 (unconditional stores)
+    const float* zrow = a.Z + tok_e * 256 + 4 * h;
+    const float* drow = a.add + tok_e * 256 + 4 * h;
+    float* orow = a.Y + tok_e * 256 + 4 * h;
+    {
+      f32x4 xz[32], ad[32];
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) xz[i] = *reinterpret_cast<const f32x4*>(zrow + 8 * i);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) ad[i] = *reinterpret_cast<const f32x4*>(drow + 8 * i);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) sum += (xz[i][0] + xz[i][1]) + (xz[i][2] + xz[i][3]);
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.f / 256.f);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xz[i][e] - mean; ss += d * d; }
+      ss += __shfl_xor(ss, 32);
+      const float rstd = 1.f / sqrtf(ss * (1.f / 256.f) + 1e-5f);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {                        // i = 4 nb + q
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(lng + 8 * i + 4 * h);
+        f32x4 gq = quad(acc2[i >> 2], i & 3) * os * gm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xz[i][e] = (xz[i][e] - mean) * rstd;
+          t1 += gq[e]; t2 += gq[e] * xz[i][e];
+          acc2[i >> 2][4 * (i & 3) + e] = gq[e];
+        }
+      }
+      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+      const float m1 = t1 * (1.f / 256.f), m2 = t2 * (1.f / 256.f);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (acc2[i >> 2][4 * (i & 3) + e] - m1 - xz[i][e] * m2) * rstd + ad[i][e];
+        *reinterpret_cast<f32x4*>(orow + 8 * i) = o;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");        // (bounds the operations in flight before the next tile, as ffx.hip)
+  }
+#undef TK_PIECE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if (lane == 0) {
+    if (a.amax_out) atomicMax(reinterpret_cast<unsigned*>(a.amax_out), __builtin_bit_cast(unsigned, amax));
+    if (a.range_flag && (!(amax * s_in < 60000.f) || (amax > 0.f && amax * s_in < 0.125f))) atomicMax(a.range_flag, a.site + 1);
+  }
+  if (touch == 1.2345e-30f && a.amax_out) a.amax_out[0] = touch;      // (keeps the touches alive; never true in practice)
+}
+
+int launch_tklb(const TklbArgs& a, hipStream_t s) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  RAMP_REQUIRE(a.M > 0 && a.X && a.Z && a.add && a.Y && a.W && a.ln_g, "tklb: null operand");
+  RAMP_REQUIRE(al16(a.X) && al16(a.Z) && al16(a.add) && al16(a.Y) && al16(a.W), "tklb: operands must be 16-byte aligned");
+  const int n_mt = (a.M + 127) / 128;
+  hipLaunchKernelGGL(tklb_kernel, dim3(std::min(n_mt, 256)), dim3(256), TK_LDS, s, a, n_mt);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_tkl(const TklArgs& a, hipStream_t s) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   RAMP_REQUIRE(a.M > 0 && a.N >= 32 && a.N <= 768 && a.N % 32 == 0 && a.X && a.Y && a.W, "tkl: bad operand");
@@ -302,6 +503,7 @@ int init_tkl_attributes() {
   TK_ATTR3(1); TK_ATTR3(2); TK_ATTR3(8); TK_ATTR3(3);
 #undef TK_ATTR3
 #undef TK_ATTR
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tklb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS));
   return 0;
 }
 

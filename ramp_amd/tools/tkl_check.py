@@ -70,3 +70,12 @@ if __name__ == "__main__":
                 b = min(t(M, N, 3, fl_g) for _ in range(2))
                 fl = 2.0 * M * N * 256
                 print(f"M={M} N={N} {what:28s}: tkl {a:7.1f} us ({fl / a / 1e6:4.0f} TF)   tile kernel {b:7.1f} us ({fl / b / 1e6:4.0f} TF)", flush=True)
+    if "--bench-b" in sys.argv:
+        for M in (393216, 196608, 98304, 49152):
+            us = C.c_float()
+            best = 1e30
+            for _ in range(2):
+                _lib.check(lib.ramp_bench_gemm(M, 256, 768, 1, 1, 9, 0, 3, 10, C.byref(us), None)); best = min(best, us.value)
+            b = min(t(M, 256, 3, 0, K=768) for _ in range(2))
+            fl = 2.0 * M * 256 * 768
+            print(f"M={M} d(ln1) + LN1 backward: tklb {best:7.1f} us ({fl / best / 1e6:4.0f} TF)   tile kernel alone {b:7.1f} us ({fl / b / 1e6:4.0f} TF; + ln_bwd)", flush=True)

@@ -484,6 +484,43 @@ def test_tkl_token_owning_linear_against_float64(M, N, ln, epi):
     assert flag.value == 1, flag.value
 
 
+@pytest.mark.parametrize("M", [128, 293, 4173])
+def test_tklb_dln1_with_layernorm_backward_against_float64_autograd(M):
+    """d(ln1) = d(qkv) Wqkv^T with the LayerNorm-1 backward in its epilogue (tkl.hip tklb_kernel through ramp_op_tklb): the
+    input gradient of qkv = Wqkv LN1(z) (layers_attention_mini.py:132) plus the gradient that bypasses the block, against
+    float64 autograd; M not a multiple of the tile; recorded operand maximum exact, scaling from it leaves the result
+    unchanged to rounding, a stale maximum raises the range flag."""
+    import ctypes as C
+    from ramp_amd import _lib
+    gen = torch.Generator(device="cpu").manual_seed(M)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).cuda()
+    z, dqkv, add = r(M, 256, sc=1.3) + 0.2, r(M, 768, sc=0.7), r(M, 256)
+    Wqkv = r(768, 256, sc=1 / 16)                                  # qkv = LN(z) Wqkv^T
+    g, b = 1 + r(256, sc=0.1), r(256, sc=0.1)
+    zz = z.double().requires_grad_(True)
+    qkv = torch.nn.functional.layer_norm(zz, (256,), g.double(), b.double(), 1e-5) @ Wqkv.double().T
+    (dz,) = torch.autograd.grad(qkv, zz, dqkv.double())
+    ref = (dz + add.double()).cpu().numpy()
+    Wt = Wqkv.T.contiguous()                                       # (256, 768): the operand the kernel takes
+    out = torch.empty(M, 256, device="cuda")
+    amax, flag = C.c_float(0), C.c_int32(0)
+
+    def go(prev):
+        out.fill_(float("nan"))
+        _lib.check(_lib.load().ramp_op_tklb(_lib.ptr(dqkv), _lib.ptr(Wt), _lib.ptr(z), _lib.ptr(g), _lib.ptr(add), M, prev, _lib.ptr(out),
+                                            C.byref(amax), C.byref(flag), None), "ramp_op_tklb")
+        return rel(out.double().cpu().numpy(), ref)
+
+    e = go(0.0)
+    assert e < 3e-6 and flag.value == 0, (e, flag.value)
+    true_max = dqkv.abs().max().item()
+    assert abs(amax.value - true_max) <= 1e-6 * true_max
+    e2 = go(amax.value)
+    assert e2 < 3e-6 and flag.value == 0, (e2, flag.value)
+    go(true_max / 4096.0)
+    assert flag.value == 1, flag.value
+
+
 STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, compare with the exact-fp32 kernel?
     ("fp16x3 bias-only 768x256 (QKV; third resident block)", 393216, 768, 256, 1, 1, 3, 1, True),
     ("fp16x3 residual 256x256 (out-proj, 64x256 tile)", 393216, 256, 256, 1, 1, 3, 3, True),
