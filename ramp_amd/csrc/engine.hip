@@ -200,7 +200,7 @@ struct ramp_ctx {
   std::map<std::string, std::pair<float*, size_t>> dbg;
   int64_t launches = 0;
   // per-launch HIP-event profiler (eager mode only): category, algorithmic flops, start/stop events
-  bool prof_on = false, prof_dump = false; int ffx_ablate = 0;
+  bool prof_on = false, prof_dump = false; int ffx_ablate = 0; bool tklb_off = false;
   std::vector<hipEvent_t> prof_ev; size_t prof_used = 0;
   std::vector<int> prof_cat; std::vector<double> prof_flops; std::vector<std::array<int, 4>> prof_shape;
 };
@@ -441,7 +441,7 @@ struct Run {
   // d(ln1) = d(qkv) Wqkv^T and the LayerNorm-1 backward behind it in one token-owning launch (tkl.hip, tklb_kernel); consumes
   // the call site of the d(ln1) GEMM it replaces
   bool use_tklb(int M) const {
-    return c->tkl_min_rows > 0 && M >= c->tkl_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe;
+    return !c->tklb_off && c->tkl_min_rows > 0 && M >= c->tkl_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe;
   }
   int tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, float* out, int M) {
     prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 768, {M, 256, 768, -1});
@@ -1010,6 +1010,7 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
     c->prof_dump = getenv("RAMP_PROFILE_DUMP") != nullptr;
     const char* ae = getenv("RAMP_FFX_ABLATE");              // diagnostic A/B of the fused feed-forward inside a whole job
     if (ae) c->ffx_ablate = atoi(ae);
+    c->tklb_off = getenv("RAMP_TKLB_OFF") != nullptr;       // diagnostic: d(ln1) + LN1 backward on the tile kernel + ln_bwd pair
   }
   *out = c;
   return 0;

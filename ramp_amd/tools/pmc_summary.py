@@ -11,7 +11,7 @@ import sys
 
 
 def klass(name):
-    if "gemm_x6" in name or "gemm_kernel" in name or "ff_fwd_kernel" in name or "ffx_kernel" in name or "tkl_kernel" in name:
+    if "gemm_x6" in name or "gemm_kernel" in name or "ff_fwd_kernel" in name or "ffx_kernel" in name or "tkl_kernel" in name or "tklb_kernel" in name:
         return "gemm"
     if "attn2" in name:
         return "attention"
