@@ -534,6 +534,9 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("fused FF1->GEGLU->FF2 forward (ff_fwd_kernel)", 393216, 2048, 256, 1, 1, 5, 0, False),
     ("token-owning fused feed-forward, forward (ffx)", 393216, 2048, 256, 1, 1, 6, 0, False),
     ("token-owning fused feed-forward, backward (ffx)", 393216, 2048, 256, 1, 1, 7, 0, False),
+    ("token-owning LN1 -> QKV (tkl)", 393216, 768, 256, 1, 1, 8, 1, False),
+    ("token-owning out-projection with bias and residual (tkl)", 393216, 256, 256, 1, 1, 8, 2, False),
+    ("token-owning d(ln1) with LayerNorm-1 backward (tklb)", 393216, 256, 768, 1, 1, 9, 0, False),
 ]
 
 
