@@ -176,12 +176,20 @@ void tkl_kernel(TklArgs a, int n_mt) {
           for (int e = 0; e < 4; ++e) { const float d = xn[i][e] - mean; ss += d * d; }
         ss += __shfl_xor(ss, 32);
         const float rstd = 1.f / sqrtf(ss * (1.f / 256.f) + 1e-5f);
+        // one LDS base per tile (opaque) + immediate offsets: as `lng + k` hipcc kept 32 separate address registers alive across
+        // the tile loop, spilled them and reloaded each behind an s_waitcnt vmcnt(0)
+        unsigned lgh = (unsigned)(uintptr_t)(lng + 8 * h);
+        asm volatile("" : "+v"(lgh));
+        typedef __attribute__((address_space(3))) const char* lds_cptr_t;      // (an LDS pointer: 32 bits; a generic pointer rebuilt from them would be a flat load)
+        typedef __attribute__((address_space(3))) const f32x4* lds_f4ptr_t;
+        const lds_cptr_t lgp = (lds_cptr_t)lgh;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-          const int k = 16 * (i >> 1) + 8 * h + 4 * (i & 1);
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(lng + k), bt = *reinterpret_cast<const f32x4*>(lnb + k);
+          const int k = 16 * (i >> 1) + 4 * (i & 1);
+          const f32x4 gm = *(lds_f4ptr_t)(lgp + 4 * k), bt = *(lds_f4ptr_t)(lgp + 4 * (256 + k));
 #pragma unroll
           for (int e = 0; e < 4; ++e) xn[i][e] = (xn[i][e] - mean) * rstd * gm[e] + bt[e];
+          if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (keeps hipcc from hoisting all 64 table reads: 256 registers)
         }
       }
 #pragma unroll
@@ -189,19 +197,27 @@ void tkl_kernel(TklArgs a, int n_mt) {
         amax_pin(amax, xn[2 * s][0], xn[2 * s][1]); amax_pin(amax, xn[2 * s][2], xn[2 * s][3]);      // (pinned: see tokmma.h)
         amax_pin(amax, xn[2 * s + 1][0], xn[2 * s + 1][1]); amax_pin(amax, xn[2 * s + 1][2], xn[2 * s + 1][3]);
         split8(xn[2 * s] * s_in, xn[2 * s + 1] * s_in, XB[s][0], XB[s][1]);
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
     // rows this lane stores (and reads the residual of): token 8 j + l8 of the wave, clamped (rows past M rewrite row M - 1
     // with the same bits: every lane issues every load and store)
-    float* yrow[4]; const float* rrow[4]; const float* rbp[4];
+    // (addresses are formed where they are used, from a tile index hipcc cannot see through: as per-tile arrays of row
+    // pointers they were spilled and every slab reloaded them from scratch behind an s_waitcnt vmcnt(0))
+    int rbo[4] = {0, 0, 0, 0};                              // LDS offset of each row's variant constants
+    if (EPI & 2) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      long t = (long)mt * 128 + wave * 32 + 8 * j + l8;
-      t = t < a.M ? t : a.M - 1;
-      yrow[j] = a.Y + t * a.ldy + c4;
-      rrow[j] = (EPI & 1) ? a.resid + t * a.ldr + c4 : nullptr;
-      rbp[j] = (EPI & 2) ? reinterpret_cast<const float*>(smem + TK_RB) + a.rowvar[a.row0 + (int)(t / a.L)] * 256 + c4 : nullptr;
+      for (int j = 0; j < 4; ++j) {
+        long t = (long)mt * 128 + wave * 32 + 8 * j + l8;
+        t = t < a.M ? t : a.M - 1;
+        rbo[j] = a.rowvar[a.row0 + (int)(t / a.L)] * 256 + c4;
+      }
     }
+    auto row_of = [&](int j) __attribute__((always_inline)) {
+      int mt_o = mt; asm volatile("" : "+s"(mt_o));
+      long t = (long)mt_o * 128 + wave * 32 + 8 * j + l8;
+      return t < a.M ? t : a.M - 1;
+    };
 
     // epilogue of feature block pb (accumulator P), one step per macro-step of the next slab:
     // 0 residual requested | 1 accumulators -> transpose scratch | 2 read back token-major | 3 bias, constants | 4..7 one store each
@@ -210,7 +226,7 @@ void tkl_kernel(TklArgs a, int n_mt) {
       if (st == 0) {
         if (EPI & 1) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) rz[j] = *reinterpret_cast<const f32x4*>(rrow[j] + 32 * pb);
+          for (int j = 0; j < 4; ++j) rz[j] = *reinterpret_cast<const f32x4*>(a.resid + row_of(j) * a.ldr + c4 + 32 * pb);
         }
       } else if (st == 1) {
 #pragma unroll
@@ -222,14 +238,14 @@ void tkl_kernel(TklArgs a, int n_mt) {
         bq = *reinterpret_cast<const f32x4*>(bs + 32 * pb);
         if (EPI & 2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) rbq[j] = *reinterpret_cast<const f32x4*>(rbp[j] + 32 * pb);
+          for (int j = 0; j < 4; ++j) rbq[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + TK_RB) + rbo[j] + 32 * pb);
         }
       } else {
         const int j = st - 4;
         f32x4 v = tv[j] * os + bq;
         if (EPI & 2) v += rbq[j];
         if (EPI & 1) v += rz[j];
-        if (!(ABL & 2) || mt < 0) *reinterpret_cast<f32x4*>(yrow[j] + 32 * pb) = v;
+        if (!(ABL & 2) || mt < 0) *reinterpret_cast<f32x4*>(a.Y + row_of(j) * a.ldy + c4 + 32 * pb) = v;
       }
     };
     auto no_side = [](int) __attribute__((always_inline)) {};
