@@ -216,3 +216,51 @@ def test_gemm_kernels_keep_their_occupancy():
         elif "gemm_kernel" in n:
             assert v <= 256, (n, v)
     assert seen["x6p"] >= 8 and seen["x6p3"] >= 1
+
+
+def _kernel_notes(obj_name):
+    """{kernel name: {vgpr_count, vgpr_spill_count, private_segment_fixed_size}} of a built object's gfx950 code object."""
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "ramp_amd", "lib", "obj", obj_name)
+    if not (os.path.exists(obj) and all(os.path.exists(f"{llvm}/{t}") for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"))):
+        pytest.skip("no built object / no llvm tools")
+    d = tempfile.mkdtemp()
+    try:
+        subprocess.check_call([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, f"{d}/fat.bin"])
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               f"--input={d}/fat.bin", f"--output={d}/k.co", "--unbundle"])
+        notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", f"{d}/k.co"], text=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for entry in notes.split(".agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", entry).group(1)
+        out[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", entry).group(1))
+                     for k in ("vgpr_count", "vgpr_spill_count", "private_segment_fixed_size")}
+    return out
+
+
+def test_token_owning_kernels_do_not_spill():
+    """The token-owning kernels run ONE wave per SIMD with inline-asm LDS-DMA in flight: a scratch reload there is an
+    s_waitcnt vmcnt(0), i.e. a full memory round trip in the middle of the MFMA stream (round 3 removed 30 of them per tile from
+    the fused feed-forward).  The shipped forward feed-forward, LN1 -> QKV, d(o) and d(ln1) kernels must
+    stay free of scratch; the backward feed-forward and the residual variants may only spill a handful of per-tile values."""
+    ffx = _kernel_notes("ffx.o")
+    tkl = _kernel_notes("tkl.o")
+    def one(d, pat):
+        hits = [v for k, v in d.items() if pat in k]
+        assert len(hits) == 1, (pat, [k for k in d if pat in k])
+        return hits[0]
+    assert one(ffx, "ffx_kernelILb0ELi0E")["vgpr_spill_count"] == 0          # forward, product variant
+    assert one(ffx, "ffx_kernelILb1ELi0E")["vgpr_spill_count"] <= 48         # backward: tile prologue / epilogue only (41 today)
+    assert one(tkl, "tkl_kernelILb1ELi0ELi0E")["vgpr_spill_count"] == 0      # LN1 -> QKV
+    assert one(tkl, "tkl_kernelILb0ELi0ELi0E")["vgpr_spill_count"] == 0      # d(o)
+    assert one(tkl, "tklb_kernel")["vgpr_spill_count"] == 0                  # d(ln1) + LayerNorm-1 backward
+    for pat in ("tkl_kernelILb0ELi1ELi0E", "tkl_kernelILb0ELi3ELi0E"):      # out-projection (residual, + row-variant constant)
+        assert one(tkl, pat)["vgpr_spill_count"] <= 8
+    for d in (ffx, tkl):
+        for k, v in d.items():
+            assert v["vgpr_count"] <= 512, (k, v)
