@@ -306,6 +306,7 @@ void tklb_kernel(TklbArgs a, int n_mt) {
   int is_q = 0, is_g = 0;                                   // is_q: slab of the tile, 8 c + nb
   const char* cur_src = wsrc; unsigned cur_dst = 0;
   auto dma_begin = [&]() __attribute__((always_inline)) {
+    asm volatile("" : "+s"(is_q), "+s"(is_g));              // (opaque: with the tile's 24 slabs unrolled hipcc otherwise precomputes -- and spills -- every slab's addresses)
     cur_src = wsrc + (long)(is_q & 7) * (3 * TK_SLAB) + (long)(is_q >> 3) * TK_SLAB;
     cur_dst = (unsigned)(uintptr_t)(smem + (is_g & (TK_R - 1)) * TK_SLAB + wave * 8192);
     is_q = is_q + 1 == 24 ? 0 : is_q + 1;
@@ -328,12 +329,14 @@ void tklb_kernel(TklbArgs a, int n_mt) {
   const char* rd = smem + lane * 16;
   u32x4 XB[16][2];
   f32x16 acc2[8];
+  f32x4 pf[32];                                             // the next operand chunk, raw, fetched one eighth per slab
   float touch = 0.f, tch[4] = {0.f, 0.f, 0.f, 0.f};         // sink of the L2 touches
 
   auto slab = [&](f32x16& ac, auto side) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     dma_begin();
+    asm volatile("" : "+s"(g));
     const int slot = g & (TK_R - 1), nslot = (g + 1) & (TK_R - 1);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -365,6 +368,7 @@ void tklb_kernel(TklbArgs a, int n_mt) {
 
   // one dword of line j (of 4) of this lane's half row of columns [256 c, 256 c + 256) of tile mt: brings the line into the L2
   auto x_touch = [&](int mt, int c, int j) __attribute__((always_inline)) {
+    asm volatile("" : "+s"(mt));
     long tok = (long)mt * 128 + wave * 32 + r;
     tok = tok < a.M ? tok : a.M - 1;
     tch[j] = a.X[tok * 768 + 256 * c + 128 * h + 32 * j];   // (consumed after the chunk's slabs: no wait inside them)
@@ -385,31 +389,44 @@ void tklb_kernel(TklbArgs a, int n_mt) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
-#pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-      {
-        long tok = (long)mt * 128 + wave * 32 + r;
-        tok = tok < a.M ? tok : a.M - 1;                    // (rows past M recompute row M - 1)
-        const float* xrow = a.X + tok * 768 + 256 * c + 8 * h;   // lane (r, h) holds k = 16 s + 8 h + i of token r
-        f32x4 xv[32];
+    // chunk c + 1's columns are fetched into pf during chunk c's slabs (chunks 1 and 2); chunk 0 of a tile is loaded at the tile
+    // switch (its lines were touched into the L2 during the previous tile's last slabs)
+    auto pf_x = [&](int c, int j) __attribute__((always_inline)) {        // columns [256 c, 256 c + 256) of this tile, eighth j
+      int mt_o = mt; asm volatile("" : "+s"(mt_o));                       // (addresses formed at use, not carried across the slabs)
+      long tok = (long)mt_o * 128 + wave * 32 + r;
+      tok = tok < a.M ? tok : a.M - 1;                                    // (rows past M recompute row M - 1)
+      const float* xrow = a.X + tok * 768 + 256 * c + 8 * h;              // lane (r, h) holds k = 16 s + 8 h + i of token r
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          xv[2 * s] = *reinterpret_cast<const f32x4*>(xrow + 16 * s);
-          xv[2 * s + 1] = *reinterpret_cast<const f32x4*>(xrow + 16 * s + 4);
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          amax_pin(amax, xv[2 * s][0], xv[2 * s][1]); amax_pin(amax, xv[2 * s][2], xv[2 * s][3]);
-          amax_pin(amax, xv[2 * s + 1][0], xv[2 * s + 1][1]); amax_pin(amax, xv[2 * s + 1][2], xv[2 * s + 1][3]);
-          split8(xv[2 * s] * s_in, xv[2 * s + 1] * s_in, XB[s][0], XB[s][1]);
-        }
+      for (int s2 = 2 * j; s2 < 2 * j + 2; ++s2) {
+        pf[2 * s2] = *reinterpret_cast<const f32x4*>(xrow + 16 * s2);
+        pf[2 * s2 + 1] = *reinterpret_cast<const f32x4*>(xrow + 16 * s2 + 4);
       }
-      const int nmt = c < 2 ? mt : mt_next, nc = c < 2 ? c + 1 : 0;
-#define TB_SLAB(NB, J) slab(acc2[NB], [&](int m) __attribute__((always_inline)) { if (J >= 0 && m == 0) x_touch(nmt, nc, J < 0 ? 0 : J); })
-      TB_SLAB(0, -1); TB_SLAB(1, -1); TB_SLAB(2, -1); TB_SLAB(3, 0); TB_SLAB(4, 1); TB_SLAB(5, 2); TB_SLAB(6, 3); TB_SLAB(7, -1);
+    };
+    auto convert = [&]() __attribute__((always_inline)) {                 // pf (raw chunk) -> XB planes
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        amax_pin(amax, pf[2 * s2][0], pf[2 * s2][1]); amax_pin(amax, pf[2 * s2][2], pf[2 * s2][3]);
+        amax_pin(amax, pf[2 * s2 + 1][0], pf[2 * s2 + 1][1]); amax_pin(amax, pf[2 * s2 + 1][2], pf[2 * s2 + 1][3]);
+        split8(pf[2 * s2] * s_in, pf[2 * s2 + 1] * s_in, XB[s2][0], XB[s2][1]);
+        if ((s2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf_x(0, j);
+    convert();
+#define TB_SLAB(NB, WORK) slab(acc2[NB], [&](int m) __attribute__((always_inline)) { if (m == 0) { WORK; } })
+    TB_SLAB(0, pf_x(1, 0)); TB_SLAB(1, pf_x(1, 1)); TB_SLAB(2, pf_x(1, 2)); TB_SLAB(3, pf_x(1, 3));
+    TB_SLAB(4, pf_x(1, 4)); TB_SLAB(5, pf_x(1, 5)); TB_SLAB(6, pf_x(1, 6)); TB_SLAB(7, pf_x(1, 7));
+    convert();
+    TB_SLAB(0, pf_x(2, 0)); TB_SLAB(1, pf_x(2, 1)); TB_SLAB(2, pf_x(2, 2)); TB_SLAB(3, pf_x(2, 3));
+    TB_SLAB(4, pf_x(2, 4)); TB_SLAB(5, pf_x(2, 5)); TB_SLAB(6, pf_x(2, 6)); TB_SLAB(7, pf_x(2, 7));
+    convert();
+    // (the last chunk prefetches nothing into registers: z AND the bypassing gradient of the epilogue would need 256 arch VGPRs
+    // beside the accumulators' copies -- hipcc spills every arriving quad; it touches the next tile's first chunk into the L2)
+    TB_SLAB(0, (void)0); TB_SLAB(1, (void)0); TB_SLAB(2, (void)0); TB_SLAB(3, x_touch(mt_next, 0, 0));
+    TB_SLAB(4, x_touch(mt_next, 0, 1)); TB_SLAB(5, x_touch(mt_next, 0, 2)); TB_SLAB(6, x_touch(mt_next, 0, 3)); TB_SLAB(7, (void)0);
 #undef TB_SLAB
-      touch += (tch[0] + tch[1]) + (tch[2] + tch[3]);
-    }
+    touch += (tch[0] + tch[1]) + (tch[2] + tch[3]);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
     // ---- epilogue: out = add + LNbwd(d(ln1); z, gamma)  (rowops.hip ln_bwd_kernel; ffx.hip's backward epilogue) ------------------
