@@ -278,8 +278,8 @@ void ffx_kernel(FfxArgs f, int n_mt) {
         const float* p = stash_w + (long)u * 8192;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          st1[BWD ? q : 0] = *reinterpret_cast<const f32x4*>(p + (2 * q) * 256);
-          st2[BWD ? q : 0] = *reinterpret_cast<const f32x4*>(p + (2 * q + 1) * 256);
+          st1[BWD ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (2 * q) * 256));      // (read once)
+          st2[BWD ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (2 * q + 1) * 256));
         }
       }
     };
@@ -340,8 +340,12 @@ void ffx_kernel(FfxArgs f, int n_mt) {
           hq[q][2 * hf] *= s_2; hq[q][2 * hf + 1] *= s_2;
           if (hf == 1 && !(ABL & 2)) {
             float* p = stash_w + (long)u * 8192;
-            *reinterpret_cast<f32x4*>(p + (2 * q) * 256) = s1q;
-            *reinterpret_cast<f32x4*>(p + (2 * q + 1) * 256) = s2q;
+            // non-temporal, like the backward's loads of it: the stash is written once and read once a whole pass later; keeping it
+            // out of the L2's way measured +1.2 % (stores) and +1.3 % (loads, which are prefetched three slabs ahead) END TO END.
+            // (The same hint on the kernels' outputs or on their exposed epilogue loads measured -1.2 ... -3.3 %: those are consumed
+            // within microseconds / sit on the critical path.)
+            __builtin_nontemporal_store(s1q, reinterpret_cast<f32x4*>(p + (2 * q) * 256));
+            __builtin_nontemporal_store(s2q, reinterpret_cast<f32x4*>(p + (2 * q + 1) * 256));
           }
         }
       }
