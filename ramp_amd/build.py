@@ -28,18 +28,33 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(LIBDIR, exist_ok=True)
+def header_deps():
+    """Every shared header / include file a translation unit may pull in (csrc/*.h, csrc/*.inc, the public header) plus this
+    script (its flags): a change to any of them makes every object stale."""
+    import glob
+    hs = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")))
+    return hs + [os.path.join(HERE, "..", "include", "ramp_hip.h"), os.path.abspath(__file__)]
+
+
+def stale_sources(force: bool = False):
+    """(source, object) pairs that build() would recompile now."""
     objdir = os.path.join(LIBDIR, "obj")
-    os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_x6p_body.inc"), os.path.join(HERE, "..", "include", "ramp_hip.h"), os.path.abspath(__file__)]
+    headers = header_deps()
     jobs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(op, [sp] + headers):
             jobs.append((sp, op))
+    return jobs
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = stale_sources(force)
 
     def compile_one(job):
         sp, op = job

@@ -30,6 +30,16 @@ const char* last_error_cstr();
     }                                                                                 \
   } while (0)
 
+// [a, a + na) and [b, b + nb) share a byte (null operands never overlap anything)
+inline bool ranges_overlap(const void* a, size_t na, const void* b, size_t nb) {
+  if (!a || !b || !na || !nb) return false;
+  const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+  return x < y + nb && y < x + na;
+}
+// compute units of the current device (hipDeviceProp_t::multiProcessorCount, cached per device): the token-owning kernels
+// launch one 4-wave block per CU
+int device_cu_count();
+
 // ---- GEMM -----------------------------------------------------------------------------------
 // C[m, n] = sum_{tap<taps} sum_{k<K} Asrc(m + shift0 + tap*shift_step)[k] * W[tap][n][k]
 //           (+ bias[n]) (+ rowbias[rowvar[row0 + m / L]][n]) (+ resid[m, n]) (+ resid2[m, n])

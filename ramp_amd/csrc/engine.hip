@@ -24,6 +24,16 @@ namespace ramp {
 
 static thread_local std::string g_err;
 void set_last_error(const std::string& msg) { g_err = msg; }
+int device_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cached[dev]) {
+    hipDeviceProp_t p;
+    cached[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }
+  return cached[dev];
+}
 const char* last_error_cstr() { return g_err.c_str(); }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,16 +429,27 @@ struct Run {
   }
   // a K = 256 linear on the token-owning kernel (tkl.hip), optionally with LayerNorm folded into its operand; consumes the
   // call site of the tile-kernel launch it replaces (same operand, same maxima)
+  // the weight W [N][K] carries fragment-packed fp16 planes (what prep() would attach in an fp16x3 evaluation): a weight without
+  // them keeps its launch on the tile kernels instead of failing inside the token-owning wrapper
+  bool has_h3(const float* W, int N, int K) const {
+    auto it = c->x6.upper_bound(W);
+    if (it == c->x6.begin()) return false;
+    --it;
+    const auto& e = it->second;
+    if (!(W >= it->first && W < it->first + e.n)) return false;
+    const size_t off = W - it->first;
+    return c->x6_pipe && e.packed && e.packed3 && e.K == K && off % (32ul * K) == 0 && N % 32 == 0;
+  }
   bool use_tkl(const GemmArgs& a) const {
     return c->tkl_min_rows > 0 && a.M >= c->tkl_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe && a.K == 256 && a.lda == 256 &&
-           a.taps == 1 && a.N % 32 == 0 && a.N <= 768 && !a.A2 && !a.Amul && !a.resid2 && !a.C2 && a.epi == EPI_LINEAR;
+           a.taps == 1 && a.N % 32 == 0 && a.N <= 768 && !a.A2 && !a.Amul && !a.resid2 && !a.C2 && a.epi == EPI_LINEAR && has_h3(a.W, a.N, a.K);
   }
   int tkl(const GemmArgs& a, const float* ln_g, const float* ln_b) {
-    prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K, {a.M, a.N, a.K, ln_g ? -1 : 1});
     GemmArgs b = a;
     const int kind = prep(b);
     if (kind < 0) return kind;
-    RAMP_REQUIRE(kind == 2, "tkl: weight without fp16 fragment planes");
+    RAMP_REQUIRE(kind == 2, "tkl: weight without fp16 fragment planes (use_tkl must have been checked)");
+    prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K, {a.M, a.N, a.K, ln_g ? -1 : 1});
     TklArgs t; t.M = a.M; t.N = a.N; t.X = a.A; t.Y = a.C; t.ldy = a.ldc; t.W = b.Wx; t.bias = a.bias; t.resid = a.resid; t.ldr = a.ldr;
     t.rowbias = a.rowbias; t.rowvar = a.rowvar; t.row0 = a.row0; t.rb_stride = a.rb_stride; t.L = a.L; t.n_var = a.rowbias ? c->n_variants : 0;
     t.ln_g = ln_g; t.ln_b = ln_b; t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.wsi = b.w_scale_inv; t.site = b.site_id;
@@ -440,15 +461,15 @@ struct Run {
   }
   // d(ln1) = d(qkv) Wqkv^T and the LayerNorm-1 backward behind it in one token-owning launch (tkl.hip, tklb_kernel); consumes
   // the call site of the d(ln1) GEMM it replaces
-  bool use_tklb(int M) const {
-    return !c->tklb_off && c->tkl_min_rows > 0 && M >= c->tkl_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe;
+  bool use_tklb(int M, const float* W) const {
+    return !c->tklb_off && c->tkl_min_rows > 0 && M >= c->tkl_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe && has_h3(W, 256, 768);
   }
   int tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, float* out, int M) {
-    prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 768, {M, 256, 768, -1});
     GemmArgs b; b.A = dqkv; b.lda = 768; b.W = W; b.C = out; b.ldc = 256; b.M = M; b.N = 256; b.K = 768; b.taps = 1; b.L = 1;
     const int kind = prep(b);
     if (kind < 0) return kind;
-    RAMP_REQUIRE(kind == 2, "tklb: weight without fp16 fragment planes");
+    RAMP_REQUIRE(kind == 2, "tklb: weight without fp16 fragment planes (use_tklb must have been checked)");
+    prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 768, {M, 256, 768, -1});
     TklbArgs t; t.M = M; t.X = dqkv; t.Z = z; t.add = add; t.Y = out; t.W = b.Wx; t.ln_g = ln_g;
     t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.wsi = b.w_scale_inv; t.site = b.site_id; t.range_flag = b.range_flag;
     int rc = launch_tklb(t, s);
@@ -662,7 +683,7 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx, int s
       if (r.use_tkl(o)) CK(r.tkl(o, nullptr, nullptr)); else CK(r.gemm(o));
     }
     LAUNCH(c, r.s, CAT_ATTN, 32.0 * Rb * m.L * m.L * 64, launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, Rb, m.L, r.s));
-    if (r.use_tklb(Mb)) {      // d(ln1) and the LayerNorm-1 backward in one token-owning launch: dz = dz1 + LN1bwd(d(qkv) Wqkv^T)
+    if (r.use_tklb(Mb, k.wqkv_b)) {      // d(ln1) and the LayerNorm-1 backward in one token-owning launch: dz = dz1 + LN1bwd(d(qkv) Wqkv^T)
       CK(r.tklb(c->t_dqkv, k.wqkv_b, zin, k.ln1_g, dz1, dz, Mb));
     } else {
       CK(r.gemm(lin(c->t_dqkv, 768, k.wqkv_b, nullptr, c->t_dln, D, Mb, D, 768)));        // d(ln1)
@@ -1009,7 +1030,15 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
     if (te) c->three_blocks = te[0] != '0';
     c->prof_dump = getenv("RAMP_PROFILE_DUMP") != nullptr;
     const char* ae = getenv("RAMP_FFX_ABLATE");              // diagnostic A/B of the fused feed-forward inside a whole job
-    if (ae) c->ffx_ablate = atoi(ae);
+    if (ae) {   // only the variants that compute the SAME result may ride a product launch (16: LayerNorm tables from LDS, 32: no
+                // bounding wait at the tile switch, 48: both); the result-changing twins (1, 2, 4, 8, ...) stay in ramp_bench_gemm
+      const int av = atoi(ae);
+      if (!(av == 0 || av == 16 || av == 32 || av == 48)) {
+        delete c;
+        RAMP_REQUIRE(false, "RAMP_FFX_ABLATE accepts 0, 16, 32 or 48 (result-preserving variants) on a context; the others change results and exist in ramp_bench_gemm only");
+      }
+      c->ffx_ablate = av;
+    }
     c->tklb_off = getenv("RAMP_TKLB_OFF") != nullptr;       // diagnostic: d(ln1) + LN1 backward on the tile kernel + ln_bwd pair
   }
   *out = c;

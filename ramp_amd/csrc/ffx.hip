@@ -604,8 +604,12 @@ int launch_ffx(const FfxArgs& f, bool bwd, hipStream_t s) {
   RAMP_REQUIRE(f.M > 0 && f.X && f.Y && f.Z1 && f.stash && f.Wstream && f.ln_g && (bwd || (f.ln_b && f.b1 && f.b2)), "ffx: null operand");
   RAMP_REQUIRE(al16(f.X) && al16(f.Y) && al16(f.Z1) && al16(f.stash) && al16(f.Wstream) && al16(f.ln_g) && al16(f.ln_b) &&
                al16(f.b1) && al16(f.b2), "ffx: operands must be 16-byte aligned");
+  {   // rows past M are recomputed and rewritten from the inputs (unconditional stores): the output may alias none of them
+    const size_t yb = (size_t)f.M * 256 * 4;
+    RAMP_REQUIRE(!ranges_overlap(f.Y, yb, f.X, yb) && !ranges_overlap(f.Y, yb, f.Z1, yb), "ffx: the output must not overlap X or z1 (no in-place use)");
+  }
   const int n_mt = (f.M + 127) / 128;
-  const int nb = std::min(n_mt, 256);                        // one 4-wave block per CU
+  const int nb = std::min(n_mt, device_cu_count());          // one 4-wave block per CU
 #define FX_GO(B, A) hipLaunchKernelGGL((ffx_kernel<B, A>), dim3(nb), dim3(256), FX_LDS, s, f, n_mt)
   if (f.ablate == 0) { if (bwd) FX_GO(true, 0); else FX_GO(false, 0); }
   else if (f.ablate == 1) { if (bwd) FX_GO(true, 1); else FX_GO(false, 1); }

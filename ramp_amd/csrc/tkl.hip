@@ -495,8 +495,13 @@ int launch_tklb(const TklbArgs& a, hipStream_t s) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   RAMP_REQUIRE(a.M > 0 && a.X && a.Z && a.add && a.Y && a.W && a.ln_g, "tklb: null operand");
   RAMP_REQUIRE(al16(a.X) && al16(a.Z) && al16(a.add) && al16(a.Y) && al16(a.W), "tklb: operands must be 16-byte aligned");
+  {   // rows past M are recomputed and rewritten from the inputs (unconditional stores): the output may alias none of them
+    const size_t yb = (size_t)a.M * 256 * 4;
+    RAMP_REQUIRE(!ranges_overlap(a.Y, yb, a.X, (size_t)a.M * 768 * 4) && !ranges_overlap(a.Y, yb, a.Z, yb) && !ranges_overlap(a.Y, yb, a.add, yb),
+                 "tklb: the output must not overlap d(qkv), z or the bypassing gradient (no in-place use)");
+  }
   const int n_mt = (a.M + 127) / 128;
-  hipLaunchKernelGGL(tklb_kernel, dim3(std::min(n_mt, 256)), dim3(256), TK_LDS, s, a, n_mt);
+  hipLaunchKernelGGL(tklb_kernel, dim3(std::min(n_mt, device_cu_count())), dim3(256), TK_LDS, s, a, n_mt);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -507,8 +512,14 @@ int launch_tkl(const TklArgs& a, hipStream_t s) {
   RAMP_REQUIRE(al16(a.X) && al16(a.Y) && al16(a.W) && al16(a.resid) && a.ldy % 4 == 0 && a.ldr % 4 == 0, "tkl: operands must be 16-byte aligned");
   RAMP_REQUIRE(!a.rowbias || (a.rowvar && a.N == 256 && a.n_var >= 1 && a.n_var <= 4 && a.L >= 1 && a.resid), "tkl: row-variant bias needs N = 256, <= 4 variants, a residual");
   RAMP_REQUIRE(!a.ln_g == !a.ln_b, "tkl: LayerNorm needs gamma and beta");
+  {   // rows past M are recomputed and rewritten from the inputs (unconditional stores): an in-place residual (Y == resid) would add
+      // the last row's update twice when M is not a multiple of 128
+    const size_t yb = ((size_t)(a.M - 1) * a.ldy + a.N) * 4;
+    RAMP_REQUIRE(!ranges_overlap(a.Y, yb, a.X, (size_t)a.M * 256 * 4) && !ranges_overlap(a.Y, yb, a.resid, a.resid ? ((size_t)(a.M - 1) * a.ldr + a.N) * 4 : 0),
+                 "tkl: the output must not overlap the operand or the residual (no in-place use)");
+  }
   const int n_mt = (a.M + 127) / 128;
-  const int nb = std::min(n_mt, 256);                        // one 4-wave block per CU
+  const int nb = std::min(n_mt, device_cu_count());          // one 4-wave block per CU
   const bool ln = a.ln_g != nullptr;
   const int epi = (a.resid ? 1 : 0) | (a.rowbias ? 2 : 0);
 #define TK_GO(LNV, E, A) hipLaunchKernelGGL((tkl_kernel<LNV, E, A>), dim3(nb), dim3(256), TK_LDS, s, a, n_mt)

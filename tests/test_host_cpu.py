@@ -264,3 +264,27 @@ def test_token_owning_kernels_do_not_spill():
     for d in (ffx, tkl):
         for k, v in d.items():
             assert v["vgpr_count"] <= 512, (k, v)
+
+
+def test_touching_a_shared_header_marks_its_objects_stale():
+    """build(force=False) must recompile when ANY shared header changes (round-3 review: tokmma.h was missing from the
+    dependency list, so an edit of the token-owning kernels' helpers left ffx.o / tkl.o stale)."""
+    from ramp_amd import build as B
+    deps = [os.path.basename(p) for p in B.header_deps()]
+    for h in ("common.h", "tokmma.h", "gemm_x6p_body.inc", "ramp_hip.h", "build.py"):
+        assert h in deps, (h, deps)
+    csrc = os.path.join(ROOT, "ramp_amd", "csrc")
+    on_disk = {f for f in os.listdir(csrc) if f.endswith((".h", ".inc"))}
+    assert on_disk <= set(deps), on_disk - set(deps)
+    B.build(force=False, verbose=False)                     # everything current first
+    assert B.stale_sources() == []
+    hdr = os.path.join(csrc, "tokmma.h")
+    st = os.stat(hdr)
+    try:
+        newest = max(os.path.getmtime(op) for _, op in B.stale_sources(force=True))
+        os.utime(hdr, (newest + 10, newest + 10))           # "edited after the last build"
+        stale = {os.path.basename(sp) for sp, _ in B.stale_sources()}
+        assert {"ffx.hip", "tkl.hip"} <= stale, stale
+    finally:
+        os.utime(hdr, (st.st_atime, st.st_mtime))
+    assert B.stale_sources() == []
