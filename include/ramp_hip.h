@@ -153,13 +153,27 @@ typedef struct ramp_sample_params {
   ramp_apf_params apf;
   int32_t use_graph;             /* 1: capture the whole loop in a hipGraph and replay it */
   int32_t reserved;
+  /* noise_mode 0: the caller injects the noise (the `noise` argument; the parity runs and every torch.randn-compatible
+   * caller).  noise_mode 1: the job draws its own N(0, I) INSIDE the captured graph -- counter-based Philox4x32-10 +
+   * Box-Muller (ramp_philox_normal below), element i of the job's (n_steps+1, B, H, S) noise block = element i of the
+   * stream (philox_seed, philox_offset); `noise` may be NULL.  Seed and offset sit in a device record the graph reads,
+   * so every replay draws fresh numbers without re-capturing. */
+  int32_t noise_mode;
+  int32_t reserved2;
+  uint64_t philox_seed;
+  uint64_t philox_offset;        /* in groups of four elements */
 } ramp_sample_params;
 
 /* noise: device (n_steps+1, B, H, S) for DDPM — noise[0] = x_T, noise[1+j] the randn_like of
- * iteration j; for DDIM only noise[0] is read.  chain_out: device (n_steps+1, B, H, S) or NULL.
+ * iteration j; for DDIM only noise[0] is read (NULL with noise_mode 1).  chain_out: device (n_steps+1, B, H, S) or NULL.
  * x_out: device (B,H,S) final trajectories or NULL. */
 int ramp_sample(ramp_ctx* ctx, const ramp_sample_params* p, const float* noise, float* chain_out,
                 float* x_out, void* stream);
+/* torch.randn stand-in of the throughput jobs (sample_functions.py:36; diffusion_model_static.py:239): out[0..n) ~ N(0, 1),
+ * element 4 g + j = output j of philox4x32_10(counter = (lo32(g + offset), hi32(g + offset), 0, 0), key = (lo32(seed),
+ * hi32(seed))) through Box-Muller: u = ((r >> 9) + 0.5) 2^-23, (z0, z1) = sqrt(-2 ln u0) (cos, sin)(2 pi u1), (z2, z3) from
+ * (u2, u3).  Host-replicable from (seed, offset); `out` device, 16-byte aligned. */
+int ramp_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 
 /* ---- receding-horizon replanning: DynamicGaussianDiffusionModel.ddim_p_sample_loop, STAGE II
  *      (diffusion_model_dynamic.py:533-612) ----

@@ -41,7 +41,8 @@ class RampSampleParams(C.Structure):
                 ("sqrt_1m_a_t", c_f32p), ("sqrt_a_prev", c_f32p), ("dir_coef", c_f32p), ("apply_apf", c_i32p),
                 ("noise_scale", c_f32p), ("clip_denoised", C.c_int32), ("reserved0", C.c_int32),
                 ("n_hard", C.c_int32), ("hard_idx_host", c_i32p), ("hard_val", C.c_void_p),
-                ("apf", RampApfParams), ("use_graph", C.c_int32), ("reserved", C.c_int32)]
+                ("apf", RampApfParams), ("use_graph", C.c_int32), ("reserved", C.c_int32),
+                ("noise_mode", C.c_int32), ("reserved2", C.c_int32), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64)]
 
 
 class RampReplanParams(C.Structure):
@@ -86,6 +87,7 @@ PROTOTYPES = {
     "ramp_score_mode": (C.c_int, [C.c_void_p, c_i32p]),
     "ramp_sample": (C.c_int, [C.c_void_p, C.POINTER(RampSampleParams), C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p]),
+    "ramp_philox_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "ramp_replan": (C.c_int, [C.c_void_p, C.POINTER(RampReplanParams), C.POINTER(RampReplanState), C.c_void_p, C.c_void_p,
                               C.c_void_p, C.POINTER(RampReplanResult), C.c_void_p]),
     "ramp_select_best": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float,

@@ -241,6 +241,8 @@ int launch_ddpm_finish(const float* mean, const float* noise, float stdv, float 
 int launch_ddim_finish(const float* x_in, const float* x0, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
                        float dir_coef, HardConds hc, float* x, float* chain_out, int B, int H, int S, hipStream_t s);
 int launch_hard_cond(float* x, HardConds hc, int B, int H, int S, hipStream_t s);
+// out[0..n) ~ N(0, 1): Philox4x32-10 + Box-Muller, rec = device {seed, offset in groups of four elements} (sampler.hip)
+int launch_philox_normal(float* out, long n, const unsigned long long* rec, hipStream_t s);
 
 struct ApfArgs {
   float* traj = nullptr;        // (B,H,S) modified in place (xy channels only)

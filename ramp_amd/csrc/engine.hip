@@ -162,6 +162,7 @@ struct ramp_ctx {
   // sampler state
   float *s_x = nullptr, *s_eps = nullptr, *s_mean = nullptr, *s_x0 = nullptr, *s_noise = nullptr, *s_chain = nullptr;
   size_t s_cap_B = 0, s_cap_rows = 0, s_noise_cap = 0, s_chain_cap = 0;
+  unsigned long long* s_philox = nullptr;      // device {seed, offset} of a job that draws its own noise (ramp_sample_params.noise_mode 1)
   int* s_hard_idx = nullptr; float* s_hard_val = nullptr; size_t s_hard_val_cap = 0; float* s_window = nullptr;
   float* s_cloud = nullptr; size_t s_cloud_cap = 0;
   // graph cache
@@ -1409,6 +1410,9 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
   const int B = p->B, H = c->cfg.horizon, S = c->cfg.state_dim;
   const size_t HS = (size_t)H * S, n = (size_t)B * HS;
   HardConds hc; hc.idx = c->s_hard_idx; hc.val = c->s_hard_val; hc.n = p->n_hard;
+  // noise_mode 1: the job's whole noise block is drawn here, inside the (captured) job, from the device record {seed, offset}
+  if (p->noise_mode == 1)
+    LAUNCH(c, s, CAT_SAMPLER, 0, launch_philox_normal(c->s_noise, (long)((p->ddim ? 1 : (size_t)p->n_steps + 1) * n), c->s_philox, s));
   // x_T = noise[0]; apply_hard_conditioning; chain[0]
   RAMP_HIP_CHECK(hipMemcpyAsync(c->s_x, c->s_noise, n * 4, hipMemcpyDeviceToDevice, s));
   LAUNCH(c, s, CAT_SAMPLER, 0, launch_hard_cond(c->s_x, hc, B, H, S, s));
@@ -1466,9 +1470,25 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
   return 0;
 }
 
+int ramp_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  RAMP_REQUIRE(out && n > 0, "null argument");
+  hipStream_t s = as_stream(stream);
+  unsigned long long* rec = nullptr;
+  RAMP_HIP_CHECK(hipMalloc(&rec, 16));
+  const unsigned long long h[2] = {seed, offset};
+  hipError_t e = hipMemcpyAsync(rec, h, 16, hipMemcpyHostToDevice, s);
+  int rc = e == hipSuccess ? launch_philox_normal(out, (long)n, rec, s) : -1;
+  if (e != hipSuccess) set_last_error(std::string("hipMemcpyAsync failed: ") + hipGetErrorString(e));
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(rec);
+  return rc;
+}
+
 int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, float* chain_out, float* x_out,
                 void* stream) {
-  RAMP_REQUIRE(c && p && noise, "null argument");
+  RAMP_REQUIRE(c && p, "null argument");
+  RAMP_REQUIRE(p->noise_mode == 0 || p->noise_mode == 1, "noise_mode must be 0 (injected) or 1 (Philox inside the job)");
+  RAMP_REQUIRE(noise || p->noise_mode == 1, "null noise (only a job that draws its own, noise_mode 1, may omit it)");
   RAMP_REQUIRE(p->B > 0 && p->n_steps > 0 && p->n_rp >= 1 && p->n_rp <= 3, "bad sample dims");
   RAMP_REQUIRE(p->t && p->sqrt_recip && p->sqrt_recipm1, "missing schedule arrays");
   if (p->ddim) RAMP_REQUIRE(p->sqrt_a_t && p->sqrt_1m_a_t && p->sqrt_a_prev && p->dir_coef, "missing DDIM arrays");
@@ -1498,7 +1518,13 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
     RAMP_HIP_CHECK(hipMemcpyAsync(c->s_hard_idx, p->hard_idx_host, p->n_hard * 4, hipMemcpyHostToDevice, s));
     RAMP_HIP_CHECK(hipMemcpyAsync(c->s_hard_val, p->hard_val, hv * 4, hipMemcpyDeviceToDevice, s));
   }
-  RAMP_HIP_CHECK(hipMemcpyAsync(c->s_noise, noise, n_noise * 4, hipMemcpyDeviceToDevice, s));
+  if (p->noise_mode == 1) {
+    if (!c->s_philox) { float* q; CK(dev_alloc(c, &q, 4)); c->s_philox = reinterpret_cast<unsigned long long*>(q); }
+    const unsigned long long rec[2] = {p->philox_seed, p->philox_offset};
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->s_philox, rec, 16, hipMemcpyHostToDevice, s));     // (pageable host memory: the copy is staged before the call returns)
+  } else {
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->s_noise, noise, n_noise * 4, hipMemcpyDeviceToDevice, s));
+  }
   c->launches = 0;
   c->score_calibrated = false; c->r_calibrated = false;      // the loop below overwrites the delayed-scaling tables
   // key: everything baked into the captured nodes (and what a kept calibration belongs to)
@@ -1515,7 +1541,7 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
     put(&p->clip_denoised, 4); put(&p->n_hard, 4);
     const int has_apf = p->apf.cloud != nullptr; put(&has_apf, 4);
     put(&p->apf.n_points, 4); put(&p->apf.window, 4); put(&p->apf.threshold, 8); put(&p->apf.strength, 8); put(&p->apf.passes, 4);
-    const int ch = chain; put(&ch, 4); put(&c->force_x6, 4);
+    const int ch = chain; put(&ch, 4); put(&c->force_x6, 4); put(&p->noise_mode, 4);
   }
   const bool h3 = c->gemm_mode == 2 && !c->force_x6;
   steady = h3 && c->cal_reuse && c->s_calibrated && c->s_cal_key == key;

@@ -13,6 +13,8 @@
 // changes a rounding (the x0 clamp makes borderline elements sensitive to single ulps).
 #include "common.h"
 
+#include <algorithm>
+
 namespace ramp {
 
 __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
@@ -526,6 +528,53 @@ int launch_traj_costs(const float* traj, const float* cloud, int B, int H, int S
                       float* plen, float* smooth, hipStream_t s) {
   RAMP_REQUIRE(B > 0 && H > 1 && H <= APF_MAXH && S >= 2 && P > 0, "bad cost dims");
   hipLaunchKernelGGL(traj_costs_kernel, dim3(B), dim3(256), 0, s, traj, cloud, H, S, P, thr, mask, plen, smooth);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- Gaussian noise inside the job: counter-based Philox4x32-10 (Salmon et al., SC'11) + Box-Muller --------------------------
+// The reference draws torch.randn on the host stream (sample_functions.py:36, diffusion_model_static.py:239); a throughput job
+// draws the same N(0, I) inside its captured graph instead.  Element 4 g + j of the stream is output j of
+// philox4x32_10(counter = (lo32(g + offset), hi32(g + offset), 0, 0), key = (lo32(seed), hi32(seed))) turned into a normal:
+// u = ((r >> 9) + 0.5) * 2^-23 in (0, 1) (exact in fp32); (z0, z1) = sqrt(-2 ln u0) * (cos, sin)(2 pi u1), (z2, z3) likewise from (u2, u3).
+// Host-replicable from (seed, offset) alone (tests/util.py restates it in numpy); seed / offset live in a 16-byte device
+// record so that a captured graph draws fresh noise on every replay.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, long n, const unsigned long long* __restrict__ rec) {
+  const unsigned long long seed = rec[0], offset = rec[1];
+  const long n_grp = (n + 3) >> 2;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n_grp; g += (long)gridDim.x * 256) {
+    const unsigned long long ctr = (unsigned long long)g + offset;
+    unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u0 = ((float)(c[2 * h] >> 9) + 0.5f) * 1.1920928955078125e-7f;
+      const float u1 = ((float)(c[2 * h + 1] >> 9) + 0.5f) * 1.1920928955078125e-7f;
+      const float rad = sqrtf(-2.f * logf(u0));
+      float sn, cs;
+      sincosf(6.283185307179586f * u1, &sn, &cs);
+      z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+    }
+    const long e = g << 2;
+    if (e + 3 < n) *reinterpret_cast<float4*>(out + e) = make_float4(z[0], z[1], z[2], z[3]);
+    else for (int j = 0; j < 4 && e + j < n; ++j) out[e + j] = z[j];
+  }
+}
+int launch_philox_normal(float* out, long n, const unsigned long long* rec, hipStream_t s) {
+  RAMP_REQUIRE(out && rec && n > 0, "philox: null operand");
+  RAMP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "philox: output must be 16-byte aligned");
+  const long n_grp = (n + 3) >> 2;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)std::min<long>((n_grp + 255) / 256, 8192)), dim3(256), 0, s, out, n, rec);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }

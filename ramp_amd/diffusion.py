@@ -69,10 +69,20 @@ class _GaussianDiffusionBase(nn.Module):
     def __init__(self, model=None, variance_schedule='exponential', n_diffusion_steps=100, clip_denoised=True,
                  predict_epsilon=False, loss_type='l2', context_model=None, compose=False, use_apf=False,
                  training=False, sampler: Optional[str] = None, cfg_weight: Optional[float] = None,
-                 compose_weights=None, use_graph: bool = True, fp16_fallback: bool = True, **kwargs):
+                 compose_weights=None, use_graph: bool = True, fp16_fallback: bool = True, noise_source: str = "torch",
+                 noise_seed: int = 0, **kwargs):
         super().__init__()
         self.model = model
         self.fp16_fallback = fp16_fallback      # fp16x3 range guard tripped -> repeat the job in bf16x6 (else raise)
+        self.range_fallbacks = 0                # jobs / replans the fp16x3 range guard sent to the bf16x6 kernels so far
+        # "torch": the reference's torch.randn / randn_like draws (sample_functions.py:36; what the parity runs patch);
+        # "philox": the job draws its noise INSIDE the captured graph (ramp_sample_params.noise_mode 1), stream
+        # (noise_seed, running offset) -- host-replicable through ramp_philox_normal / tests.util.philox_normal
+        if noise_source not in ("torch", "philox"):
+            raise ValueError("noise_source must be 'torch' or 'philox'")
+        self.noise_source = noise_source
+        self.noise_seed = int(noise_seed)
+        self._philox_offset = 0                 # groups of four elements consumed so far
         self.context_model = context_model
         self.n_diffusion_steps = n_diffusion_steps
         self.ddim_num_inference_steps = 8 if (compose and use_apf) else 5      # diffusion_model_static.py:40
@@ -132,8 +142,15 @@ class _GaussianDiffusionBase(nn.Module):
         """network-row -> scene-variant pattern (variant 1 = unconditional); rows are [b*n_rp + v]."""
         return [0, 1]
 
+    def invalidate_scene(self):
+        """See ``TemporalUnetInference.invalidate_scene``: call after modifying a cloud tensor in a way autograd's version
+        counter does not see."""
+        self.model.invalidate_scene()
+
     def _prepare_scene(self, obstacle_pts: torch.Tensor, B=None):
-        """Encode the distinct scene(s) once and hand the variants to the context."""
+        """Encode the distinct scene(s) once and hand the variants to the context.  Cache contract: a cloud is re-encoded when
+        its content differs from the last one's (``torch.equal`` against a kept clone); the comparison is skipped only for the
+        same tensor OBJECT with the same ``_version`` -- writes that bypass the version counter need ``invalidate_scene()``."""
         m = self.model
         dev = self._device()
         zero = torch.zeros(1, m.context_dim, device=dev)
@@ -260,7 +277,13 @@ class _GaussianDiffusionBase(nn.Module):
         p.use_graph = int(self.use_graph)
         chain = torch.empty((n_steps + 1, B, H, S), device=dev, dtype=torch.float32) if return_chain else None
         x_out = torch.empty((B, H, S), device=dev, dtype=torch.float32)
-        noise = noise.contiguous()
+        if noise is None:          # the job draws its own: the next (n_steps + 1 | 1) * B * H * S elements of the Philox stream
+            n_el = (1 if ddim else n_steps + 1) * B * H * S
+            p.noise_mode, p.philox_seed, p.philox_offset = 1, self.noise_seed, self._philox_offset
+            self.last_philox = (self.noise_seed, self._philox_offset, n_el)
+            self._philox_offset += (n_el + 3) // 4
+        else:
+            noise = noise.contiguous()
         with torch.cuda.device(dev):
             lib = _lib.load()
             _lib.check(lib.ramp_sample(m.ctx(), C.byref(p), _lib.ptr(noise), _lib.ptr(chain), _lib.ptr(x_out),
@@ -274,6 +297,7 @@ class _GaussianDiffusionBase(nn.Module):
                     raise _lib.RampHipError("fp16x3 GEMM: an operand left the fp16 range between two score evaluations "
                                             f"(call site {flag.value - 1}); use gemm_mode='bf16x6'")
                 warnings.warn(f"fp16x3 range guard tripped at GEMM call site {flag.value - 1}: repeating the job in bf16x6")
+                self.range_fallbacks += 1
                 _lib.check(lib.ramp_set_fallback(m.ctx(), 1), "ramp_set_fallback")
                 try:
                     _lib.check(lib.ramp_sample(m.ctx(), C.byref(p), _lib.ptr(noise), _lib.ptr(chain), _lib.ptr(x_out),
@@ -290,20 +314,22 @@ class _GaussianDiffusionBase(nn.Module):
         """diffusion_model_static.py:232-256 / diffusion_model_3d.py:185-218 (resample_steps = 1)."""
         device = self._device()
         B = shape[0]
-        x = torch.randn(shape, device=device)
+        philox = self.noise_source == "philox"
+        x = None if philox else torch.randn(shape, device=device)
         noises = [x]
         steps, scales = [], []
         for i in reversed(range(-n_diffusion_steps_without_noise, self.n_diffusion_steps)):
             t = max(i, 0)                                           # sample_functions.py:25-27
             steps.append(t)
-            noises.append(torch.randn_like(x))                      # drawn every step, zeroed at t == 0
+            if not philox:
+                noises.append(torch.randn_like(x))                  # drawn every step, zeroed at t == 0
             scales.append(1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(i)))
         # compose: ddpm_sample_fn calls p_mean_variance_compose, which has no APF hook (static.py:188-229)
         apf = [1 if (self.APF and self._supports_apf and not self.compose and j > self.apf_ddpm['after']) else 0
                for j in range(len(steps))]
         cfg = dict(self.apf_ddpm, passes=1) if any(apf) else None
-        x_out, chain = self._launch(B, torch.stack(noises), hard_conds, obstacle_pts, False, steps, apf, scales, cfg,
-                                    return_chain)
+        x_out, chain = self._launch(B, None if philox else torch.stack(noises), hard_conds, obstacle_pts, False, steps, apf, scales,
+                                    cfg, return_chain)
         if return_chain:
             return x_out, chain.permute(1, 0, 2, 3)       # reference stacks along dim=1
         return x_out
@@ -320,11 +346,11 @@ class _GaussianDiffusionBase(nn.Module):
         """diffusion_model_static.py:347-384 (eta = 0, use_clipped_model_output)."""
         device = self._device()
         B = shape[0]
-        x = torch.randn(shape, device=device)
+        x = None if self.noise_source == "philox" else torch.randn(shape, device=device)
         steps = [int(i) for i in self.ddim_set_timesteps(self.ddim_num_inference_steps)]
         apf = [1 if (self.APF and self._supports_apf and j >= self.apf_ddim['start']) else 0 for j in range(len(steps))]
         cfg = dict(self.apf_ddim) if any(apf) else None
-        x_out, chain = self._launch(B, x.unsqueeze(0), hard_conds, obstacle_pts, True, steps, apf, None, cfg,
+        x_out, chain = self._launch(B, None if x is None else x.unsqueeze(0), hard_conds, obstacle_pts, True, steps, apf, None, cfg,
                                     return_chain)
         if return_chain:
             return x_out, chain.permute(1, 0, 2, 3)
@@ -722,6 +748,7 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
                                            _lib.ptr(mask) if (log is not None or sharded) else None, C.byref(res), _lib.current_stream()),
                            "ramp_replan")
             if res.fell_back:
+                self.range_fallbacks += 1
                 warnings.warn(f"fp16x3 range guard tripped at GEMM call site {res.fell_back - 1}: replan repeated in bf16x6")
             if log is not None:
                 log.append(dict(batch=batch.clone(), npts=cost_cloud.shape[0] + (64 if near else 0),
@@ -737,18 +764,27 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
             if n_free_all == 0:
                 # no candidate survived: the reference re-plans from scratch until one does (:591-605), eager path
                 from .cost import compute_trajectory_costs
-                xs = None
-                while xs is None:
+                # Sharded: the ranks re-plan round by round in LOCK-STEP (every rank draws the same number of torch / numpy random
+                # numbers, so their pursuer clouds stay identical afterwards, and nobody waits in a collective while another rank
+                # is still looping); after each round the lowest rank that found a collision-free plan broadcasts it.
+                while True:
                     nb = min(30, B)
                     new_hc = {kk: v[:nb].clone() for kk, v in hard_conds.items()}
                     xs = self.ddim_replan_scratch((nb, H, S), new_hc, context, traj_normalized, forward_t=k,
                                                   obstacle_pts=cloud, use_apf=False, executed_history=executed_history)
                     xs[:, stepp + 1:stepp + 3] = self.sm(xs[:, stepp], xs[:, stepp + 2], num_steps=2)
                     xs, _, _, _, _ = compute_trajectory_costs(xs, cost_cloud, collision_threshold=thr_low)
-                xs = xs.clone(); xs[0, 2:] = 0.0
-                best.copy_(xs)
-                if sharded:
-                    tdist.broadcast(best, src=0)                   # every rank re-planned on its own noise: rank 0's plan is executed
+                    if xs is not None:
+                        xs = xs.clone(); xs[0, 2:] = 0.0
+                        best.copy_(xs)
+                    if not sharded:
+                        if xs is not None:
+                            break
+                        continue
+                    src = rdist.lowest_rank_with(xs is not None, device)
+                    if src >= 0:
+                        tdist.broadcast(best, src=src)
+                        break
             x_cur = best.clone()
             best_host = x_cur.cpu().numpy()
             x_clean = x_cur

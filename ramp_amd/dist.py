@@ -135,12 +135,26 @@ def select_best_sharded(batch_local: torch.Tensor, mask_local: torch.Tensor, ple
     owner, start = 0, 0
     while row >= start + counts[owner]:
         start += counts[owner]; owner += 1
-    best = batch_local[row - start].clone() if owner == rank else torch.empty_like(batch_local[0])
+    # (the receive buffer is shaped from (H, S) and the dtype, not from batch_local[0]: a rank may hold no candidate at all)
+    best = batch_local[row - start].clone() if owner == rank else torch.empty(tuple(batch_local.shape[1:]), dtype=batch_local.dtype,
+                                                                                  device=batch_local.device)
     if sharded:
         dist.broadcast(best, src=owner)
     if zero_start:
         best[0, 2:] = 0.0                                     # diffusion_model_dynamic.py:607
     return best, int(n_free), int(row)
+
+
+def lowest_rank_with(flag: bool, device) -> int:
+    """The lowest rank whose `flag` is set, or -1 when no rank's is (one MIN all-reduce of a rank number); without a process
+    group: 0 / -1.  Used by the sharded planner's lock-step scratch re-plan."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return 0 if flag else -1
+    world = dist.get_world_size()
+    t = torch.tensor([dist.get_rank() if flag else world], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    v = int(t.item())
+    return v if v < world else -1
 
 
 def _select_hip(mask, plen, smooth, w_smooth, w_len):

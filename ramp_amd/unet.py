@@ -238,8 +238,17 @@ class TemporalUnetInference(nn.Module):
     def reset_cache(self):
         self.cached_scene_latents = None
         self.cached_batch_size = None
-        self._scene_key = None              # the samplers' content-keyed cache too: forces a re-encode
+        self.invalidate_scene()             # the samplers' content-keyed cache too: forces a re-encode
+
+    def invalidate_scene(self):
+        """Forget the scene the samplers encoded last.  The samplers skip the comparison of the cloud's CONTENT when they are
+        handed the very tensor object they saw last time with an unchanged autograd version counter; a write that does not
+        bump that counter (``x.data.copy_()``, a raw-pointer kernel, a DLPack / externally shared buffer) must be followed by
+        this call (or ``reset_cache()``), otherwise the previous scene encoding stays in use."""
+        self._scene_key = None
         self._scene_ref = None
+        self._scene_ident = None
+        self._scene_src = None
 
     # ------------------------------------------------------------------ forward
     def _run(self, x, time, obstacle_pts, compose, want_f, want_eps):

@@ -584,3 +584,50 @@ def test_ddpm_chain_at_another_horizon():
     assert err < 1e-4
     with pytest.raises(Exception):
         build_unet(4, 44, False, max_rows=8).ctx()            # not a multiple of 8: refused at ramp_create, like the reference's shapes
+
+
+def test_philox_noise_is_host_replicable_and_jobs_draw_it_inside_the_graph():
+    """Throughput jobs draw N(0, I) inside the captured job (noise_source='philox': Philox4x32-10 + Box-Muller from a
+    (seed, offset) device record) instead of torch.randn on the host stream (sample_functions.py:36).  (1) the stream equals
+    its numpy restatement; (2) a job that draws its own noise equals, bit for bit, the same job with that noise INJECTED
+    (what the parity runs do), for the first (calibrating) job, the continuing one and a third that replays its graph --
+    every job consumes the next block of the stream."""
+    from ramp_amd import _lib
+    lib = _lib.load()
+    n = 4 * 48 * 4 * 26
+    out = torch.empty(n + 3, device="cuda")[:n]
+    for seed, off in ((0, 0), (0x1234567890ABCDEF, 7), (99, (1 << 33) + 5)):
+        _lib.check(lib.ramp_philox_normal(_lib.ptr(out), n, seed, off, None), "ramp_philox_normal")
+        z, _ = util.philox_normal(seed, off, n)
+        got = out.cpu().numpy()
+        assert np.abs(got - z).max() < 2e-5, np.abs(got - z).max()
+    big = torch.empty(1 << 22, device="cuda")
+    _lib.check(lib.ramp_philox_normal(_lib.ptr(big), big.numel(), 5, 0, None), "ramp_philox_normal")
+    assert abs(float(big.mean())) < 2e-3 and abs(float(big.std()) - 1.0) < 2e-3 and float(big.abs().max()) < 6.0
+    assert abs(float((big ** 4).mean()) - 3.0) < 3e-2
+    # a tail that is not a multiple of four
+    tail = torch.full((16,), 7.0, device="cuda")
+    _lib.check(lib.ramp_philox_normal(_lib.ptr(tail), 6, 1, 0, None), "ramp_philox_normal")
+    assert bool((tail[6:] == 7.0).all()) and np.abs(tail[:6].cpu().numpy() - util.philox_normal(1, 0, 6)[0]).max() < 2e-5
+
+    g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
+    from ramp_amd.models import StaticGaussianDiffusionModel
+    B, H, S, T = 4, 48, 4, 25
+    def make(source):
+        u = build_unet(S, H, False)
+        return StaticGaussianDiffusionModel(model=u, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True,
+                                            use_apf=False, sampler="ddpm", use_graph=True, noise_source=source, noise_seed=77).eval().to("cuda")
+    dp, dt = make("philox"), make("torch")
+    hc = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(S, H).items()}
+    kw = dict(n_samples=B, horizon=H, return_chain=True, traj_normalized=None, obstacle_pts=dev(g["cloud"]), sample_fn=None,
+              noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=0)
+    for job in range(3):
+        a = dp.run_inference(None, hc, **kw).cpu().numpy()
+        seed, off, n_el = dp.last_philox
+        assert (seed, n_el) == (77, (T + 1) * B * H * S) and off == job * ((n_el + 3) // 4)
+        nz = torch.empty(n_el, device="cuda")
+        _lib.check(lib.ramp_philox_normal(_lib.ptr(nz), n_el, seed, off, None), "ramp_philox_normal")
+        with NoiseInjector(list(nz.reshape(T + 1, B, H, S))):
+            b = dt.run_inference(None, hc, **kw).cpu().numpy()
+        assert np.array_equal(a, b), (job, np.abs(a - b).max())
+        assert np.isfinite(a).all() and np.abs(a).max() < 10.0

@@ -288,3 +288,15 @@ def test_touching_a_shared_header_marks_its_objects_stale():
     finally:
         os.utime(hdr, (st.st_atime, st.st_mtime))
     assert B.stale_sources() == []
+
+
+def test_philox_replica_known_answer():
+    """tests/util.philox_normal (the host replica the GPU test compares ramp_philox_normal with) against the published
+    known-answer vector of Philox4x32-10 (Random123 kat_vectors: counter 0, key 0) and the moments of its normals."""
+    import util
+    z, r = util.philox_normal(0, 0, 4)
+    assert [int(v) for v in r[:4]] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    z, _ = util.philox_normal(5, 0, 1 << 20)
+    assert abs(float(z.mean())) < 4e-3 and abs(float(z.std()) - 1.0) < 4e-3 and np.isfinite(z).all()
+    a, _ = util.philox_normal(5, 3, 8)           # offset = groups of four elements
+    assert np.array_equal(a, z[12:20])

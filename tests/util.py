@@ -115,3 +115,27 @@ def make_fake_pursuit_env(stop_at=None, log=None):
     sphere = Sphere()
     env = NS(obj_fixed_list=[NS(fields=[boxes])], obj_extra_list=[NS(fields=[sphere])])
     return NS(env=env), sphere
+
+
+def philox_normal(seed, offset, n):
+    """Host replica of ramp_philox_normal (include/ramp_hip.h; sampler.hip philox_normal_kernel): returns (z float32 [n],
+    r uint32 [4 * ceil(n / 4)]) -- Philox4x32-10 words (exact) and their Box-Muller normals (float32 numpy math, so within a
+    few ulp of the device's logf / sincosf)."""
+    ng = (n + 3) // 4
+    ctr = (np.arange(ng, dtype=np.uint64) + np.uint64(offset))
+    c = [(ctr & np.uint64(0xFFFFFFFF)).astype(np.uint64), (ctr >> np.uint64(32)).astype(np.uint64),
+         np.zeros(ng, np.uint64), np.zeros(ng, np.uint64)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    M = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]; p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & M, p0 & M]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M; k1 = (k1 + np.uint64(0xBB67AE85)) & M
+    r = np.stack(c, axis=1).astype(np.uint32)                       # (ng, 4)
+    u = ((r >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    z = np.empty((ng, 4), np.float32)
+    for h in range(2):
+        rad = np.sqrt(np.float32(-2.0) * np.log(u[:, 2 * h])).astype(np.float32)
+        ang = (np.float32(6.283185307179586) * u[:, 2 * h + 1]).astype(np.float32)
+        z[:, 2 * h] = rad * np.cos(ang); z[:, 2 * h + 1] = rad * np.sin(ang)
+    return z.reshape(-1)[:n], r.reshape(-1)
