@@ -58,6 +58,13 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch trajectories PER GPU (the driver's default); strong: --batch trajectories in TOTAL, sharded "
                          "contiguously over the ranks (ramp_amd.dist.shard_counts)")
+    ap.add_argument("--preset", choices=["config5-strong"], default=None,
+                    help="config5-strong = BASELINE configs[4] as ONE job: --config 5 --scaling strong --batch 65536 (65536 Maze3D "
+                         "trajectories, H=64, T=50, 8000-pt cloud, sharded over the --gpus ranks, one RCCL all-gather)")
+    ap.add_argument("--noise", choices=["philox", "torch"], default="philox",
+                    help="philox: every job draws its N(0, I) inside its captured graph (Philox4x32-10, SURVEY 8(d)); torch: "
+                         "torch.randn on the host stream + a copy into the job, like the reference")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs 3 / 4 / 5 sub-lines of the default run")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based): 2 = headline Maze2D B=4096 H=48 T=25 (default); "
                          "3 = Maze3D B=4096 H=48 T=25 4k-pt cloud; 4 = Maze2D dynamic replanning B=8192 (10 high-level DDIM steps "
@@ -77,6 +84,7 @@ WL = WORKLOADS[2]
 
 
 MAX_ROWS = None       # --max-rows: network rows per chunk (default: the whole batch, 2 B, in one chunk)
+NOISE = "philox"      # --noise
 
 
 def build_model(B, device, gemm_mode="default"):
@@ -98,15 +106,39 @@ def build_model(B, device, gemm_mode="default"):
         return dm.eval().to(device), sd
     cls = GaussianDiffusionModel3d if WL["o3"] else StaticGaussianDiffusionModel
     dm = cls(model=unet, variance_schedule="exponential", n_diffusion_steps=WL["T"], predict_epsilon=True,
-             compose=False, use_apf=WL["apf"], sampler="ddpm", use_graph=True)
+             compose=False, use_apf=WL["apf"], sampler="ddpm", use_graph=True, noise_source=NOISE, noise_seed=1234)
     dm = dm.eval().to(device)
     return dm, sd
 
 
-def run_job(dm, B, cloud, hard_conds, world, n_total=None, want_local=False):
+class StepEvents:
+    """HIP events on the job's stream around the two halves of every timed step: [start, sampling job done, all-gather done].
+    The all-gather's span starts when THIS rank's job is done, so it contains the wait for the slowest rank."""
+
+    def __init__(self):
+        self.ev = []
+
+    def mark(self, k):
+        import torch
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if k == 0:
+            self.ev.append([e])
+        else:
+            self.ev[-1].append(e)
+
+    def sums(self):
+        job = sum(a.elapsed_time(b) for a, b, _ in self.ev) * 1e-3
+        gather = sum(b.elapsed_time(c) for _, b, c in self.ev) * 1e-3
+        return job, gather
+
+
+def run_job(dm, B, cloud, hard_conds, world, n_total=None, want_local=False, events=None):
     """One step = one run_inference of this rank's B trajectories + the final all-gather to n_total (default B * world)."""
     import torch
     from ramp_amd import dist as rdist
+    if events is not None:
+        events.mark(0)
     if WL.get("dynamic"):
         # one job = the high-level plan (10 DDIM steps, one graph) + selection + WL["replans"] replans (5 DDIM steps each,
         # one graph per replan) against a freshly reset pursuit environment; the executed plan (H, S) is the product
@@ -118,13 +150,19 @@ def run_job(dm, B, cloud, hard_conds, world, n_total=None, want_local=False):
         hc = {k: v.unsqueeze(0).expand(B, -1).contiguous() for k, v in hard_conds.items()}
         x, _chain, _obs, _start = dm.ddim_p_sample_loop((B, WL["H"], WL["S"]), hc, context=ctx, return_chain=False,
                                                         obstacle_pts=cloud, max_iteration=WL["replans"])
+        if events is not None:
+            events.mark(1); events.mark(2)
         return (x, x) if want_local else x
     x = dm.run_inference(None, hard_conds, n_samples=B, horizon=WL["H"], return_chain=False, traj_normalized=None,
                          obstacle_pts=cloud, sample_fn=None, guide=None, n_guide_steps=1, t_start_guide=7,
                          noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=0)
     local = x
+    if events is not None:
+        events.mark(1)
     if world > 1:
         x = rdist.all_gather_trajectories(x.contiguous(), n_total if n_total is not None else B * world)
+    if events is not None:
+        events.mark(2)
     return (x, local) if want_local else x
 
 
@@ -278,9 +316,12 @@ def main():
     from ramp_amd import dist as rdist
     from ramp_amd import synth
 
-    global WL, MAX_ROWS
+    global WL, MAX_ROWS, NOISE
+    if args.preset == "config5-strong":
+        args.config, args.scaling, args.batch = 5, "strong", 65536
     WL = WORKLOADS[args.config]
     MAX_ROWS = args.max_rows or None
+    NOISE = args.noise
     if args.config in (4, 5) and args.batch == 4096:
         args.batch = 8192
     rank, world, local = rdist.env_rank()
@@ -304,6 +345,7 @@ def main():
     torch.manual_seed(1234 + rank)
 
     dm, sd = build_model(B, device)
+    dm.noise_seed = 1234 + rank                                   # (noise_source 'philox': a stream of its own per rank)
     if args.no_calibration_reuse:
         dm.model.set_calibration_reuse(False)
     cloud_np = synth.make_cloud(WL["cloud"][0], WL["cloud"][1], 3 if WL["o3"] else 2, seed=42)   # config 2: 16 x 64 = 1024 pts
@@ -316,18 +358,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    cold = {}
+    if rank == 0 and world == 1 and args.config == 2:
+        # SURVEY 8(d) "also report including them": what a FRESH context pays before its first trajectory -- weight upload +
+        # packing (ramp_load_weight / ramp_finalize_weights), time table + scene encoding, then the first job (graph capture +
+        # the calibrating bf16x6 evaluation); the steady job time is added below
+        torch.cuda.synchronize(); tq = time.perf_counter()
+        dm.model.ctx()
+        torch.cuda.synchronize(); cold["weight_load_and_pack_s"] = time.perf_counter() - tq
+        tq = time.perf_counter()
+        dm.model.prepare_time_table(dm.n_diffusion_steps)
+        dm._prepare_scene(cloud, B)
+        torch.cuda.synchronize(); cold["time_table_and_scene_encode_s"] = time.perf_counter() - tq
+        tq = time.perf_counter()
+        run_job(dm, B, cloud, hard_conds, world, n_total)
+        torch.cuda.synchronize(); cold["first_job_s"] = time.perf_counter() - tq
     for _ in range(args.warmup):
         run_job(dm, B, cloud, hard_conds, world, n_total)
     barrier()
+    events = StepEvents()
+    fallbacks0 = getattr(dm, "range_fallbacks", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out, out_local = run_job(dm, B, cloud, hard_conds, world, n_total, want_local=True)
+        out, out_local = run_job(dm, B, cloud, hard_conds, world, n_total, want_local=True, events=events)
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    job_s, gather_s = events.sums()
+    rank_timing = rdist.rank_timing_report(job_s, gather_s, dt_local, device)      # (a collective: every rank calls it)
     if WL.get("dynamic"):
         assert out.shape == (WL["H"], WL["S"]) and bool(torch.isfinite(out).all())
         gather_check = {"world": dist.get_world_size() if world > 1 else 1, "note": "planner: the ranks' candidates are merged at "
@@ -377,7 +439,36 @@ def main():
         "n_ranks_rccl": gather_check["world"], "gather_check": gather_check,
         "trajectories_total": n_total,
         "workspace_gb": dm.model.workspace_bytes() / 2 ** 30,
+        "range_flag": getattr(dm, "range_fallbacks", 0) - fallbacks0,      # timed jobs the fp16x3 range guard sent to bf16x6 (0 expected)
+        "noise": "philox4x32-10 + Box-Muller drawn inside every job's captured graph (ramp_sample_params.noise_mode 1)"
+                 if NOISE == "philox" and not WL.get("dynamic") else "torch.randn on the host stream, copied into the job",
+        # multi-GPU diagnosis: per-rank sampling-job time and the all-gather's own span, over the timed steps
+        "rank_timing": rank_timing,
+        "scaling_note": "weak: every rank samples --batch trajectories, so --gpus 1 of this mode IS the single-GPU BENCH workload; "
+                        "strong: --batch trajectories in total over the ranks (preset config5-strong = BASELINE configs[4], 65536 "
+                        "trajectories); value = trajectories of all ranks / max-over-ranks wall time either way",
     }
+    if cold:
+        steady = dt / args.steps
+        cold["steady_job_s"] = steady
+        cold["note"] = ("fresh context on rank 0: weights uploaded and packed, time table + scene encoded, first job = graph capture "
+                        "+ calibrating evaluation; value_incl_* = B / (weight load + scene encode + ONE steady job), i.e. a "
+                        "cold start that replays an existing graph; value_first_job_* additionally pays capture + calibration")
+        result["cold_start"] = cold
+        result["value_incl_scene_encode_and_weight_load"] = B / (cold["weight_load_and_pack_s"] + cold["time_table_and_scene_encode_s"] + steady)
+        result["value_first_job_incl_everything"] = B / (cold["weight_load_and_pack_s"] + cold["time_table_and_scene_encode_s"] + cold["first_job_s"])
+    if rank == 0 and world == 1 and args.config == 2 and not args.no_calibration_reuse:
+        # the same job when nothing is carried from job to job: every job's first evaluation calibrates on the bf16x6 kernels
+        dm.model.set_calibration_reuse(False)
+        run_job(dm, B, cloud, hard_conds, world, n_total)
+        torch.cuda.synchronize(); tq = time.perf_counter()
+        for _ in range(2):
+            run_job(dm, B, cloud, hard_conds, world, n_total)
+        torch.cuda.synchronize(); dq = (time.perf_counter() - tq) / 2
+        dm.model.set_calibration_reuse(True)
+        run_job(dm, B, cloud, hard_conds, world, n_total)        # (re-establishes the kept calibration for what follows)
+        result["no_calibration_reuse"] = {"value": B / dq, "unit": "trajectories/s", "ms_per_step": dq * 1e3,
+                                          "note": "--no-calibration-reuse: self-contained jobs (first evaluation in bf16x6)"}
 
     if rank == 0 and not WL["o3"] and not WL.get("dynamic"):
         # solution quality of the last timed batch, outside the timed region (on-device metrics);
@@ -447,6 +538,41 @@ def main():
                            "e2e_frac_of_its_roofline": tf * 6 / PEAK_FP16_MFMA_TFLOPS if mode == "bf16x6" else tf / PEAK_FP32_MFMA_TFLOPS}
             del dm2
             torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and args.config == 2 and not args.no_other_configs:
+        # BASELINE configs[2], [3], [4] (one GPU's share) in the driver's own run: 1 warm-up + 2 timed jobs each
+        try:
+            del dm
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        result["other_configs"] = {}
+        for cfg in (3, 4, 5):
+            WL = WORKLOADS[cfg]
+            Bc = 4096 if cfg == 3 else 8192
+            dmc, _ = build_model(Bc, device)
+            cl = torch.from_numpy(synth.make_cloud(WL["cloud"][0], WL["cloud"][1], 3 if WL["o3"] else 2, seed=42)).to(device)
+            hcc = {k: torch.from_numpy(v).to(device) for k, v in synth.default_hard_conds(WL["S"], WL["H"]).items()}
+            run_job(dmc, Bc, cl, hcc, 1)
+            f0 = getattr(dmc, "range_fallbacks", 0)
+            torch.cuda.synchronize(); tq = time.perf_counter()
+            for _ in range(2):
+                oc = run_job(dmc, Bc, cl, hcc, 1)
+            torch.cuda.synchronize(); dq = (time.perf_counter() - tq) / 2
+            assert bool(torch.isfinite(oc).all())
+            flop_c = {3: 1.323e9, 4: 1.324e9, 5: 1.773e9}[cfg]
+            tf = Bc * 2 * WL.get("evals", WL["T"]) * flop_c / dq / 1e12
+            result["other_configs"][f"config{cfg}"] = {
+                "workload": {3: "Maze3D DDPM w=5.75, B=4096 x 2 CFG rows, H=48, S=6, T=25, 4000-pt cloud",
+                             4: "Maze2D dynamic replanning, B=8192 candidates x 2 CFG rows, H=48, 10 high-level DDIM + 3 replans x 5 "
+                                "score steps, 1024-pt static + 1024-pt moving pursuer cloud, one hipGraph per replan",
+                             5: "one GPU's shard of Maze3D B=65536: B=8192 x 2 CFG rows, H=64, S=6, T=50, 8000-pt cloud"}[cfg],
+                "value": Bc / dq, "unit": "trajectories/s" if cfg != 4 else "candidate trajectories/s", "ms_per_step": dq * 1e3,
+                "steps": 2, "warmup": 1, "workspace_gb": dmc.model.workspace_bytes() / 2 ** 30,
+                "range_flag": getattr(dmc, "range_fallbacks", 0) - f0,
+                "e2e_algorithmic_tflops": tf, "e2e_frac_of_fp16x3_ceiling": tf * FP16_PRODUCTS_PER_FP32 / PEAK_FP16_MFMA_TFLOPS}
+            del dmc, oc
+            torch.cuda.empty_cache()
+        WL = WORKLOADS[args.config]
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
         result["cpu_baseline"] = cpu_baseline(sd, cloud_np, args.cpu_sample)
     elif rank == 0:

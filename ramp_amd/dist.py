@@ -145,6 +145,27 @@ def select_best_sharded(batch_local: torch.Tensor, mask_local: torch.Tensor, ple
     return best, int(n_free), int(row)
 
 
+def rank_timing_report(job_s: float, gather_s: float, wall_s: float, device=None) -> dict:
+    """What makes a multi-GPU bench line diagnosable: every rank's own sampling-job time, its all-gather span (which contains
+    the wait for the slowest rank) and its wall time of the timed region, gathered with one small collective AFTER the timed
+    region.  Without a process group the lists have one entry."""
+    vals = torch.tensor([job_s, gather_s, wall_s], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        allv = torch.empty(dist.get_world_size() * 3, dtype=torch.float64, device=vals.device)
+        dist.all_gather_into_tensor(allv, vals)
+        allv = allv.reshape(-1, 3)
+    else:
+        allv = vals[None]
+    allv = allv.cpu()
+    job, gat, wall = ([float(v) for v in allv[:, k]] for k in range(3))
+    return {"world": int(allv.shape[0]),
+            "per_rank_job_s": job, "job_s_min": min(job), "job_s_max": max(job),
+            "per_rank_all_gather_s": gat, "all_gather_s_min": min(gat), "all_gather_s_max": max(gat),
+            "per_rank_wall_s": wall, "wall_s_max": max(wall),
+            "note": "job = HIP events around run_inference on the rank's stream; all-gather = from the rank's own job end to the "
+                    "collective's end (its minimum over ranks is the collective itself, the rest is waiting for slower ranks)"}
+
+
 def lowest_rank_with(flag: bool, device) -> int:
     """The lowest rank whose `flag` is set, or -1 when no rank's is (one MIN all-reduce of a rank number); without a process
     group: 0 / -1.  Used by the sharded planner's lock-step scratch re-plan."""

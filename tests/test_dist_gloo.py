@@ -113,18 +113,28 @@ def _merge_worker(rank, world, port, counts, q):
     none, nf, _ = rdist.select_best_sharded(traj[lo:hi], torch.ones_like(mask[lo:hi]), plen[lo:hi], smooth[lo:hi], 0.1, 0.9, select_fn=_costs_select)
     ok = ok and none is None and nf == 0
     # verified gather: the block really holds `world` shards; a tampered block is caught
-    local = traj[lo:hi].contiguous()
-    gathered = rdist.all_gather_trajectories(local, n_total)
-    chk = rdist.verify_gather(local, gathered, n_total)
-    bad = gathered.clone(); bad[0, 0, 0] += 1.0
-    chk_bad = rdist.verify_gather(local, bad, n_total)
-    ok = ok and chk == {"world": world, "ranks_seen": list(range(world)), "checksum_ok": True} and not chk_bad["checksum_ok"]
+    if list(counts) == rdist.shard_counts(n_total, world):      # (a rank WITHOUT candidates only exists in the selection: [7, 0])
+        local = traj[lo:hi].contiguous()
+        gathered = rdist.all_gather_trajectories(local, n_total)
+        chk = rdist.verify_gather(local, gathered, n_total)
+        bad = gathered.clone(); bad[0, 0, 0] += 1.0
+        chk_bad = rdist.verify_gather(local, bad, n_total)
+        ok = ok and chk == {"world": world, "ranks_seen": list(range(world)), "checksum_ok": True} and not chk_bad["checksum_ok"]
+    # what bench.py --gpus N prints to make a multi-GPU line diagnosable: per-rank job time, the all-gather's own span
+    rep = rdist.rank_timing_report(1.0 + rank, 0.25 * (world - rank), 2.0 + 0.5 * rank)
+    ok = ok and rep["world"] == world and rep["per_rank_job_s"] == [1.0 + r for r in range(world)] \
+        and rep["job_s_min"] == 1.0 and rep["job_s_max"] == float(world) \
+        and rep["per_rank_all_gather_s"] == [0.25 * (world - r) for r in range(world)] and rep["all_gather_s_min"] == 0.25 \
+        and rep["wall_s_max"] == 2.0 + 0.5 * (world - 1)
+    # the lock-step scratch re-plan's decision: the lowest rank that found a plan, or -1 on every rank
+    ok = ok and rdist.lowest_rank_with(rank == world - 1, "cpu") == world - 1 and rdist.lowest_rank_with(True, "cpu") == 0 \
+        and rdist.lowest_rank_with(False, "cpu") == -1
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("counts", [[5, 5], [4, 3]])
+@pytest.mark.parametrize("counts", [[5, 5], [4, 3], [7, 0]])
 def test_merged_selection_and_verified_gather_world2(counts):
     """Config 4 over several GPUs (diffusion_model_dynamic.py:547, 592-608): candidates sharded, the selection
     merged -- equal to the unsharded compute_trajectory_costs selection (winner row, x[0, 2:] = 0, n_free), also for uneven

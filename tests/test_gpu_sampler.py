@@ -459,16 +459,19 @@ def test_dynamic_replanning_loop_against_reference_run(impl):
     assert np.abs(sphere.centers.numpy() - g["pursuer_final"]).max() < 1e-4
 
 
-def test_dynamic_replanning_reference_run_embedded_in_a_large_batch():
-    """The planner's numerics at a batch the large-launch kernels serve (B = 768 candidates: 73728 tokens at the first
-    level, the token-owning fused feed-forward path): the six candidates of the reference run (replan_chain.npz) tiled 128
-    times.  Replicas tie with their originals and the selection takes the FIRST minimum (torch.argmin), so the plan evolves
-    exactly as in the reference run: every ranked batch's first six rows, every selected index, every collision mask."""
+@pytest.mark.parametrize("B", [768, 8192])
+def test_dynamic_replanning_reference_run_embedded_in_a_large_batch(B):
+    """The planner's numerics at the batches the large-launch kernels serve -- B = 768 candidates (73728 tokens at the first
+    level) and BASELINE configs[3]'s full B = 8192 (6 x 1365 replicas + 2): the six candidates of the reference run
+    (replan_chain.npz, diffusion_model_dynamic.py:495-624) tiled over the batch.  Replicas tie with their originals and the
+    selection takes the FIRST minimum (torch.argmin), so the plan evolves exactly as in the reference run: every ranked batch's
+    first six rows, every selected index, every collision mask, every pursuer update -- through the captured ramp_replan graphs."""
     from ramp_amd.models import DynamicGaussianDiffusionModel
     from util import NoiseInjector, StopReplan, make_fake_pursuit_env
     g = np.load(f"{GOLDEN}/replan_chain.npz")
     K = int(g["n_iter"]); B0, H, S = g["noise"].shape[1:]
-    rep = 128; B = B0 * rep
+    rep, extra = divmod(B, B0)
+    tile = lambda a: np.concatenate([np.tile(a, (rep,) + (1,) * (a.ndim - 1)), a[:extra]])
     u = build_unet(4, 48, False, max_rows=2 * B)
     dm = DynamicGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True, use_graph=True).eval().to("cuda")
     log_env = []
@@ -476,18 +479,23 @@ def test_dynamic_replanning_reference_run_embedded_in_a_large_batch():
     hard = {0: dev(g["hard0"]).repeat(B, 1), H - 1: dev(g["hardN"]).repeat(B, 1)}
     np.random.seed(23)
     dm.replan_log = []
-    with NoiseInjector([np.tile(n, (rep, 1, 1)) for n in g["noise"]]):
+    with NoiseInjector([tile(n) for n in g["noise"]]):
         with pytest.raises(StopReplan):
             dm.ddim_p_sample_loop((B, H, S), hard, context={'dataset': dataset}, return_chain=True, obstacle_pts=dev(g["cloud"]))
     assert len(dm.replan_log) == int(g["n_cost"]) and len(log_env) == int(g["n_env"])
+    assert dm.range_fallbacks == 0
     errs = []
     for j, e in enumerate(dm.replan_log):
         tr = e["batch"].cpu().numpy()
+        assert tr.shape == (B, H, S)
         errs.append(float(np.abs(tr[:B0] - g[f"cost{j}/trajs"]).max()))
-        assert float(np.abs(tr.reshape(rep, B0, H, S) - tr[:B0]).max()) < 1e-5          # replicas stay with their originals
+        assert float(np.abs(tr - tile(tr[:B0])).max()) < 1e-5                          # replicas stay with their originals
         assert e["idx"] == int(g[f"cost{j}/idx"]), (j, e["idx"])                        # rank among the free ones: the winner is an original
-        assert np.array_equal(e["free"].cpu().numpy(), np.tile(g[f"cost{j}/free"], rep)), j
-    print("large-batch replan errs", errs)
+        assert np.array_equal(e["free"].cpu().numpy(), tile(g[f"cost{j}/free"])), j
+    for j, (t, st) in enumerate(log_env):
+        assert t == int(g[f"env{j}/t"])
+        errs.append(float(np.abs(st[:B0] - g[f"env{j}/state"]).max()))
+    print(f"B = {B} replan errs", errs)
     assert errs[0] < 1e-4 and max(errs) < 2e-4
     assert np.abs(sphere.centers.numpy() - g["pursuer_final"]).max() < 1e-4
 
