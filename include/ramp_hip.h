@@ -59,7 +59,10 @@ typedef struct ramp_launch_plan {
   int32_t x6_pipe;        /* fragment-packed weights + pipelined split-precision kernels (1) or LDS-staged weights (0) */
   int32_t tkl_rows;       /* K = 256 transformer linears (LayerNorm-1 -> QKV with the norm folded in, attention out-projection, its
                            * input gradient) on the token-owning kernel (tkl.hip) from this many tokens: 0 never, 1 always */
-  int32_t reserved[2];
+  int32_t atk_rows;       /* self-attention + output projection (+ bias, cross-attention constant, residual) as ONE launch of
+                           * sample-owning waves (atk.hip) from this many tokens, on levels whose token count divides 48 or 32:
+                           * 0 never, 1 always */
+  int32_t reserved;
 } ramp_launch_plan;
 int ramp_get_launch_plan(ramp_ctx* ctx, ramp_launch_plan* out);
 int ramp_set_launch_plan(ramp_ctx* ctx, const ramp_launch_plan* plan);
@@ -324,6 +327,13 @@ int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* 
 int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
                 const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
                 float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
+/* Self-attention fused with its output projection (atk.hip; the product path's replacement of the attention kernel + the
+ * out-projection launch -- reference layers_attention_mini.py:101-127 and :132):
+ *   Y[m] = resid[m] + Wo softmax(q k^T / 8) v [m] + bias + rowbias[rowvar[m / L]],  4 heads x 64, softmax over the L tokens of
+ * m's sample.  qkv (M, 768) = [q | k | v] rows, Wo (256, 256), resid / Y (M, 256), rowbias (n_var, 256), device fp32; L must
+ * divide 48 or 32 and M be whole samples.  Scaling arguments as ramp_op_tkl (the operand is the attention output o). */
+int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const float* resid, const float* rowbias, const int32_t* rowvar,
+                int32_t L, int32_t M, float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
 /* d(ln1) = d(qkv) Wqkv^T with the LayerNorm-1 backward in its epilogue (tkl.hip, tklb_kernel; the product path's replacement of
  * the d(ln1) GEMM + ln_bwd pair, reference layers_attention_mini.py:132 differentiated): out = add + LNbwd(dqkv W^T; z, ln_g).
  * dqkv (M, 768), W (256, 768) = [Wq | Wk | Wv]^T rows, z / add / out (M, 256), device fp32.  Scaling arguments as ramp_op_tkl. */

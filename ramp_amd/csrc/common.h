@@ -160,6 +160,27 @@ struct TklbArgs {
 };
 int launch_tklb(const TklbArgs& a, hipStream_t s);
 
+// ---- self-attention fused with the linear layer behind it, sample-owning waves (atk.hip) ---------------------------------------
+// forward: Y[m][:] = resid[m][:] + Wo attention(q, k, v)[m][:] + bias + rowbias[rowvar[row0 + m / L]][:]; QKV (M, 768) row-major as the
+// QKV linear writes it, 4 heads x 64, softmax over the L tokens of m's sample.  fp16x3 products; the projection's operand o uses
+// the delayed scale / maxima / range guard of ONE call site (the out-projection's), the attention-internal operands exact
+// per-wave scales.  L must divide 48 or 32 (ato_applicable).
+struct AtoArgs {
+  int M = 0, L = 0;                    // tokens; tokens per sample
+  const float* QKV = nullptr;          // [M][768]
+  const unsigned short* W = nullptr;   // the projection's weight stream (ato_pack): 8 slabs x 32 KB
+  const float* bias = nullptr;         // [256]
+  const float* rowbias = nullptr; const int* rowvar = nullptr; int row0 = 0, rb_stride = 0;
+  const float* resid = nullptr;        // [M][256]
+  float* Y = nullptr;                  // [M][256]
+  const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;
+  int* range_flag = nullptr;
+};
+bool ato_applicable(int M, int L, int* ng);
+int launch_ato(const AtoArgs& a, hipStream_t s);
+int ato_pack(const float* W /*[256][256] fp32, device*/, float scale, unsigned short* out /*8 * 32 KB*/, hipStream_t s);
+int init_atk_attributes();
+
 // ---- row-wise ops (rowops.hip) --------------------------------------------------------------
 // GroupNorm over (L, C/8) per (row, group) [+ Mish] [+ per-channel time bias] [+ residual]
 struct GnArgs {

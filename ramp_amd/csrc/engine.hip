@@ -112,6 +112,8 @@ struct STBlock {
   float *a_qkv = nullptr, *a_z1 = nullptr, *a_ag = nullptr, *a_z2 = nullptr;
   // token-owning fused feed-forward (ffx.hip): the two weight streams, the weight scales of their first / second product
   unsigned short *ffx_f = nullptr, *ffx_b = nullptr; float ffx_wsi_w1 = 1.f, ffx_wsi_w2 = 1.f;
+  // self-attention fused with the output projection (atk.hip): the projection's weight stream
+  unsigned short* ato_w = nullptr; float ato_wsi = 1.f;
 };
 struct ST {
   std::string name;
@@ -201,6 +203,8 @@ struct ramp_ctx {
                                      // kernels of ffx.hip, forward and backward (RAMP_FFX: 0 never, n that threshold)
   int tkl_min_rows = 65536;          // fp16x3 evaluations: K = 256 transformer linears (LN1 -> QKV, out-proj, d(o)) with at least this many
                                      // tokens run the token-owning kernel of tkl.hip (RAMP_TKL: 0 never, n that threshold)
+  int atk_min_rows = 16384;          // fp16x3 evaluations: self-attention + output projection as one launch of sample-owning waves (atk.hip)
+                                     // from this many tokens where the level's token count divides 48 or 32 (RAMP_ATK: 0 never, n that threshold)
   int share_prefix = 1;              // sampling jobs: rows of one trajectory share the network prefix (RAMP_SHARE_PREFIX=0: off)
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
@@ -460,6 +464,23 @@ struct Run {
     c->launches++;
     return rc;
   }
+  // self-attention + output projection (+ bias, + the row variant's cross-attention constant, + residual) in one launch of
+  // sample-owning waves (atk.hip); consumes the call site of the out-projection launch it replaces (same operand o, same maxima)
+  bool use_ato(const STBlock& k, int M, int L) const {
+    return k.ato_w && c->atk_min_rows > 0 && M >= c->atk_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe && ato_applicable(M, L, nullptr);
+  }
+  int ato(const STBlock& k, const float* qkv, const float* resid, float* Y, int M, int L, const float* rowbias, int rb_stride) {
+    RAMP_REQUIRE(c->site < ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
+    prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 256 + 16.0 * M * L * 64, {M, 256, 256, -4});
+    AtoArgs t; t.M = M; t.L = L; t.QKV = qkv; t.W = k.ato_w; t.bias = k.bo; t.resid = resid; t.Y = Y;
+    t.rowbias = rowbias; t.rowvar = c->row_variant; t.row0 = row0; t.rb_stride = rb_stride;
+    t.amax_in = c->obs_in + c->site; t.amax_out = c->obs_out + c->site; t.wsi = k.ato_wsi; t.site = c->site; t.range_flag = c->range_flag;
+    c->site++;
+    int rc = launch_ato(t, s);
+    prof_post(c, s);
+    c->launches++;
+    return rc;
+  }
   // d(ln1) = d(qkv) Wqkv^T and the LayerNorm-1 backward behind it in one token-owning launch (tkl.hip, tklb_kernel); consumes
   // the call site of the d(ln1) GEMM it replaces
   bool use_tklb(int M, const float* W) const {
@@ -612,12 +633,16 @@ int st_forward(Run& r, ST& m, const float* x, int share = 1) {
         CK(r.gemm(q));
       }
     }
+    const float* rowbias = c->cross_bias + (size_t)(m.blk0 + b) * D; const int rb_stride = c->n_blocks_total * D;
+    if (r.use_ato(k, Mb, m.L)) {      // softmax(q k^T / 8) v -> out-projection + bias + constant + residual: o never reaches HBM
+      CK(r.ato(k, k.a_qkv, zin, pre ? c->t_ln : k.a_z1, Mb, m.L, pre ? nullptr : rowbias, rb_stride));
+    } else {
     LAUNCH(c, r.s, CAT_ATTN, 16.0 * Rb * m.L * m.L * 64, launch_attn_fwd(k.a_qkv, c->t_o, Rb, m.L, r.s));
     GemmArgs a = lin(c->t_o, D, k.wo_f, k.bo, pre ? c->t_ln : k.a_z1, D, Mb, D, D);
     a.resid = zin; a.ldr = D; a.L = m.L;
-    const float* rowbias = c->cross_bias + (size_t)(m.blk0 + b) * D; const int rb_stride = c->n_blocks_total * D;
     if (!pre) { a.rowbias = rowbias; a.rb_stride = rb_stride; a.rowvar = c->row_variant; a.row0 = r.row0; }
     if (r.use_tkl(a) && (!a.rowbias || c->n_variants <= 4)) CK(r.tkl(a, nullptr, nullptr)); else CK(r.gemm(a));
+    }
     if (pre) LAUNCH(c, r.s, CAT_ROW, 0, launch_expand_rows(c->t_ln, k.a_z1, R, share, m.L, D, rowbias, rb_stride, c->row_variant, r.row0, r.s));
     if (r.use_ffx(k, M)) {      // LN3 -> FF1 -> GEGLU -> FF2 -> + z1 in one launch, nothing but the stash and z2 written
       CK(r.ffx(k, false, k.a_z1, k.a_z1, k.a_z2, M));
@@ -1025,6 +1050,8 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
     if (xe) c->ffx_min_rows = atoi(xe);
     const char* ke = getenv("RAMP_TKL");
     if (ke) c->tkl_min_rows = atoi(ke);
+    const char* ate = getenv("RAMP_ATK");
+    if (ate) c->atk_min_rows = atoi(ate);
     const char* se = getenv("RAMP_SHARE_PREFIX");
     if (se) c->share_prefix = atoi(se) != 0;
     const char* te = getenv("RAMP_X6_THREE");
@@ -1048,16 +1075,17 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
 
 int ramp_get_launch_plan(ramp_ctx* c, ramp_launch_plan* out) {
   RAMP_REQUIRE(c && out, "null argument");
-  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, c->tkl_min_rows, {0, 0}};
+  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, c->tkl_min_rows, c->atk_min_rows, 0};
   return 0;
 }
 int ramp_set_launch_plan(ramp_ctx* c, const ramp_launch_plan* p) {
   RAMP_REQUIRE(c && p, "null argument");
-  RAMP_REQUIRE(p->ff_fused_rows >= 0 && p->ffx_rows >= 0 && p->tkl_rows >= 0, "row thresholds must be >= 0");
+  RAMP_REQUIRE(p->ff_fused_rows >= 0 && p->ffx_rows >= 0 && p->tkl_rows >= 0 && p->atk_rows >= 0, "row thresholds must be >= 0");
   RAMP_REQUIRE(!c->finalized || (p->x6_pipe != 0) == (c->x6_pipe != 0), "x6_pipe is fixed once the weights are packed (ramp_finalize_weights)");
   const bool changed = p->ff_fused_rows != c->ff_fused || p->ffx_rows != c->ffx_min_rows || (p->share_prefix != 0) != (c->share_prefix != 0) ||
-                       (p->three_blocks != 0) != (c->three_blocks != 0) || p->tkl_rows != c->tkl_min_rows;
+                       (p->three_blocks != 0) != (c->three_blocks != 0) || p->tkl_rows != c->tkl_min_rows || p->atk_rows != c->atk_min_rows;
   c->ff_fused = p->ff_fused_rows; c->ffx_min_rows = p->ffx_rows; c->tkl_min_rows = p->tkl_rows; c->share_prefix = p->share_prefix != 0;
+  c->atk_min_rows = p->atk_rows;
   c->three_blocks = p->three_blocks != 0; c->x6_pipe = p->x6_pipe != 0;
   if (changed && c->finalized) {   // other kernels from here on: captured graphs and kept calibrations belong to the old plan
     c->graph_key.clear(); c->r_key.clear();
@@ -1255,6 +1283,17 @@ int ramp_finalize_weights(ramp_ctx* c) {
           k.ffx_wsi_w1 = e1.w_scale_inv; k.ffx_wsi_w2 = e2.w_scale_inv;
         }
     }
+    if (c->gemm_mode == 2 && c->x6_pipe) {
+      // weight streams of the fused self-attention + output projection (atk.hip): Wo in head order, k permuted to the row order
+      // of the attention output's accumulator tiles, with the scale the tile kernels' planes of the same weight carry
+      for (auto& st : c->sts)
+        for (auto& k : st.blk) {
+          const auto& eo = c->x6.at(k.wo_f);
+          float* q; CK(dev_alloc(c, &q, 8 * 8192 + 4));
+          k.ato_w = reinterpret_cast<unsigned short*>(q); k.ato_wsi = eo.w_scale_inv;
+          CK(ato_pack(k.wo_f, 1.f / eo.w_scale_inv, k.ato_w, 0));
+        }
+    }
     for (auto& d : c->downs) { CK(reg(d.w_f, 3ul * d.C * d.C, d.C)); CK(reg(d.w_b, 3ul * d.C * d.C, d.C)); }
     for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C, u.C)); CK(reg(u.w_b, 4ul * u.C * u.C, u.C)); }
   }
@@ -1264,6 +1303,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
   CK(init_attention_attributes());
   CK(init_ffx_attributes());
   CK(init_tkl_attributes());
+  CK(init_atk_attributes());
   c->finalized = true;
   return 0;
 }
@@ -2062,6 +2102,40 @@ int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* 
   a.ln_g = ln_g; a.ln_b = ln_b; a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
   a.range_flag = reinterpret_cast<int*>(slots + 2);
   int rc = launch_tkl(a, s);
+  hipError_t e = hipStreamSynchronize(s);
+  float back[4] = {0, 0, 0, 0};
+  if (rc == 0 && e == hipSuccess) {
+    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
+    if (absmax_out_host) *absmax_out_host = back[1];
+    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
+  }
+  RAMP_HIP_CHECK(e);
+  return rc;
+}
+
+int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const float* resid, const float* rowbias, const int32_t* rowvar,
+                int32_t L, int32_t M, float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  RAMP_REQUIRE(qkv && Wo && resid && Y && M > 0 && L > 0, "bad arguments");
+  hipStream_t s = as_stream(stream);
+  DevArena ar;
+  std::vector<float> hw((size_t)256 * 256);
+  RAMP_HIP_CHECK(hipMemcpy(hw.data(), Wo, hw.size() * 4, hipMemcpyDeviceToHost));
+  float mx = 0.f;
+  for (float v : hw) mx = std::max(mx, std::fabs(v));
+  float sc = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
+  unsigned short* stream_w = reinterpret_cast<unsigned short*>(ar.alloc(8 * 8192 + 4));
+  float* slots = ar.alloc(4);
+  RAMP_REQUIRE(stream_w && slots, "hipMalloc failed");
+  CK(init_atk_attributes());
+  CK(ato_pack(Wo, sc, stream_w, s));
+  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
+  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
+  AtoArgs a; a.M = M; a.L = L; a.QKV = qkv; a.W = stream_w; a.bias = bias; a.resid = resid; a.Y = Y;
+  a.rowbias = rowbias; a.rowvar = rowvar; a.row0 = 0; a.rb_stride = 256;
+  a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
+  a.range_flag = reinterpret_cast<int*>(slots + 2);
+  int rc = launch_ato(a, s);
   hipError_t e = hipStreamSynchronize(s);
   float back[4] = {0, 0, 0, 0};
   if (rc == 0 && e == hipSuccess) {

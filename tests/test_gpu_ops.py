@@ -521,6 +521,62 @@ def test_tklb_dln1_with_layernorm_backward_against_float64_autograd(M):
     assert flag.value == 1, flag.value
 
 
+def _attention_block_float64(qkv, Wo, bias, resid, rowbias, rowvar, L):
+    """resid + to_out(softmax(q k^T / 8) v) + bias + per-row-variant constant in float64 (layers_attention_mini.py:101-127, 132)."""
+    M = qkv.shape[0]
+    x = qkv.double().reshape(M // L, L, 3, 4, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)      # (R, 4, L, 64)
+    p = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(M, 256)
+    y = resid.double() + o @ Wo.double().T
+    if bias is not None:
+        y = y + bias.double()
+    if rowbias is not None:
+        y = y + rowbias.double()[rowvar.long()[torch.arange(M, device=qkv.device) // L]]
+    return y, o
+
+
+@pytest.mark.parametrize("L,R,rb", [(48, 4, True), (48, 9, False), (24, 7, True), (12, 33, True), (6, 131, True), (6, 64, False),
+                                    (16, 5, True), (32, 3, True), (8, 40, False), (4, 9, True), (3, 50, True), (2, 7, False), (1, 100, True)])
+def test_ato_attention_with_output_projection_against_float64(L, R, rb):
+    """Self-attention fused with its output projection (atk.hip through ramp_op_ato: sample-owning waves, every product on the
+    16 x 16 fp16 MFMAs in the fp16x3 split) against float64: every level length that divides 48 or 32, sample counts that leave
+    the last wave / block partly or wholly empty, with and without the per-row-variant constant; the recorded operand maximum
+    is the attention output's true one, scaling from it leaves the result unchanged to rounding, a stale maximum raises the
+    range flag."""
+    import ctypes as C
+    from ramp_amd import _lib
+    M = R * L
+    gen = torch.Generator(device="cpu").manual_seed(1000 * L + R)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).cuda()
+    qkv = r(M, 768, sc=1.5)
+    qkv[:, 512:] = qkv[:, 512:] * 0.3 + 0.1
+    Wo, bias, resid = r(256, 256, sc=1 / 16), r(256, sc=0.3), r(M, 256)
+    n_var = 3
+    rowbias = r(n_var, 256, sc=0.5) if rb else None
+    rowvar = (torch.arange(R, device="cuda") % n_var).to(torch.int32) if rb else None
+    ref, o = _attention_block_float64(qkv, Wo, bias, resid, rowbias, rowvar, L)
+    ref = ref.cpu().numpy(); omax = o.abs().max().item()
+    Y = torch.empty(M, 256, device="cuda")
+    out, flag = C.c_float(0), C.c_int32(0)
+    p = lambda t_: _lib.ptr(t_) if t_ is not None else None
+
+    def go(prev):
+        Y.fill_(float("nan"))
+        _lib.check(_lib.load().ramp_op_ato(p(qkv), p(Wo), p(bias), p(resid), p(rowbias), p(rowvar), L, M, prev, p(Y), C.byref(out),
+                                           C.byref(flag), None), "ramp_op_ato")
+        return rel(Y.double().cpu().numpy(), ref)
+
+    e = go(0.0)
+    print(f"ato L={L} R={R}: {e:.2e}")
+    assert e < 3e-6 and flag.value == 0, (e, flag.value)
+    assert abs(out.value - omax) <= 2e-6 * omax, (out.value, omax)
+    e2 = go(out.value)
+    assert e2 < 3e-6 and flag.value == 0, (e2, flag.value)
+    go(omax / 4096.0)
+    assert flag.value == 1, flag.value
+
+
 STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, compare with the exact-fp32 kernel?
     ("fp16x3 bias-only 768x256 (QKV; third resident block)", 393216, 768, 256, 1, 1, 3, 1, True),
     ("fp16x3 residual 256x256 (out-proj, 64x256 tile)", 393216, 256, 256, 1, 1, 3, 3, True),
