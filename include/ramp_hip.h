@@ -330,10 +330,10 @@ int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* 
 /* Self-attention fused with its output projection (atk.hip; the product path's replacement of the attention kernel + the
  * out-projection launch -- reference layers_attention_mini.py:101-127 and :132):
  *   Y[m] = resid[m] + Wo softmax(q k^T / 8) v [m] + bias + rowbias[rowvar[m / L]],  4 heads x 64, softmax over the L tokens of
- * m's sample.  qkv (M, 768) = [q | k | v] rows, Wo (256, 256), resid / Y (M, 256), rowbias (n_var, 256), device fp32; L must
+ * m's sample.  qkv (M, 768) = [q | k | v] rows, Wo (256, 256), resid / Y (M, 256), rowbias (n_var <= 4, 256), device fp32; L must
  * divide 48 or 32 and M be whole samples.  Scaling arguments as ramp_op_tkl (the operand is the attention output o). */
 int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const float* resid, const float* rowbias, const int32_t* rowvar,
-                int32_t L, int32_t M, float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
+                int32_t n_var, int32_t L, int32_t M, float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
 /* d(ln1) = d(qkv) Wqkv^T with the LayerNorm-1 backward in its epilogue (tkl.hip, tklb_kernel; the product path's replacement of
  * the d(ln1) GEMM + ln_bwd pair, reference layers_attention_mini.py:132 differentiated): out = add + LNbwd(dqkv W^T; z, ln_g).
  * dqkv (M, 768), W (256, 768) = [Wq | Wk | Wv]^T rows, z / add / out (M, 256), device fp32.  Scaling arguments as ramp_op_tkl. */

@@ -34,8 +34,14 @@ namespace {
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
 constexpr int AT_SLAB = 32 * 1024;                      // 8 output blocks of 16 x 2 k32 steps x 2 planes x 1 KB
-constexpr int AT_R = 2;                                 // ring slots (v1: slab g + 1 is fetched while slab g computes)
-constexpr size_t AT_LDS = (size_t)AT_R * AT_SLAB;
+constexpr int AT_R = 3;                                 // ring slots: slab g + 2 is requested behind the barrier of slab g
+constexpr int AT_BIAS = AT_R * AT_SLAB;                 // bias (256 floats)
+constexpr int AT_RB = AT_BIAS + 256 * 4;                // row-variant constants (<= 4 x 256 floats)
+constexpr int AT_V = AT_RB + 4 * 256 * 4;               // per wave: the v rows of one head, 4-row groups of 1 KB + 64 B pad (bank spread)
+constexpr int AT_VG = 1024 + 64;                        // group stride
+constexpr int AT_VW = 12 * AT_VG;                       // per wave (T = 48: 12 groups)
+constexpr size_t AT_LDS = (size_t)AT_V + 4 * AT_VW;
+static_assert(AT_LDS <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ f32x4 mm32(const u32x4 a, const u32x4 b, const f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
@@ -97,7 +103,17 @@ int ato_pack(const float* W, float scale, unsigned short* out, hipStream_t s) {
   return 0;
 }
 
-// NG: 16-token groups per wave (3: T = 48, 2: T = 32).  EPI bit 1: row-variant constant.
+// NG: 16-token groups per wave (3: T = 48, 2: T = 32).  RB: per-row-variant constant.
+//
+// Schedule of a wave.  The work is a flat sequence of HEAD STEPS (tile, head): [attention of the head on registers] -> [slab 2 h] ->
+// [slab 2 h + 1] -> (head 3: epilogue of the tile).  The raw q / k / v rows of the NEXT head step (the next tile's head 0 after head 3)
+// are requested behind the first slab's barrier, so their latency hides behind 288 MFMAs and they occupy registers only while the
+// projection runs; the v rows go through a wave-private LDS region by LDS-DMA behind the second barrier (the values vector instructions
+// touch must fit the 256 architectural registers: the 192 accumulators live in the other half of the file).  Vector-memory order per
+// head step: [DMA slab g + 2][q, k loads of the next step][DMA slab g + 3][v DMA of the next step](epilogue: 4 x (12 residual loads, 12 stores)); the
+// head step starts with s_waitcnt vmcnt(0) (vmcnt(24) after an epilogue: its last batch stays in flight), which drains every LDS-DMA
+// piece issued before -- each slab's pieces are issued two slabs ahead into a 3-slot ring, so the barrier at a slab top only has to
+// publish them.
 template <int NG, bool RB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ato_kernel(AtoArgs a, int n_tiles) {
@@ -107,10 +123,19 @@ void ato_kernel(AtoArgs a, int n_tiles) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   const int n_my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int n_steps = 4 * n_my;
 
   const float s_in = scale_of(a.amax_in);
   const float os = a.wsi / s_in;
   float amax = 0.f;
+
+  // tables -> LDS (published by the first slab barrier)
+  float* bs = reinterpret_cast<float*>(smem + AT_BIAS);
+  bs[tid] = a.bias ? a.bias[tid] : 0.f;
+  if (RB) {
+    float* rbs = reinterpret_cast<float*>(smem + AT_RB);
+    for (int v = 0; v < a.n_var; ++v) rbs[v * 256 + tid] = a.rowbias[(long)v * a.rb_stride + tid];
+  }
 
   // sample of each key row / query column of the wave's T x T score matrix (tile-independent: wave tiles start at sample starts)
   int samp_q[NG], samp_k[NG][4];
@@ -121,14 +146,12 @@ void ato_kernel(AtoArgs a, int n_tiles) {
     for (int i = 0; i < 4; ++i) samp_k[t][i] = (16 * t + 4 * g + i) / a.L;
   }
 
-  // ---- weight ring (v1): wave w copies bytes [8 w KB, +8 KB) of a slab as 8 LDS-DMA pieces; slab g + 1 is issued behind the barrier
-  // of slab g (every wave has left slab g - 1, whose slot it overwrites) and waited for, with everything else in flight, at the
-  // top of slab g + 1.
+  // ---- weight ring: wave w copies bytes [8 w KB, +8 KB) of a slab as 8 LDS-DMA pieces of 1 KB (inline asm, as ffx.hip / tkl.hip)
   const char* wsrc = reinterpret_cast<const char*>(a.W) + wave * 8192 + lane * 16;
   int is_g = 0;
   auto issue_slab = [&]() __attribute__((always_inline)) {
     const char* src = wsrc + (long)(is_g & 7) * AT_SLAB;
-    const unsigned dst = (unsigned)(uintptr_t)(smem + (is_g & (AT_R - 1)) * AT_SLAB + wave * 8192);
+    const unsigned dst = (unsigned)(uintptr_t)(smem + (is_g % AT_R) * AT_SLAB + wave * 8192);
 #define AT_PIECE(C) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" \
                                  :: "v"(src + ((C) >> 2) * 4096), "s"(dst + ((C) >> 2) * 4096), "n"(((C) & 3) * 1024) : "memory", "m0")
     AT_PIECE(0); AT_PIECE(1); AT_PIECE(2); AT_PIECE(3); AT_PIECE(4); AT_PIECE(5); AT_PIECE(6); AT_PIECE(7);
@@ -138,203 +161,299 @@ void ato_kernel(AtoArgs a, int n_tiles) {
   int gs = 0;                                               // slabs consumed
   const char* rd = smem + lane * 16;
 
-  issue_slab();                                             // slab 0 of the first tile
+  // byte offsets of the wave's rows in qkv (32-bit: launch_ato bounds M), clamped into [0, M): tokens past M read row M - 1
+  const char* qbase = reinterpret_cast<const char*>(a.QKV);
+  auto qk_off = [&](int tile, int t) __attribute__((always_inline)) {        // row of token 16 t + c, + 16 g bytes: features 4 g ..
+    long tk = (long)tile * (4 * T) + wave * T + 16 * t + c;
+    tk = tk < a.M ? tk : (long)a.M - 1;
+    return (unsigned)(tk * 3072 + 16 * g);
+  };
+  f32x4 qr[4][NG], kr[4][NG];                               // raw q, k rows of the NEXT head step
+  auto load_qk = [&](int tile, int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+      const char* row = qbase + qk_off(tile, t) + 256 * h;
+#pragma unroll
+      for (int fb = 0; fb < 4; ++fb) {
+        qr[fb][t] = *reinterpret_cast<const f32x4*>(row + 64 * fb);
+        kr[fb][t] = *reinterpret_cast<const f32x4*>(row + 1024 + 64 * fb);
+      }
+    }
+  };
+  // v rows of a head: LDS-DMA into the wave's own LDS region (no register, no vector instruction): one instruction moves the 256-byte
+  // head slices of 4 consecutive tokens (lane -> row lane >> 4, 16-byte chunk lane & 15); the attention reads them back with the token
+  // index in the registers (4 ds_read_b32 per tile: the A operand of O^T = V^T P^T); groups are padded by 64 bytes: conflict-free
+  const unsigned vdst = (unsigned)(uintptr_t)(smem + AT_V + wave * AT_VW);
+  auto dma_v = [&](int tile, int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int gr = 0; gr < T / 4; ++gr) {
+      long tk = (long)tile * (4 * T) + wave * T + 4 * gr + g;
+      tk = tk < a.M ? tk : (long)a.M - 1;
+      const char* src = qbase + (unsigned)(tk * 3072 + 2048 + 16 * c) + 256 * h;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(vdst + gr * AT_VG) : "memory", "m0");
+    }
+  };
+  const char* vrd = smem + AT_V + wave * AT_VW + g * AT_VG + 4 * c;      // + (4 kg) groups, + 256 i, + 64 fb
 
-  for (int ti = 0; ti < n_my; ++ti) {
-    const int tile = (int)blockIdx.x + ti * (int)gridDim.x;
-    const long tok0 = (long)tile * (4 * T) + wave * T;
-    auto tok_of = [&](int tl) __attribute__((always_inline)) {      // token tl of the wave, clamped into [0, M)
-      const long t = tok0 + tl;
-      return t < a.M ? t : (long)a.M - 1;
-    };
+  issue_slab(); issue_slab();                               // slabs 0, 1 of the first tile
+  load_qk((int)blockIdx.x, 0); dma_v((int)blockIdx.x, 0);
 
-    f32x4 acc[16][NG];
+  // (the accumulators are cleared from ONE register the compiler cannot see through: as literal zeros hipcc hoists 192 zero registers
+  // out of the head-step loop, spills them and reloads them in every iteration)
+  f32x4 acc[16][NG];
+  {
+    float z = 0.f;
+    asm volatile("" : "+v"(z));
 #pragma unroll
     for (int nb = 0; nb < 16; ++nb)
 #pragma unroll
-      for (int t = 0; t < NG; ++t) acc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NG; ++t) acc[nb][t] = f32x4{z, z, z, z};
+  }
 
 #pragma unroll 1
-    for (int h = 0; h < 4; ++h) {
-      // ================= attention of head h on the wave's T tokens =================
-      u32x4 oh[NG][2], ol[NG][2];                           // o^T planes: [token group][k32 step of the head]
-      {
-        // ---- q^T, k^T: lane (c, g) holds features 16 fb + 4 g + i of token 16 t + c
-        f32x4 qr[4][NG], kr[4][NG];
+  for (int hs = 0; hs < n_steps; ++hs) {
+    const int h = hs & 3;
+    const int tile = (int)blockIdx.x + (hs >> 2) * (int)gridDim.x;
+    const int hs_n = hs + 1 < n_steps ? hs + 1 : hs;        // (the last step re-requests its own rows: unused)
+    const int tile_n = (int)blockIdx.x + (hs_n >> 2) * (int)gridDim.x, h_n = hs_n & 3;
+    const long tok0 = (long)tile * (4 * T) + wave * T;
+    const bool full = tok0 + T <= a.M;                      // wave-uniform
+    // the projection's accumulators belong in the accumulation half of the register file: left to itself hipcc keeps these loop-carried
+    // values in architectural registers (copying them to AGPR temporaries around every MFMA) and spills the attention's operands
 #pragma unroll
-        for (int t = 0; t < NG; ++t) {
-          const float* row = a.QKV + tok_of(16 * t + c) * 768 + 64 * h + 4 * g;
+    for (int nb = 0; nb < 16; ++nb)
 #pragma unroll
-          for (int fb = 0; fb < 4; ++fb) {
-            qr[fb][t] = *reinterpret_cast<const f32x4*>(row + 16 * fb);
-            kr[fb][t] = *reinterpret_cast<const f32x4*>(row + 256 + 16 * fb);
-          }
+      for (int t = 0; t < NG; ++t) asm volatile("" : "+a"(acc[nb][t]));
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+      for (int t = 0; t < NG; ++t) { asm volatile("" : "+v"(qr[fb][t])); asm volatile("" : "+v"(kr[fb][t])); }
+
+    // every request of the previous head step has landed (after an epilogue its last batch of 12 loads + 12 stores may stay in flight)
+    if (h == 0 && hs > 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ================= attention of head h on the wave's T tokens =================
+    // (ordered so that the values vector instructions touch stay below the 256 architectural registers: K planes 48, one query
+    // group's Q planes 16 and score tiles 12 at a time, P planes 36, raw v 48; sched_barriers keep hipcc from merging the phases)
+    u32x4 oh[NG][2], ol[NG][2];                             // o^T planes: [token group][k32 step of the head]
+    {
+      float mq = 0.f, mk = 0.f;
+#pragma unroll
+      for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int t = 0; t < NG; ++t) { mq = amax4(qr[fb][t], mq); mk = amax4(kr[fb][t], mk); }
+      mq = wave_max(mq); mk = wave_max(mk);
+      const float sq = pow2_scale(mq, 13), sk = pow2_scale(mk, 13);
+      // exp2 of log2(e)-scaled logits; S^T / 8 with the operand scales undone
+      const float ssc = 0.125f * 1.4426950408889634f / (sq * sk);
+
+      u32x4 kh[NG][2], kl[NG][2];
+#pragma unroll
+      for (int t = 0; t < NG; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          u32x2 h0, l0, h1, l1;
+          split4s(kr[2 * j][t], sk, h0, l0); split4s(kr[2 * j + 1][t], sk, h1, l1);
+          kh[t][j] = cat2(h0, h1); kl[t][j] = cat2(l0, l1);
         }
-        // ---- v: lane (c, g) holds feature 16 fb + c of tokens 16 t + 4 g + i
-        f32x4 vr[4][NG];
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- per query group: S^T = K Q^T (tiles (kg, qg), d = 64 = 2 k32 steps), P^T = softmax over keys (registers + lane groups),
+      // masked to the query's own sample, scaled by 2^13 and split into its planes
+      u32x2 ph[NG][NG], pl[NG][NG];
 #pragma unroll
-        for (int t = 0; t < NG; ++t)
+      for (int qg = 0; qg < NG; ++qg) {
+        u32x4 qh[2], ql[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          u32x2 h0, l0, h1, l1;
+          split4s(qr[2 * j][qg], sq, h0, l0); split4s(qr[2 * j + 1][qg], sq, h1, l1);
+          qh[j] = cat2(h0, h1); ql[j] = cat2(l0, l1);
+        }
+        f32x4 st[NG];
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) {
+          f32x4 sv4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            sv4 = mm32(kh[kg][j], ql[j], sv4);
+            sv4 = mm32(kl[kg][j], qh[j], sv4);
+            sv4 = mm32(kh[kg][j], qh[j], sv4);
+          }
+          st[kg] = sv4;
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float* row = a.QKV + tok_of(16 * t + 4 * g + i) * 768 + 512 + 64 * h + c;
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) vr[fb][t][i] = row[16 * fb];
+            const float v = samp_k[kg][i] == samp_q[qg] ? st[kg][i] * ssc : -3.0e38f;
+            st[kg][i] = v;
+            mx = fmaxf(mx, v);
           }
-        float mq = 0.f, mk = 0.f, mv = 0.f;
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
+        for (int kg = 0; kg < NG; ++kg)
 #pragma unroll
-          for (int t = 0; t < NG; ++t) { mq = amax4(qr[fb][t], mq); mk = amax4(kr[fb][t], mk); mv = amax4(vr[fb][t], mv); }
-        mq = wave_max(mq); mk = wave_max(mk); mv = wave_max(mv);
-        const float sq = pow2_scale(mq, 13), sk = pow2_scale(mk, 13), sv = pow2_scale(mv, 13);
+          for (int i = 0; i < 4; ++i) {
+            const float e = __builtin_amdgcn_exp2f(st[kg][i] - mx);          // (masked entries: exp2(-3e38) = 0)
+            st[kg][i] = e;
+            sum += e;
+          }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 8192.f * __builtin_amdgcn_rcpf(sum);               // (the sum's rcp: 1 ulp, a common factor of the column)
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) { unsigned h0, h1, l0, l1; split4(st[kg] * inv, h0, h1, l0, l1); ph[kg][qg] = u32x2{h0, h1}; pl[kg][qg] = u32x2{l0, l1}; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 
-        // ---- S^T = K Q^T: tile (kg, qg) over d = 64 = 2 k32 steps (fb pairs)
-        f32x4 st[NG][NG];
-        {
-          u32x4 qh[NG][2], ql[NG][2], kh[NG][2], kl[NG][2];
+      // ---- O^T = V^T P^T: tile (fb, qg), contraction over the keys: key groups (0, 1) as one k32 step, a third group as a k16 step
+      float mv = 0.f;
+      {
+        f32x4 vt[NG];
 #pragma unroll
-          for (int t = 0; t < NG; ++t)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              u32x2 h0, l0, h1, l1;
-              split4s(qr[2 * j][t], sq, h0, l0); split4s(qr[2 * j + 1][t], sq, h1, l1);
-              qh[t][j] = cat2(h0, h1); ql[t][j] = cat2(l0, l1);
-              split4s(kr[2 * j][t], sk, h0, l0); split4s(kr[2 * j + 1][t], sk, h1, l1);
-              kh[t][j] = cat2(h0, h1); kl[t][j] = cat2(l0, l1);
-            }
+        for (int fb = 0; fb < 4; ++fb) {
 #pragma unroll
           for (int kg = 0; kg < NG; ++kg)
 #pragma unroll
-            for (int qg = 0; qg < NG; ++qg) {
-              f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) vt[kg][i] = *reinterpret_cast<const float*>(vrd + 4 * kg * AT_VG + 256 * i + 64 * fb);
 #pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                s = mm32(kh[kg][j], ql[qg][j], s);
-                s = mm32(kl[kg][j], qh[qg][j], s);
-                s = mm32(kh[kg][j], qh[qg][j], s);
-              }
-              st[kg][qg] = s;
-            }
+          for (int kg = 0; kg < NG; ++kg) mv = amax4(vt[kg], mv);
         }
-        // ---- P^T = softmax over keys (registers + lane groups) of S^T / 8, masked to the query's own sample
-        const float ssc = 0.125f / (sq * sk);
+      }
+      mv = wave_max(mv);
+      const float sv = pow2_scale(mv, 13);
+      const float so = 1.f / (sv * 8192.f);
+      float lm[NG];
+#pragma unroll
+      for (int t = 0; t < NG; ++t) lm[t] = (full || tok0 + 16 * t + c < a.M) ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {                         // feature-block pair (2 j, 2 j + 1) = the projection's k32 step j of this head
+        u32x2 vh[2][NG], vl[2][NG];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int kg = 0; kg < NG; ++kg) {
+            f32x4 vt;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vt[i] = *reinterpret_cast<const float*>(vrd + 4 * kg * AT_VG + 256 * i + 64 * (2 * j + f));
+            split4s(vt, sv, vh[f][kg], vl[f][kg]);
+          }
 #pragma unroll
         for (int qg = 0; qg < NG; ++qg) {
-          float mx = -3.0e38f;
+          f32x4 o2[2];
 #pragma unroll
-          for (int kg = 0; kg < NG; ++kg)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float v = samp_k[kg][i] == samp_q[qg] ? st[kg][qg][i] * ssc : -3.0e38f;
-              st[kg][qg][i] = v;
-              mx = fmaxf(mx, v);
+          for (int f = 0; f < 2; ++f) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            const u32x4 vh01 = cat2(vh[f][0], vh[f][1]), vl01 = cat2(vl[f][0], vl[f][1]);
+            const u32x4 ph01 = cat2(ph[0][qg], ph[1][qg]), pl01 = cat2(pl[0][qg], pl[1][qg]);
+            o = mm32(vh01, pl01, o);
+            o = mm32(vl01, ph01, o);
+            o = mm32(vh01, ph01, o);
+            if (NG == 3) {      // (a k32 step with an empty upper half, not v_mfma_f32_16x16x16_f16: behind that instruction hipcc placed the
+                                // first read of the accumulator too early on gfx950 -- registers 0, 1 of the tile still held the previous sum)
+              const u32x2 z2 = {0u, 0u};
+              const u32x4 vh2 = cat2(vh[f][NG - 1], z2), vl2 = cat2(vl[f][NG - 1], z2);
+              const u32x4 ph2 = cat2(ph[NG - 1][qg], z2), pl2 = cat2(pl[NG - 1][qg], z2);
+              o = mm32(vh2, pl2, o);
+              o = mm32(vl2, ph2, o);
+              o = mm32(vh2, ph2, o);
             }
-          mx = fmaxf(mx, __shfl_xor(mx, 16));
-          mx = fmaxf(mx, __shfl_xor(mx, 32));
-          float sum = 0.f;
-#pragma unroll
-          for (int kg = 0; kg < NG; ++kg)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float e = samp_k[kg][i] == samp_q[qg] ? expf(st[kg][qg][i] - mx) : 0.f;
-              st[kg][qg][i] = e;
-              sum += e;
-            }
-          sum += __shfl_xor(sum, 16);
-          sum += __shfl_xor(sum, 32);
-          const float inv = 8192.f / sum;                   // P^T scaled by 2^13 for its fp16 planes
-#pragma unroll
-          for (int kg = 0; kg < NG; ++kg) st[kg][qg] = st[kg][qg] * inv;
-        }
-        // ---- O^T = V^T P^T: tile (fb, qg), contraction over the keys: key groups (0, 1) as one k32 step, a third group as a k16 step
-        f32x4 ot[4][NG];
-        {
-          u32x2 ph[NG][NG], pl[NG][NG], vh[4][NG], vl[4][NG];
-#pragma unroll
-          for (int kg = 0; kg < NG; ++kg)
-#pragma unroll
-            for (int qg = 0; qg < NG; ++qg) split4s(st[kg][qg], 1.f, ph[kg][qg], pl[kg][qg]);
-#pragma unroll
-          for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int kg = 0; kg < NG; ++kg) split4s(vr[fb][kg], sv, vh[fb][kg], vl[fb][kg]);
-#pragma unroll
-          for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int qg = 0; qg < NG; ++qg) {
-              f32x4 o = {0.f, 0.f, 0.f, 0.f};
-              const u32x4 vh01 = cat2(vh[fb][0], vh[fb][1]), vl01 = cat2(vl[fb][0], vl[fb][1]);
-              const u32x4 ph01 = cat2(ph[0][qg], ph[1][qg]), pl01 = cat2(pl[0][qg], pl[1][qg]);
-              o = mm32(vh01, pl01, o);
-              o = mm32(vl01, ph01, o);
-              o = mm32(vh01, ph01, o);
-              if (NG == 3) {
-                o = mm16(vh[fb][NG - 1], pl[NG - 1][qg], o);
-                o = mm16(vl[fb][NG - 1], ph[NG - 1][qg], o);
-                o = mm16(vh[fb][NG - 1], ph[NG - 1][qg], o);
-              }
-              ot[fb][qg] = o;
-            }
-        }
-        // ---- o (true scale) -> recorded maximum, scaled planes of the projection's B operand
-        const float so = 1.f / (sv * 8192.f);
-#pragma unroll
-        for (int t = 0; t < NG; ++t)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const f32x4 o0 = ot[2 * j][t] * so, o1 = ot[2 * j + 1][t] * so;
-            amax = amax4(o0, amax); amax = amax4(o1, amax);
-            u32x2 h0, l0, h1, l1;
-            split4s(o0, s_in, h0, l0); split4s(o1, s_in, h1, l1);
-            oh[t][j] = cat2(h0, h1); ol[t][j] = cat2(l0, l1);
+            o2[f] = o * so;                                 // o, true scale
           }
-      }
-      // ================= output projection: the head's two slabs (output features [0, 128), [128, 256)) =================
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of slab gs has landed (v1: everything else in flight too)
-        __builtin_amdgcn_s_barrier();                       // slab gs certified; every wave has left slab gs - 1
-        issue_slab();                                       // slab gs + 1 into the other slot (past the last tile: bytes nobody reads)
-        const char* sl = rd + (gs & (AT_R - 1)) * AT_SLAB;
-#pragma unroll
-        for (int nbl = 0; nbl < 8; ++nbl)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const u32x4 wh = *reinterpret_cast<const u32x4*>(sl + ((nbl * 2 + j) * 2) * 1024);
-            const u32x4 wl = *reinterpret_cast<const u32x4*>(sl + ((nbl * 2 + j) * 2 + 1) * 1024);
-#pragma unroll
-            for (int t = 0; t < NG; ++t) {
-              f32x4 v = acc[8 * half + nbl][t];
-              v = mm32(wh, ol[t][j], v);
-              v = mm32(wl, oh[t][j], v);
-              v = mm32(wh, oh[t][j], v);
-              acc[8 * half + nbl][t] = v;
-            }
-          }
-        ++gs;
+          // recorded maximum (live tokens only), scaled planes of the projection's B operand
+          amax = amax4(o2[0] * lm[qg], amax); amax = amax4(o2[1] * lm[qg], amax);
+          u32x2 h0, l0, h1, l1;
+          split4s(o2[0], s_in, h0, l0); split4s(o2[1], s_in, h1, l1);
+          oh[qg][j] = cat2(h0, h1); ol[qg][j] = cat2(l0, l1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // ================= output projection: the head's two slabs (output features [0, 128), [128, 256)) =================
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __builtin_amdgcn_s_barrier();                         // slab gs is complete in LDS (every wave drained its pieces at the head-step start); slab gs - 1 is left
+      issue_slab();                                         // slab gs + 2 into the slot of slab gs - 1 (past the last tile: bytes nobody reads)
+      if (half == 0) load_qk(tile_n, h_n); else dma_v(tile_n, h_n);      // (this head's v was consumed before its first slab)
+      const char* sl = rd + (gs % AT_R) * AT_SLAB;
+#pragma unroll
+      for (int nbl = 0; nbl < 8; ++nbl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const u32x4 wh = *reinterpret_cast<const u32x4*>(sl + ((nbl * 2 + j) * 2) * 1024);
+          const u32x4 wl = *reinterpret_cast<const u32x4*>(sl + ((nbl * 2 + j) * 2 + 1) * 1024);
+#pragma unroll
+          for (int t = 0; t < NG; ++t) {
+            f32x4 v = acc[8 * half + nbl][t];
+            v = mm32(wh, ol[t][j], v);
+            v = mm32(wl, oh[t][j], v);
+            v = mm32(wh, oh[t][j], v);
+            acc[8 * half + nbl][t] = v;
+          }
+          // (fragment reads may run two macro-steps ahead of their MFMAs, not a whole slab: 128 registers)
+          if ((nbl * 2 + j) & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      ++gs;
+    }
 
-    // ================= epilogue: y[tok][16 nb + 4 g ..] = acc * os + bias + constant of the row's variant + residual =================
-    {
-      long trow[NG]; bool live[NG]; int rbo[NG];
+    // ================= epilogue (head 3): y[tok][16 nb + 4 g ..] = acc * os + bias + constant of the row's variant + residual =================
+    if (h == 3) {
+      const float* bsr = reinterpret_cast<const float*>(smem + AT_BIAS) + 4 * g;
+      unsigned yoff[NG]; int rbo[NG];
 #pragma unroll
       for (int t = 0; t < NG; ++t) {
-        const long tk = tok0 + 16 * t + c;
-        live[t] = tk < a.M;
-        trow[t] = live[t] ? tk : (long)a.M - 1;
-        rbo[t] = RB ? a.rowvar[a.row0 + (int)(trow[t] / a.L)] * a.rb_stride : 0;
+        long tk = tok0 + 16 * t + c;
+        tk = tk < a.M ? tk : (long)a.M - 1;
+        yoff[t] = (unsigned)(tk * 1024 + 16 * g);
+        rbo[t] = RB ? a.rowvar[a.row0 + (int)(tk / a.L)] * 256 + 4 * g : 0;
       }
+      const char* rbase = reinterpret_cast<const char*>(a.resid);
+      char* ybase = reinterpret_cast<char*>(a.Y);
+      float z = 0.f;
+      asm volatile("" : "+v"(z));
+      if (full) {
+        // all loads of a batch first, every store unconditional (a store behind a per-lane predicate sits in its own basic block behind
+        // s_waitcnt vmcnt(0): DESIGN.md section 5); 8 batches x (6 loads, 6 stores) -- the head-step start counts on >= 24 operations here
 #pragma unroll
-      for (int nb = 0; nb < 16; ++nb) {
-        const f32x4 bq = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + 16 * nb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b2 = 0; b2 < 8; ++b2) {
+          f32x4 rz[2][NG];
 #pragma unroll
-        for (int t = 0; t < NG; ++t) {
-          f32x4 v = acc[nb][t] * os + bq;
-          if (RB) v += *reinterpret_cast<const f32x4*>(a.rowbias + rbo[t] + 16 * nb + 4 * g);
-          v += *reinterpret_cast<const f32x4*>(a.resid + trow[t] * 256 + 16 * nb + 4 * g);
-          if (live[t]) *reinterpret_cast<f32x4*>(a.Y + trow[t] * 256 + 16 * nb + 4 * g) = v;
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < NG; ++t) rz[q][t] = *reinterpret_cast<const f32x4*>(rbase + yoff[t] + 64 * (2 * b2 + q));
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int nb = 2 * b2 + q;
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bsr + 16 * nb);
+#pragma unroll
+            for (int t = 0; t < NG; ++t) {
+              f32x4 v = acc[nb][t] * os + bq + rz[q][t];
+              if (RB) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + AT_RB) + rbo[t] + 16 * nb);
+              *reinterpret_cast<f32x4*>(ybase + yoff[t] + 64 * nb) = v;
+              acc[nb][t] = f32x4{z, z, z, z};
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
+      } else {
+        // the block's last, partly (or wholly) empty wave tile: per-token predicate
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) {
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(bsr + 16 * nb);
+#pragma unroll
+          for (int t = 0; t < NG; ++t) {
+            f32x4 v = acc[nb][t] * os + bq + *reinterpret_cast<const f32x4*>(rbase + yoff[t] + 64 * nb);
+            if (RB) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + AT_RB) + rbo[t] + 16 * nb);
+            if (tok0 + 16 * t + c < a.M) *reinterpret_cast<f32x4*>(ybase + yoff[t] + 64 * nb) = v;
+            acc[nb][t] = f32x4{z, z, z, z};
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the next head step's vmcnt(24) assumes a full epilogue's operation count)
       }
     }
   }
@@ -360,7 +479,8 @@ int launch_ato(const AtoArgs& a, hipStream_t s) {
   RAMP_REQUIRE(ato_applicable(a.M, a.L, &ng), "ato: tokens per sample must divide 48 or 32 (and M be whole samples)");
   RAMP_REQUIRE(a.QKV && a.W && a.resid && a.Y, "ato: null operand");
   RAMP_REQUIRE(al16(a.QKV) && al16(a.W) && al16(a.resid) && al16(a.Y) && al16(a.bias) && al16(a.rowbias), "ato: operands must be 16-byte aligned");
-  RAMP_REQUIRE(!a.rowbias || (a.rowvar && a.rb_stride % 4 == 0), "ato: row-variant constant needs the row -> variant table");
+  RAMP_REQUIRE(!a.rowbias || (a.rowvar && a.n_var >= 1 && a.n_var <= 4), "ato: row-variant constant needs the row -> variant table and 1 .. 4 variants");
+  RAMP_REQUIRE((long)a.M * 3072 < (1l << 32), "ato: 32-bit row offsets bound M to 1398100 tokens");
   RAMP_REQUIRE(!ranges_overlap(a.Y, (size_t)a.M * 1024, a.resid, (size_t)a.M * 1024) && !ranges_overlap(a.Y, (size_t)a.M * 1024, a.QKV, (size_t)a.M * 3072),
                "ato: the output must not overlap the residual or qkv");
   const int T = 16 * ng, n_tiles = (a.M + 4 * T - 1) / (4 * T);

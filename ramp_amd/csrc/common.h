@@ -170,7 +170,7 @@ struct AtoArgs {
   const float* QKV = nullptr;          // [M][768]
   const unsigned short* W = nullptr;   // the projection's weight stream (ato_pack): 8 slabs x 32 KB
   const float* bias = nullptr;         // [256]
-  const float* rowbias = nullptr; const int* rowvar = nullptr; int row0 = 0, rb_stride = 0;
+  const float* rowbias = nullptr; const int* rowvar = nullptr; int row0 = 0, rb_stride = 0, n_var = 0;   // <= 4 variants
   const float* resid = nullptr;        // [M][256]
   float* Y = nullptr;                  // [M][256]
   const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;

@@ -467,13 +467,14 @@ struct Run {
   // self-attention + output projection (+ bias, + the row variant's cross-attention constant, + residual) in one launch of
   // sample-owning waves (atk.hip); consumes the call site of the out-projection launch it replaces (same operand o, same maxima)
   bool use_ato(const STBlock& k, int M, int L) const {
-    return k.ato_w && c->atk_min_rows > 0 && M >= c->atk_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe && ato_applicable(M, L, nullptr);
+    return k.ato_w && c->atk_min_rows > 0 && M >= c->atk_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe && c->n_variants <= 4 &&
+           ato_applicable(M, L, nullptr);
   }
   int ato(const STBlock& k, const float* qkv, const float* resid, float* Y, int M, int L, const float* rowbias, int rb_stride) {
     RAMP_REQUIRE(c->site < ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
     prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 256 + 16.0 * M * L * 64, {M, 256, 256, -4});
     AtoArgs t; t.M = M; t.L = L; t.QKV = qkv; t.W = k.ato_w; t.bias = k.bo; t.resid = resid; t.Y = Y;
-    t.rowbias = rowbias; t.rowvar = c->row_variant; t.row0 = row0; t.rb_stride = rb_stride;
+    t.rowbias = rowbias; t.rowvar = c->row_variant; t.row0 = row0; t.rb_stride = rb_stride; t.n_var = rowbias ? c->n_variants : 0;
     t.amax_in = c->obs_in + c->site; t.amax_out = c->obs_out + c->site; t.wsi = k.ato_wsi; t.site = c->site; t.range_flag = c->range_flag;
     c->site++;
     int rc = launch_ato(t, s);
@@ -2114,7 +2115,7 @@ int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* 
 }
 
 int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const float* resid, const float* rowbias, const int32_t* rowvar,
-                int32_t L, int32_t M, float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+                int32_t n_var, int32_t L, int32_t M, float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
   RAMP_REQUIRE(qkv && Wo && resid && Y && M > 0 && L > 0, "bad arguments");
   hipStream_t s = as_stream(stream);
   DevArena ar;
@@ -2132,7 +2133,7 @@ int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const floa
   const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
   RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
   AtoArgs a; a.M = M; a.L = L; a.QKV = qkv; a.W = stream_w; a.bias = bias; a.resid = resid; a.Y = Y;
-  a.rowbias = rowbias; a.rowvar = rowvar; a.row0 = 0; a.rb_stride = 256;
+  a.rowbias = rowbias; a.rowvar = rowvar; a.row0 = 0; a.rb_stride = 256; a.n_var = rowbias ? n_var : 0;
   a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
   a.range_flag = reinterpret_cast<int*>(slots + 2);
   int rc = launch_ato(a, s);
@@ -2234,7 +2235,55 @@ thread_local StressHook* g_stress = nullptr;
 
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 9, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 11, "bad arguments");
+  if (mode == 10 || mode == 11) {                      // atk.hip: self-attention + out-projection in one launch (10) / the pair it replaces:
+                                                       // attn2_fwd + token-owning out-projection (11).  L = tokens per sample; flags 1: row-variant constant
+    hipStream_t sa = as_stream(stream);
+    DevArena ara;
+    RAMP_REQUIRE(L >= 1 && M % L == 0, "mode 10 / 11: M must be whole samples of L tokens");
+    float* Q = ara.alloc((size_t)M * 768); float* R = ara.alloc((size_t)M * 256); float* Y = ara.alloc((size_t)M * 256); float* O = ara.alloc((size_t)M * 256);
+    float* W = ara.alloc(256 * 256); float* b = ara.alloc(256); float* rbv = ara.alloc(4 * 256); float* sl = ara.alloc(4);
+    int* rv = reinterpret_cast<int*>(ara.alloc((size_t)M / L + 4));
+    unsigned short* ws = reinterpret_cast<unsigned short*>(ara.alloc(8 * 8192 + 4));
+    unsigned short* p8 = reinterpret_cast<unsigned short*>(ara.alloc((size_t)256 * 256 + 4));
+    RAMP_REQUIRE(Q && R && Y && O && W && b && rbv && sl && rv && ws && p8, "hipMalloc failed");
+    auto fill = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sa, p, (long)n, seed, sc); };
+    fill(Q, (size_t)M * 768, 1u, 1.5f); fill(R, (size_t)M * 256, 4u, 1.f); fill(W, 256 * 256, 2u, 1.f / 16.f); fill(b, 256, 5u, 1.f); fill(rbv, 1024, 6u, 1.f);
+    const int pat[2] = {0, 1};
+    int* dpat = reinterpret_cast<int*>(ara.alloc(4));
+    RAMP_REQUIRE(dpat, "hipMalloc failed");
+    RAMP_HIP_CHECK(hipMemcpyAsync(dpat, pat, sizeof(pat), hipMemcpyHostToDevice, sa));
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(64), dim3(256), 0, sa, rv, dpat, 2, M / L);
+    CK(init_atk_attributes());
+    CK(ato_pack(W, 16384.f, ws, sa));
+    CK(launch_pack_h3(W, p8, 256, 256, 16384.f, sa));
+    const float one[4] = {1.5f, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, sa));
+    AtoArgs a; a.M = M; a.L = L; a.QKV = Q; a.W = ws; a.bias = b; a.resid = R; a.Y = Y; a.amax_in = sl; a.amax_out = sl + 1; a.wsi = 1.f / 16384.f;
+    a.range_flag = reinterpret_cast<int*>(sl + 2);
+    if (flags & 1) { a.rowbias = rbv; a.rowvar = rv; a.rb_stride = 256; a.n_var = 2; }
+    TklArgs t; t.M = M; t.N = 256; t.X = O; t.Y = Y; t.ldy = 256; t.W = p8; t.bias = b; t.resid = R; t.ldr = 256; t.amax_in = sl; t.amax_out = sl + 1; t.wsi = 1.f / 16384.f;
+    t.range_flag = reinterpret_cast<int*>(sl + 2);
+    if (flags & 1) { t.rowbias = rbv; t.rowvar = rv; t.rb_stride = 256; t.L = L; t.n_var = 2; }
+    auto go = [&]() -> int {
+      if (mode == 10) return launch_ato(a, sa);
+      if (int rc = launch_attn_fwd(Q, O, M / L, L, sa)) return rc;
+      return launch_tkl(t, sa);
+    };
+    for (int i = 0; i < warmup; ++i) CK(go());
+    hipEvent_t e0, e1;
+    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+    RAMP_HIP_CHECK(hipEventRecord(e0, sa));
+    int rca = 0;
+    for (int i = 0; i < iters && rca == 0; ++i) { rca = go(); if (rca == 0) STRESS(Y, (size_t)M * 256, sa); }
+    RAMP_HIP_CHECK(hipEventRecord(e1, sa));
+    RAMP_HIP_CHECK(hipEventSynchronize(e1));
+    float msa = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&msa, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = msa * 1e3f / iters;
+    return rca;
+  }
   if (mode == 6 || mode == 7) {                        // ffx.hip: fused feed-forward with token-owning waves, forward / backward
     hipStream_t s6 = as_stream(stream);
     DevArena ar6;

@@ -563,7 +563,7 @@ def test_ato_attention_with_output_projection_against_float64(L, R, rb):
 
     def go(prev):
         Y.fill_(float("nan"))
-        _lib.check(_lib.load().ramp_op_ato(p(qkv), p(Wo), p(bias), p(resid), p(rowbias), p(rowvar), L, M, prev, p(Y), C.byref(out),
+        _lib.check(_lib.load().ramp_op_ato(p(qkv), p(Wo), p(bias), p(resid), p(rowbias), p(rowvar), n_var if rb else 0, L, M, prev, p(Y), C.byref(out),
                                            C.byref(flag), None), "ramp_op_ato")
         return rel(Y.double().cpu().numpy(), ref)
 
