@@ -175,6 +175,8 @@ struct AtoArgs {
   float* Y = nullptr;                  // [M][256]
   const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;
   int* range_flag = nullptr;
+  unsigned long long* stamps = nullptr; // diagnostic (ramp_bench_gemm): per wave 8 cycle sums
+  int ablate = 0;                      // diagnostic twin (with stamps; wrong results): 2 no k / v DMA, 4 no ring DMA, 6 neither
 };
 bool ato_applicable(int M, int L, int* ng);
 int launch_ato(const AtoArgs& a, hipStream_t s);

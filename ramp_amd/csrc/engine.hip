@@ -2270,6 +2270,13 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
       if (int rc = launch_attn_fwd(Q, O, M / L, L, sa)) return rc;
       return launch_tkl(t, sa);
     };
+    unsigned long long* stamps = nullptr;
+    if (flags & 256) {                                   // the stamped twin: where a head step's cycles go
+      stamps = reinterpret_cast<unsigned long long*>(ara.alloc(256 * 4 * 8 * 2));
+      RAMP_REQUIRE(stamps && mode == 10 && (flags & 1), "stamps: mode 10 with flags & 1");
+      RAMP_HIP_CHECK(hipMemsetAsync(stamps, 0, 256 * 4 * 8 * 8, sa));
+      a.stamps = stamps; a.ablate = (flags >> 9) & 7;
+    }
     for (int i = 0; i < warmup; ++i) CK(go());
     hipEvent_t e0, e1;
     RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
@@ -2282,6 +2289,17 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     RAMP_HIP_CHECK(hipEventElapsedTime(&msa, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_us = msa * 1e3f / iters;
+    if (rca == 0 && stamps) {
+      std::vector<unsigned long long> hst(256 * 4 * 8);
+      RAMP_HIP_CHECK(hipMemcpy(hst.data(), stamps, hst.size() * 8, hipMemcpyDeviceToHost));
+      double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nw = 0;
+      for (int w = 0; w < 1024; ++w) if (hst[w * 8 + 6]) { ++nw; for (int j = 0; j < 8; ++j) sm[j] += (double)hst[w * 8 + j]; }
+      const int T4 = 192, n_tiles = (M + T4 - 1) / T4;
+      const double steps = std::max(1, nw) * 4.0 * (double)((n_tiles + 255) / 256);
+      fprintf(stderr, "[ato stamps] per head step (s_memtime ticks, %d waves): epilogue + loop top %.0f, head-start wait %.0f, S^T + softmax %.0f, PV %.0f, "
+              "barriers %.0f, DMA issue + slab bodies %.0f; whole kernel %.0f per step; shader clock %.0f MHz\n",
+              nw, sm[0] / steps, sm[1] / steps, sm[2] / steps, sm[3] / steps, sm[4] / steps, sm[5] / steps, sm[6] / steps, sm[7] > 0 ? sm[6] / sm[7] * 100.0 : 0.0);
+    }
     return rca;
   }
   if (mode == 6 || mode == 7) {                        // ffx.hip: fused feed-forward with token-owning waves, forward / backward

@@ -18,3 +18,8 @@ for L, R in cases:
         row.append(us.value)
     fl = 2.0 * M * 256 * 256 + 16.0 * M * L * 64
     print(f"L={L:3d} rows={R:5d} tokens={M:7d}: fused {row[0]:8.1f} us ({fl / row[0] / 1e6:6.1f} TFLOP/s)   attn2_fwd + tkl out-proj {row[1]:8.1f} us   x{row[1] / row[0]:.2f}", flush=True)
+if "--stamps" in sys.argv or os.environ.get("ATK_STAMPS"):
+    for abl, what in ((0, "stamped twin"), (2, "without k / v LDS-DMA"), (4, "without ring LDS-DMA"), (6, "without either")):
+        us = C.c_float(0)
+        _lib.check(lib.ramp_bench_gemm(48 * 8192, 256, 256, 1, 48, 10, 1 | 256 | (abl << 9), 2, 3, C.byref(us), None), "ramp_bench_gemm")
+        print(f"{what}: {us.value:.1f} us", flush=True)
