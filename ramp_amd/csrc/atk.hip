@@ -109,12 +109,12 @@ int ato_pack(const float* W, float scale, unsigned short* out, hipStream_t s) {
 // Schedule of a wave.  The work is a flat sequence of HEAD STEPS (tile, head): [attention of the head] -> [4 slabs of the projection: 16 output
 // features x 4, the head's 64 k] -> (head 3: epilogue of the tile).  Register budget: the 192 accumulators live in the accumulation half of
 // the file; what vector instructions touch must fit the 256 architectural registers (and hipcc spills long before that), so of the NEXT
-// head step only the raw q rows wait in registers (48): its k and v rows go to wave-private LDS regions by LDS-DMA, one piece per
-// macro-step of the slabs (an LDS-DMA issue holds the wave for 60-180 cycles: behind an MFMA, not in a burst at the slab top).
-// Vector-memory order of a head step: wait(0) | slab 0: ring slab g+2 (4 pieces), k pieces 0-7 | slab 1: ring g+3, v pieces 0-3, k pieces
-// 8-11 | wait(12) slab 2: q loads (12), ring g+4, v pieces 4-11 | wait(12) slab 3: touches of the epilogue's residual rows (6), ring g+5 |
-// (epilogue).  A slab's pieces are issued two slabs ahead into a 3-slot ring; the two waits leave only younger requests in flight (17 and
-// more were issued behind the slab they wait for), the wait at the head step's start drains everything.
+// head step only the raw q rows wait in registers (48): its k and v rows go to wave-private LDS regions by LDS-DMA, in single pieces
+// spread over the whole head step (the kernel is bound by the rate at which HBM requests can be issued: ~11 bytes per cycle and CU).
+// Vector-memory order of a head step: wait(0) | S^T / softmax: the NEXT step's k pieces (4 per query group) | its q loads (12) | slab k:
+// ring slab g + 2 + k (4 pieces, every other macro-step), v pieces 3 k .. 3 k + 2 | slab 3 also: touches of the epilogue's residual rows (6)
+// | (epilogue).  A slab's pieces are issued two slabs ahead into a 3-slot ring; slabs 2, 3 wait with vmcnt(6) (8 and more requests are
+// younger than the slab they wait for), the wait at the head step's start drains everything.
 // ABL (diagnostic twins, ramp_bench_gemm only): bit 0 per-wave s_memtime sums of a head step's phases; bit 1 no k / v LDS-DMA, bit 2 no
 // ring LDS-DMA inside the slabs (wrong results)
 template <int NG, bool RB, int ABL = 0>
@@ -294,6 +294,10 @@ void ato_kernel(AtoArgs a, int n_tiles) {
       // exp2 of log2(e)-scaled logits; S^T / 8 with the operand scales undone
       const float ssc = 0.125f * 1.4426950408889634f / (sq * sk);
       __builtin_amdgcn_sched_barrier(0);
+      // the k region is free (its rows sit in registers as planes): the NEXT head step's k rows go there now, four pieces per query group,
+      // spread over the softmax -- the kernel is bound by the rate HBM requests can be issued at (one 1 KB piece per wave and ~360 cycles is
+      // what the memory system sustains); pieces issued in a burst, or only inside the projection's slabs, stall the wave at the issue
+      kv_tile = tile_n; kv_h = h_n;
 
       // ---- per query group: S^T = K Q^T (tiles (kg, qg), d = 64 = 2 k32 steps), P^T = softmax over keys (registers + lane groups),
       // masked to the query's own sample, scaled by 2^13 and split into its planes
@@ -319,6 +323,9 @@ void ato_kernel(AtoArgs a, int n_tiles) {
           }
           st[kg] = sv4;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_k_piece(4 * qg);
+        __builtin_amdgcn_sched_barrier(0);
         float mx = -3.0e38f;
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg)
@@ -330,6 +337,9 @@ void ato_kernel(AtoArgs a, int n_tiles) {
           }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        __builtin_amdgcn_sched_barrier(0);
+        dma_k_piece(4 * qg + 1);
+        __builtin_amdgcn_sched_barrier(0);
         float sum = 0.f;
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg)
@@ -341,11 +351,19 @@ void ato_kernel(AtoArgs a, int n_tiles) {
           }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_k_piece(4 * qg + 2);
+        __builtin_amdgcn_sched_barrier(0);
         const float inv = 8192.f * __builtin_amdgcn_rcpf(sum);               // (the sum's rcp: 1 ulp, a common factor of the column)
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg) { unsigned h0, h1, l0, l1; split4(st[kg] * inv, h0, h1, l0, l1); ph[kg][qg] = u32x2{h0, h1}; pl[kg][qg] = u32x2{l0, l1}; }
         __builtin_amdgcn_sched_barrier(0);
+        dma_k_piece(4 * qg + 3);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      // the next head step's q rows -> registers (12 loads; this step's are planes by now)
+      load_q(tile_n, h_n);
+      __builtin_amdgcn_sched_barrier(0);
 
       stamp(2);
       // ---- O^T = V^T P^T: tile (fb, qg), contraction over the keys: key groups (0, 1) as one k32 step, a third group as a second one
@@ -417,16 +435,15 @@ void ato_kernel(AtoArgs a, int n_tiles) {
     }
 
     // ================= output projection: the head's four slabs (output features [64 k, 64 k + 64)) =================
-    kv_tile = tile_n; kv_h = h_n;
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       stamp(k4 == 0 ? 3 : 5);
-      // slabs 2, 3 were requested during slabs 0, 1 of THIS step: at least 17 younger requests follow each of them
-      if (k4 >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      // slabs 2, 3 were requested during slabs 0, 1 of THIS step: at least 8 younger requests follow each of them (1 v piece behind the slab's
+      // last ring piece, 4 ring + 3 v pieces of the next slab)
+      if (k4 >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       __builtin_amdgcn_s_barrier();                         // slab gs is complete in LDS; every wave has left slab gs - 1
       stamp(4);
       ring_begin();                                         // slab gs + 2 goes into the slot of slab gs - 1 (past the last tile: bytes nobody reads)
-      if (k4 == 2) load_q(tile_n, h_n);
       if (k4 == 3) {
         // the tile's epilogue reads 48 KB of residual rows per wave: one dword of each of their 384 lines, so that its loads find them in
         // the L2 / MALL (as tklb_kernel touches its next operand chunk); every head step re-touches them, only the last matters
@@ -450,12 +467,8 @@ void ato_kernel(AtoArgs a, int n_tiles) {
         __builtin_amdgcn_sched_barrier(0);
         acc[nb][0] = mm32(wh, ol[0][j], acc[nb][0]);
         __builtin_amdgcn_sched_barrier(0);
-        if (m < 4 && !(ABL & 4)) ring_piece(m);
-        if (!(ABL & 2)) {
-          if (k4 == 0) dma_k_piece(m);                                            // k pieces 0-7
-          if (k4 == 1) { if (m < 4) dma_v_piece(m); else dma_k_piece(4 + m); }    // v pieces 0-3, k pieces 8-11
-          if (k4 == 2) dma_v_piece(4 + m);                                        // v pieces 4-11
-        }
+        if (!(m & 1) && !(ABL & 4)) ring_piece(m >> 1);                           // ring pieces at m = 0, 2, 4, 6
+        if (!(ABL & 2) && (m == 1 || m == 4 || m == 7) && 3 * k4 + m / 3 < T / 4) dma_v_piece(3 * k4 + m / 3);      // v pieces 3 k4 + (0, 1, 2)
         __builtin_amdgcn_sched_barrier(0);
         if (m + 1 < 8) {
           wf[(m + 1) & 1][0] = *reinterpret_cast<const u32x4*>(sl + ((m + 1) * 2) * 1024);

@@ -203,7 +203,7 @@ struct ramp_ctx {
                                      // kernels of ffx.hip, forward and backward (RAMP_FFX: 0 never, n that threshold)
   int tkl_min_rows = 65536;          // fp16x3 evaluations: K = 256 transformer linears (LN1 -> QKV, out-proj, d(o)) with at least this many
                                      // tokens run the token-owning kernel of tkl.hip (RAMP_TKL: 0 never, n that threshold)
-  int atk_min_rows = 16384;          // fp16x3 evaluations: self-attention + output projection as one launch of sample-owning waves (atk.hip)
+  int atk_min_rows = 40000;          // fp16x3 evaluations: self-attention + output projection as one launch of sample-owning waves (atk.hip)
                                      // from this many tokens where the level's token count divides 48 or 32 (RAMP_ATK: 0 never, n that threshold)
   int share_prefix = 1;              // sampling jobs: rows of one trajectory share the network prefix (RAMP_SHARE_PREFIX=0: off)
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3

@@ -593,6 +593,8 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("token-owning LN1 -> QKV (tkl)", 393216, 768, 256, 1, 1, 8, 1, False),
     ("token-owning out-projection with bias and residual (tkl)", 393216, 256, 256, 1, 1, 8, 2, False),
     ("token-owning d(ln1) with LayerNorm-1 backward (tklb)", 393216, 256, 768, 1, 1, 9, 0, False),
+    ("self-attention fused with the out-projection, L = 48 (atk)", 393216, 256, 256, 1, 48, 10, 1, False),
+    ("self-attention fused with the out-projection, L = 6 (atk)", 49152, 256, 256, 1, 6, 10, 1, False),
 ]
 
 

@@ -261,7 +261,15 @@ def test_token_owning_kernels_do_not_spill():
     assert one(tkl, "tklb_kernel")["vgpr_spill_count"] == 0                  # d(ln1) + LayerNorm-1 backward
     for pat in ("tkl_kernelILb0ELi1ELi0E", "tkl_kernelILb0ELi3ELi0E"):      # out-projection (residual, + row-variant constant)
         assert one(tkl, pat)["vgpr_spill_count"] <= 8
-    for d in (ffx, tkl):
+    # atk.hip (self-attention + output projection): the raw q rows / k, v LDS regions of the next head step are requested while the
+    # projection's MFMAs run; a scratch reload there drains them all.  Every product variant must be spill-free (the nested tile / head
+    # loops make it so at T = 48: as ONE flat loop hipcc spilled 150 values)
+    atk = _kernel_notes("atk.o")
+    prod = [k for k in atk if "ato_kernel" in k and k.split("ato_kernelILi")[1].split("E")[2].startswith("Li0")]
+    assert len(prod) == 4, list(atk)
+    for k in prod:
+        assert atk[k]["vgpr_spill_count"] == 0 and atk[k]["private_segment_fixed_size"] == 0, (k, atk[k])
+    for d in (ffx, tkl, atk):
         for k, v in d.items():
             assert v["vgpr_count"] <= 512, (k, v)
 
