@@ -62,7 +62,9 @@ typedef struct ramp_launch_plan {
   int32_t atk_rows;       /* self-attention + output projection (+ bias, cross-attention constant, residual) as ONE launch of
                            * sample-owning waves (atk.hip) from this many tokens, on levels whose token count divides 48 or 32:
                            * 0 never, 1 always */
-  int32_t reserved;
+  int32_t tkc_rows;       /* the k = 5 convolutions with C_in, C_out in {32, 64} (the two finest levels' residual blocks, the final block) and
+                           * their input gradients on sample-owning waves (tkc.hip) from this many tokens, on levels whose token count
+                           * (>= 8) divides 48 or 32: 0 never, 1 always */
 } ramp_launch_plan;
 int ramp_get_launch_plan(ramp_ctx* ctx, ramp_launch_plan* out);
 int ramp_set_launch_plan(ramp_ctx* ctx, const ramp_launch_plan* plan);

@@ -25,7 +25,7 @@ class RampConfig(C.Structure):
 class RampLaunchPlan(C.Structure):
     _fields_ = [("ff_fused_rows", C.c_int32), ("ffx_rows", C.c_int32), ("share_prefix", C.c_int32),
                 ("three_blocks", C.c_int32), ("x6_pipe", C.c_int32), ("tkl_rows", C.c_int32), ("atk_rows", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("tkc_rows", C.c_int32)]
 
 
 class RampApfParams(C.Structure):
@@ -172,7 +172,7 @@ def check(rc: int, what: str = "") -> None:
         raise RampHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
-GEMM_MODES = {"fp32": 0, "bf16x6": 1, "bf16x6-lds": 2, "fp16x3": 3, "fp16x3-dma": 4}       # ramp_op_gemm_mode
+GEMM_MODES = {"fp32": 0, "bf16x6": 1, "bf16x6-lds": 2, "fp16x3": 3, "fp16x3-dma": 4, "fp16x3-tkc": 5}       # ramp_op_gemm_mode
 
 
 def op_gemm(A, W, bias, resid, out, M, N, K, taps, shift0, step, L, mode="fp32", a_absmax_prev=0.0):

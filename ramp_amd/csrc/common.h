@@ -36,6 +36,27 @@ inline bool ranges_overlap(const void* a, size_t na, const void* b, size_t nb) {
   const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
   return x < y + nb && y < x + na;
 }
+// Record a wave's operand maximum.  READ_FIRST: a plain read of the slot, the atomic only where it would raise it -- in a launch of a few
+// tens of microseconds whose persistent blocks end together, 2048 same-address atomics serialize in the L2 at ~15 ns each (tkc.hip's
+// convolutions back to back: 35 -> 15 us); the read may be stale low (then an unnecessary atomic follows), never high: the slots only grow
+// between the zeroing launches of two evaluations.  In the long kernels the dependent read at the tail costs more than the atomics it
+// saves (same-box A/B of the whole job: -0.4 %), so they keep the unconditional atomic.
+#ifdef __HIPCC__
+template <bool READ_FIRST = false>
+__device__ __forceinline__ void record_amax(float* slot, float amax) {
+  if (!slot) return;
+  if (READ_FIRST) { if (amax > __builtin_nontemporal_load(slot)) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, amax)); }
+  else atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, amax));
+}
+// the 4 waves' maxima of a 256-thread block meet in 16 bytes of LDS (`scratch`: any LDS the block no longer uses), ONE atomic per block
+template <bool READ_FIRST = false>
+__device__ __forceinline__ void record_amax_block(float* slot, float wave_amax, float* scratch) {
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = wave_amax;
+  __syncthreads();
+  if (threadIdx.x == 0) record_amax<READ_FIRST>(slot, fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3])));
+}
+#endif
 // compute units of the current device (hipDeviceProp_t::multiProcessorCount, cached per device): the token-owning kernels
 // launch one 4-wave block per CU
 int device_cu_count();
@@ -182,6 +203,27 @@ bool ato_applicable(int M, int L, int* ng);
 int launch_ato(const AtoArgs& a, hipStream_t s);
 int ato_pack(const float* W /*[256][256] fp32, device*/, float scale, unsigned short* out /*8 * 32 KB*/, hipStream_t s);
 int init_atk_attributes();
+
+// ---- Conv1d(k = 5, padding 2) with C_in, C_out in {32, 64} as sample-owning waves (tkc.hip) ---------------------------------------------
+// Y[m][n] = sum_tap sum_k X[m + dir (tap - 2)][k] W[tap][n][k] (+ bias[n]) (+ resid[m][n]) (+ resid2[m][n]); rows outside m's sample of L
+// tokens read as zero.  dir = +1: the forward convolution; -1: its input gradient (W = the transposed weight, same tap order).  fp16x3
+// products, delayed scale / maxima / range guard of ONE call site.  L >= 8 must divide 48 or 32 (tkc_applicable).
+struct TkcArgs {
+  int M = 0, L = 0, N = 0, K = 0, dir = 1;
+  const float* X = nullptr; int ldx = 0;
+  const unsigned short* W = nullptr;   // tkc_pack: [tap][N / 16][K / 32][plane][lane][8] fp16
+  const float* bias = nullptr;
+  const float* resid = nullptr; int ldr = 0;
+  const float* resid2 = nullptr; int ldr2 = 0;
+  float* Y = nullptr; int ldy = 0;
+  const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;
+  int* range_flag = nullptr;
+};
+bool tkc_applicable(int M, int L, int N, int K, int* ng);
+int launch_tkc(const TkcArgs& a, hipStream_t s);
+int tkc_pack(const float* W /*[5][N][K] fp32, device*/, int N, int K, float scale, unsigned short* out, hipStream_t s);
+size_t tkc_packed_halves(int N, int K);
+int init_tkc_attributes();
 
 // ---- row-wise ops (rowops.hip) --------------------------------------------------------------
 // GroupNorm over (L, C/8) per (row, group) [+ Mish] [+ per-channel time bias] [+ residual]

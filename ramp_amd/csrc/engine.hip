@@ -205,6 +205,10 @@ struct ramp_ctx {
                                      // tokens run the token-owning kernel of tkl.hip (RAMP_TKL: 0 never, n that threshold)
   int atk_min_rows = 40000;          // fp16x3 evaluations: self-attention + output projection as one launch of sample-owning waves (atk.hip)
                                      // from this many tokens where the level's token count divides 48 or 32 (RAMP_ATK: 0 never, n that threshold)
+  int tkc_min_rows = 16384;          // fp16x3 evaluations: the k = 5 convolutions with C_in, C_out in {32, 64} as sample-owning waves (tkc.hip) from this
+                                     // many tokens, on levels whose token count (>= 8) divides 48 or 32 (RAMP_TKC: 0 never, n that threshold)
+  struct TkcW { unsigned short* planes; float wsi; };
+  std::map<const float*, TkcW> tkc_w;                       // fp32 conv weight [5][N][K] -> its tkc planes
   int share_prefix = 1;              // sampling jobs: rows of one trajectory share the network prefix (RAMP_SHARE_PREFIX=0: off)
   int force_x6 = 0;                  // ramp_set_fallback: run ramp_sample entirely in bf16x6 although the mode is fp16x3
   // single evaluations (ramp_score): the tables of the last evaluation stay valid as the next one's calibration
@@ -400,7 +404,31 @@ struct Run {
     c->site++;
     return kind;
   }
+  // a k = 5 convolution with C_in, C_out in {32, 64} on the sample-owning kernel (tkc.hip): in the calibration evaluation too (unscaled
+  // operand, maximum recorded), so that the call sites number the same in every fp16x3 evaluation of a job
+  const ramp_ctx::TkcW* tkc_planes(const GemmArgs& a) const {
+    if (!(c->tkc_min_rows > 0 && a.M >= c->tkc_min_rows && c->gemm_mode == 2 && (c->phase == 1 || c->phase == 2) && !c->force_x6 && c->x6_pipe)) return nullptr;
+    if (!(a.taps == 5 && !a.A2 && !a.Amul && !a.C2 && !a.rowbias && a.epi == EPI_LINEAR && a.a_stride == 1 && a.c_rstride == 1 && a.c_roff == 0)) return nullptr;
+    if (!((a.shift0 == -2 && a.shift_step == 1) || (a.shift0 == 2 && a.shift_step == -1))) return nullptr;
+    if (!tkc_applicable(a.M, a.L, a.N, a.K, nullptr)) return nullptr;
+    auto it = c->tkc_w.find(a.W);
+    return it == c->tkc_w.end() ? nullptr : &it->second;
+  }
+  int tkc(const GemmArgs& a, const ramp_ctx::TkcW& w) {
+    RAMP_REQUIRE(c->site < ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
+    prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, -5});
+    TkcArgs t; t.M = a.M; t.L = a.L; t.N = a.N; t.K = a.K; t.dir = a.shift_step; t.X = a.A; t.ldx = a.lda; t.W = w.planes; t.bias = a.bias;
+    t.resid = a.resid; t.ldr = a.ldr; t.resid2 = a.resid2; t.ldr2 = a.ldr2; t.Y = a.C; t.ldy = a.ldc;
+    t.amax_in = c->phase == 2 ? c->obs_in + c->site : nullptr; t.amax_out = c->obs_out + c->site; t.wsi = w.wsi; t.site = c->site;
+    t.range_flag = c->range_flag;
+    c->site++;
+    int rc = launch_tkc(t, s);
+    prof_post(c, s);
+    c->launches++;
+    return rc;
+  }
   int gemm(const GemmArgs& a) {
+    if (const ramp_ctx::TkcW* w = tkc_planes(a)) return tkc(a, *w);
     prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, a.taps});
     GemmArgs b = a;
     b.three_ok = c->three_blocks;
@@ -1051,6 +1079,8 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
     if (xe) c->ffx_min_rows = atoi(xe);
     const char* ke = getenv("RAMP_TKL");
     if (ke) c->tkl_min_rows = atoi(ke);
+    const char* tce = getenv("RAMP_TKC");
+    if (tce) c->tkc_min_rows = atoi(tce);
     const char* ate = getenv("RAMP_ATK");
     if (ate) c->atk_min_rows = atoi(ate);
     const char* se = getenv("RAMP_SHARE_PREFIX");
@@ -1076,17 +1106,18 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
 
 int ramp_get_launch_plan(ramp_ctx* c, ramp_launch_plan* out) {
   RAMP_REQUIRE(c && out, "null argument");
-  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, c->tkl_min_rows, c->atk_min_rows, 0};
+  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, c->tkl_min_rows, c->atk_min_rows, c->tkc_min_rows};
   return 0;
 }
 int ramp_set_launch_plan(ramp_ctx* c, const ramp_launch_plan* p) {
   RAMP_REQUIRE(c && p, "null argument");
-  RAMP_REQUIRE(p->ff_fused_rows >= 0 && p->ffx_rows >= 0 && p->tkl_rows >= 0 && p->atk_rows >= 0, "row thresholds must be >= 0");
+  RAMP_REQUIRE(p->ff_fused_rows >= 0 && p->ffx_rows >= 0 && p->tkl_rows >= 0 && p->atk_rows >= 0 && p->tkc_rows >= 0, "row thresholds must be >= 0");
   RAMP_REQUIRE(!c->finalized || (p->x6_pipe != 0) == (c->x6_pipe != 0), "x6_pipe is fixed once the weights are packed (ramp_finalize_weights)");
   const bool changed = p->ff_fused_rows != c->ff_fused || p->ffx_rows != c->ffx_min_rows || (p->share_prefix != 0) != (c->share_prefix != 0) ||
-                       (p->three_blocks != 0) != (c->three_blocks != 0) || p->tkl_rows != c->tkl_min_rows || p->atk_rows != c->atk_min_rows;
+                       (p->three_blocks != 0) != (c->three_blocks != 0) || p->tkl_rows != c->tkl_min_rows || p->atk_rows != c->atk_min_rows ||
+                       p->tkc_rows != c->tkc_min_rows;
   c->ff_fused = p->ff_fused_rows; c->ffx_min_rows = p->ffx_rows; c->tkl_min_rows = p->tkl_rows; c->share_prefix = p->share_prefix != 0;
-  c->atk_min_rows = p->atk_rows;
+  c->atk_min_rows = p->atk_rows; c->tkc_min_rows = p->tkc_rows;
   c->three_blocks = p->three_blocks != 0; c->x6_pipe = p->x6_pipe != 0;
   if (changed && c->finalized) {   // other kernels from here on: captured graphs and kept calibrations belong to the old plan
     c->graph_key.clear(); c->r_key.clear();
@@ -1295,6 +1326,29 @@ int ramp_finalize_weights(ramp_ctx* c) {
           CK(ato_pack(k.wo_f, 1.f / eo.w_scale_inv, k.ato_w, 0));
         }
     }
+    if (c->gemm_mode == 2 && c->x6_pipe) {
+      // fragment planes of the narrow k = 5 convolutions (tkc.hip), forward and input-gradient weights: static power-of-two scale,
+      // max |w| -> [2^10, 2^11) like every other fp16x3 weight
+      auto reg_tkc = [&](const float* w, int N, int K) -> int {
+        if (!w || c->tkc_w.count(w) || !((N == 32 || N == 64) && (K == 32 || K == 64))) return 0;
+        const size_t n = 5ul * N * K;
+        std::vector<float> hw(n);
+        RAMP_HIP_CHECK(hipMemcpy(hw.data(), w, n * sizeof(float), hipMemcpyDeviceToHost));
+        float mx = 0.f;
+        for (float v : hw) mx = std::max(mx, std::fabs(v));
+        float sc = 1.f;
+        if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
+        float* q; CK(dev_alloc(c, &q, tkc_packed_halves(N, K) / 2 + 4));
+        CK(tkc_pack(w, N, K, sc, reinterpret_cast<unsigned short*>(q), 0));
+        c->tkc_w[w] = {reinterpret_cast<unsigned short*>(q), 1.f / sc};
+        return 0;
+      };
+      for (auto& r : c->rtbs) {
+        if (!r.first) { CK(reg_tkc(r.c1.fwd, r.cout, r.cin)); CK(reg_tkc(r.c1.bwd, r.cin, r.cout)); }
+        CK(reg_tkc(r.c2.fwd, r.cout, r.cout)); CK(reg_tkc(r.c2.bwd, r.cout, r.cout));
+      }
+      CK(reg_tkc(c->final_conv.fwd, C0, C0)); CK(reg_tkc(c->final_conv.bwd, C0, C0));
+    }
     for (auto& d : c->downs) { CK(reg(d.w_f, 3ul * d.C * d.C, d.C)); CK(reg(d.w_b, 3ul * d.C * d.C, d.C)); }
     for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C, u.C)); CK(reg(u.w_b, 4ul * u.C * u.C, u.C)); }
   }
@@ -1305,6 +1359,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
   CK(init_ffx_attributes());
   CK(init_tkl_attributes());
   CK(init_atk_attributes());
+  CK(init_tkc_attributes());
   c->finalized = true;
   return 0;
 }
@@ -1948,8 +2003,38 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
                       int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step, int32_t L, int32_t mode,
                       float a_absmax_prev, float* a_absmax_out_host, int32_t* range_flag_out_host, void* stream) {
   RAMP_REQUIRE(A && W && C, "null argument");
-  RAMP_REQUIRE(mode >= 0 && mode <= 4, "mode: 0 fp32, 1 bf16x6, 2 bf16x6 (LDS-staged weights), 3 fp16x3, 4 fp16x3 through the LDS-DMA ring");
+  RAMP_REQUIRE(mode >= 0 && mode <= 5, "mode: 0 fp32, 1 bf16x6, 2 bf16x6 (LDS-staged weights), 3 fp16x3, 4 fp16x3 through the LDS-DMA ring, 5 fp16x3 "
+                                       "sample-owning k = 5 convolution (tkc.hip)");
   hipStream_t s = as_stream(stream);
+  if (mode == 5) {
+    RAMP_REQUIRE(taps == 5 && ((shift0 == -2 && shift_step == 1) || (shift0 == 2 && shift_step == -1)) && tkc_applicable(M, L, N, K, nullptr),
+                 "mode 5: a k = 5 convolution (or its input gradient) with C_in, C_out in {32, 64}, L >= 8 dividing 48 or 32");
+    DevArena ar;
+    std::vector<float> hw((size_t)5 * N * K);
+    RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
+    float mx = 0.f; for (float v : hw) mx = std::max(mx, std::fabs(v));
+    float sc = 1.f;
+    if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
+    unsigned short* pl = reinterpret_cast<unsigned short*>(ar.alloc(tkc_packed_halves(N, K) / 2 + 4));
+    float* sl = ar.alloc(4);
+    RAMP_REQUIRE(pl && sl, "hipMalloc failed");
+    CK(init_tkc_attributes());
+    CK(tkc_pack(W, N, K, sc, pl, s));
+    const float v[4] = {a_absmax_prev, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(sl, v, 16, hipMemcpyHostToDevice, s));
+    TkcArgs t; t.M = M; t.L = L; t.N = N; t.K = K; t.dir = shift_step; t.X = A; t.ldx = K; t.W = pl; t.bias = bias; t.resid = resid; t.ldr = N;
+    t.Y = C; t.ldy = N; t.amax_in = a_absmax_prev > 0.f ? sl : nullptr; t.amax_out = sl + 1; t.wsi = 1.f / sc; t.range_flag = reinterpret_cast<int*>(sl + 2);
+    int rc5 = launch_tkc(t, s);
+    hipError_t e5 = hipStreamSynchronize(s);
+    float back[4] = {0, 0, 0, 0};
+    if (rc5 == 0 && e5 == hipSuccess) {
+      e5 = hipMemcpy(back, sl, sizeof(back), hipMemcpyDeviceToHost);
+      if (a_absmax_out_host) *a_absmax_out_host = back[1];
+      if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
+    }
+    RAMP_HIP_CHECK(e5);
+    return rc5;
+  }
   GemmArgs a; a.A = A; a.lda = K; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.C = C; a.ldc = N;
   a.M = M; a.N = N; a.K = K; a.taps = taps; a.shift0 = shift0; a.shift_step = shift_step; a.L = L;
   const long n = (long)taps * N * K;
@@ -2235,7 +2320,39 @@ thread_local StressHook* g_stress = nullptr;
 
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 11, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 12, "bad arguments");
+  if (mode == 12) {                                    // tkc.hip: k = 5 convolution with C_in, C_out in {32, 64} on sample-owning waves; flags 1 bias, 2 residual, 4 input gradient
+    hipStream_t sc = as_stream(stream);
+    DevArena arc;
+    RAMP_REQUIRE(taps == 5 && tkc_applicable(M, L, N, K, nullptr), "mode 12: k = 5, C in {32, 64}, L >= 8 dividing 48 or 32");
+    float* X = arc.alloc((size_t)M * K); float* Y = arc.alloc((size_t)M * N); float* R = arc.alloc((size_t)M * N); float* W = arc.alloc((size_t)5 * N * K);
+    float* b = arc.alloc(N); float* sl = arc.alloc(4);
+    unsigned short* pl = reinterpret_cast<unsigned short*>(arc.alloc(tkc_packed_halves(N, K) / 2 + 4));
+    RAMP_REQUIRE(X && Y && R && W && b && sl && pl, "hipMalloc failed");
+    auto fill = [&](float* p, size_t n, unsigned seed, float scv) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sc, p, (long)n, seed, scv); };
+    fill(X, (size_t)M * K, 1u, 1.f); fill(R, (size_t)M * N, 4u, 1.f); fill(W, (size_t)5 * N * K, 2u, 1.f / 16.f); fill(b, N, 5u, 1.f);
+    CK(init_tkc_attributes());
+    CK(tkc_pack(W, N, K, 16384.f, pl, sc));
+    const float one[4] = {1.f, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, sc));
+    TkcArgs t; t.M = M; t.L = L; t.N = N; t.K = K; t.dir = (flags & 4) ? -1 : 1; t.X = X; t.ldx = K; t.W = pl; t.Y = Y; t.ldy = N;
+    if (flags & 1) t.bias = b;
+    if (flags & 2) { t.resid = R; t.ldr = N; }
+    t.amax_in = sl; t.amax_out = sl + 1; t.wsi = 1.f / 16384.f; t.range_flag = reinterpret_cast<int*>(sl + 2);
+    for (int i = 0; i < warmup; ++i) CK(launch_tkc(t, sc));
+    hipEvent_t e0, e1;
+    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+    RAMP_HIP_CHECK(hipEventRecord(e0, sc));
+    int rcc = 0;
+    for (int i = 0; i < iters && rcc == 0; ++i) { rcc = launch_tkc(t, sc); if (rcc == 0) STRESS(Y, (size_t)M * N, sc); }
+    RAMP_HIP_CHECK(hipEventRecord(e1, sc));
+    RAMP_HIP_CHECK(hipEventSynchronize(e1));
+    float msc = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&msc, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = msc * 1e3f / iters;
+    return rcc;
+  }
   if (mode == 10 || mode == 11) {                      // atk.hip: self-attention + out-projection in one launch (10) / the pair it replaces:
                                                        // attn2_fwd + token-owning out-projection (11).  L = tokens per sample; flags 1: row-variant constant
     hipStream_t sa = as_stream(stream);

@@ -526,9 +526,9 @@ void ffx_kernel(FfxArgs f, int n_mt) {
   // ---- maxima for the next evaluation's scales, range guard (as in gemm_x6p_body.inc) ---------------------------------
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { amax1 = fmaxf(amax1, __shfl_xor(amax1, o)); amax2 = fmaxf(amax2, __shfl_xor(amax2, o)); }
+  record_amax_block(f.amax_out1, amax1, reinterpret_cast<float*>(smem));      // (no LDS-DMA in flight: vmcnt(0) above)
+  record_amax_block(f.amax_out2, amax2, reinterpret_cast<float*>(smem) + 4);
   if (lane == 0) {
-    if (f.amax_out1) atomicMax(reinterpret_cast<unsigned*>(f.amax_out1), __builtin_bit_cast(unsigned, amax1));
-    if (f.amax_out2) atomicMax(reinterpret_cast<unsigned*>(f.amax_out2), __builtin_bit_cast(unsigned, amax2));
     if (f.range_flag) {
       if (!(amax1 * s_1 < 60000.f) || (amax1 > 0.f && amax1 * s_1 < 0.125f)) atomicMax(f.range_flag, f.site1 + 1);
       if (!(amax2 * s_2 < 60000.f) || (amax2 > 0.f && amax2 * s_2 < 0.125f)) atomicMax(f.range_flag, f.site2 + 1);

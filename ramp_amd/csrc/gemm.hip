@@ -1224,7 +1224,7 @@ void ff_fwd_kernel(FfFwdArgs f, int n_mtiles) {
     if (lane == 0) {
       const GemmArgs& g = G1 ? a : b;
       const float sc = G1 ? s_a : s_h;
-      if (g.a_absmax_out) atomicMax(reinterpret_cast<unsigned*>(g.a_absmax_out), __builtin_bit_cast(unsigned, mx));
+      record_amax(g.a_absmax_out, mx);
       if (g.range_flag && (!(mx * sc < 60000.f) || (mx > 0.f && mx * sc < 0.125f))) atomicMax(g.range_flag, g.site_id + 1);
     }
   }

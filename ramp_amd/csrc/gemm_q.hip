@@ -261,7 +261,7 @@ void split_planes_kernel(const float* __restrict__ A, int lda, unsigned short* _
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
   if ((threadIdx.x & 63) == 0) {
-    if (absmax_out) atomicMax(reinterpret_cast<unsigned*>(absmax_out), __builtin_bit_cast(unsigned, amax));
+    record_amax(absmax_out, amax);
     if (range_flag && (!(amax * s_a < 60000.f) || (amax > 0.f && amax * s_a < 0.125f))) atomicMax(range_flag, site_id + 1);
   }
 }

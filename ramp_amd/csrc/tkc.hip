@@ -1,0 +1,268 @@
+// Conv1d(k = 5, padding 2) of the narrow residual blocks (C_in, C_out <= 64) as SAMPLE-OWNING waves: the convolutions of
+// ResidualTemporalBlock / Conv1dBlock at the two finest levels and the final block (layers.py:280-297, 327-361; UnetInference.py:142-145)
+// and their input gradients (the same operator with the taps reversed and the weight transposed).
+//
+// Why its own kernel.  On the 128-wide tile kernels these layers waste half (N = 64) or three quarters (N = 32, exact-fp32 MFMA) of every
+// tile and run at 53-90 TFLOP/s; they carry 10 KFLOP-40 KFLOP per token against 256-512 bytes, i.e. they are HBM-bound work.  Here a wave owns
+// T = 48 (or 32) consecutive tokens = whole samples of L tokens (L | T), so the zero padding of the convolution is wave-local: the wave's rows
+// go, split into two scaled fp16 planes, into a wave-private LDS tile with two zero rows on either side of every sample; tap j of the
+// convolution is the SAME tile read one row further (the B operand of v_mfma_f32_16x16x32_f16: lane (c, g) = channels 32 j' + 8 g .. of token
+// c's shifted row).  The whole weight (5 taps x C_out x C_in as fp16 fragment planes, <= 80 KB) is resident in LDS for the block's lifetime --
+// no ring, no barrier after the prologue.  D^T[c_out][token] accumulates in 16 x 16 tiles; the next tile's rows are fetched into registers
+// while the current tile computes.  fp16x3 products, delayed operand scale / maxima / range guard of ONE call site, like every other GEMM.
+#include "common.h"
+#include "tokmma.h"
+
+#include <algorithm>
+
+namespace ramp {
+
+namespace {
+
+constexpr int TC_XROWS = 48 + 4 * 6;                    // rows of a wave's tile: T tokens + 4 zero rows per sample (L >= 8: at most 6 samples)
+
+__device__ __forceinline__ f32x4 tc_mm32(const u32x4 a, const u32x4 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void tc_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace
+
+// W [5][N][K] fp32 (tap, c_out, c_in) -> out [tap][N / 16][K / 32][plane 2][lane 64][8 halves]: the A fragment of v_mfma_f32_16x16x32_f16
+// (lane (r, kq): row 16 nb + r, k = 32 j + 8 kq .. + 7)
+__global__ void tkc_pack_kernel(const float* __restrict__ W, unsigned short* __restrict__ out, int N, int K, float scale) {
+  const int total = 5 * (N / 16) * (K / 32) * 64;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, f = idx >> 6;
+  const int j = f % (K / 32), nb = (f / (K / 32)) % (N / 16), tap = f / ((K / 32) * (N / 16));
+  const float* src = W + ((long)tap * N + 16 * nb + (lane & 15)) * K + 32 * j + 8 * (lane >> 4);
+  unsigned short* o = out + (long)f * 1024 + lane * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = src[e] * scale;
+    const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+    o[e] = __builtin_bit_cast(unsigned short, hi); o[512 + e] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+int tkc_pack(const float* W, int N, int K, float scale, unsigned short* out, hipStream_t s) {
+  RAMP_REQUIRE(W && out && N % 16 == 0 && K % 32 == 0 && N >= 16 && N <= 64 && K >= 32 && K <= 64, "tkc_pack: bad shape");
+  const int total = 5 * (N / 16) * (K / 32) * 64;
+  hipLaunchKernelGGL(tkc_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, out, N, K, scale);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+size_t tkc_packed_halves(int N, int K) { return (size_t)5 * (N / 16) * (K / 32) * 1024; }
+
+// NG: 16-token groups per wave; NB = N / 16 output blocks; KS = K / 32 k32 steps
+template <int NG, int NB, int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void tkc_kernel(TkcArgs a, int n_tiles) {
+  constexpr int T = 16 * NG, K = 32 * KS, N = 16 * NB;
+  constexpr int XROW = 4 * K + 16;                          // bytes of a tile row: hi plane (2 K) | lo plane (2 K) | 16 bytes of padding (bank spread)
+  constexpr int WBYTES = 5 * NB * KS * 2048;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int n_my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+  const float s_in = scale_of(a.amax_in);
+  const float os = a.wsi / s_in;
+  float amax = 0.f;
+
+  // ---- prologue: the weight planes -> LDS (once), the wave's tile zeroed (its padding rows stay zero for the block's lifetime)
+  for (int i = tid; i < WBYTES / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = reinterpret_cast<const u32x4*>(a.W)[i];
+  char* xt = smem + WBYTES + wave * (TC_XROWS * XROW);
+  for (int i = lane; i < TC_XROWS * XROW / 16; i += 64) reinterpret_cast<u32x4*>(xt)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  // rows of the wave's tokens in its tile: token t of sample s = t / L sits in row t + 4 s + 2
+  int xrow[NG];
+#pragma unroll
+  for (int t = 0; t < NG; ++t) xrow[t] = (16 * t + c) + 4 * ((16 * t + c) / a.L) + 2;
+  const int m_last = a.M - 1;
+  const char* xbase = reinterpret_cast<const char*>(a.X);
+
+  // raw rows of a tile: lane (c, g) holds channels 16 fb + 4 g .. + 3 of token 16 t + c
+  f32x4 xr[K / 16][NG];
+  auto load_x = [&](int tile) __attribute__((always_inline)) {
+    int tk0 = tile * (4 * T) + wave * T + c;
+    asm volatile("" : "+v"(tk0));
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+      const char* row = xbase + ((size_t)(unsigned)min(tk0 + 16 * t, m_last) * (unsigned)(4 * a.ldx) + 16u * (unsigned)g);
+#pragma unroll
+      for (int fb = 0; fb < K / 16; ++fb) xr[fb][t] = *reinterpret_cast<const f32x4*>(row + 64 * fb);
+    }
+  };
+  load_x((int)blockIdx.x);
+
+#pragma unroll 1
+  for (int ti = 0; ti < n_my; ++ti) {
+    const int tile = (int)blockIdx.x + ti * (int)gridDim.x;
+    const int tile_n = ti + 1 < n_my ? tile + (int)gridDim.x : tile;
+    const int tok0 = tile * (4 * T) + wave * T;
+    const bool full = tok0 + T <= a.M;
+
+    // ---- rows -> recorded maximum, two scaled fp16 planes -> the wave's LDS tile
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+      const float lm = (full || tok0 + 16 * t + c < a.M) ? 1.f : 0.f;      // tokens past M: zero rows (they are neighbours of nobody: whole samples)
+      char* dst = xt + xrow[t] * XROW + 8 * g;
+#pragma unroll
+      for (int fb = 0; fb < K / 16; ++fb) {
+        const f32x4 v = xr[fb][t] * lm;
+        amax = amax4(v, amax);
+        unsigned h0, h1, l0, l1;
+        split4(v * s_in, h0, h1, l0, l1);
+        *reinterpret_cast<u32x2*>(dst + 32 * fb) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(dst + 2 * K + 32 * fb) = u32x2{l0, l1};
+      }
+    }
+    tc_wave_sync();
+    load_x(tile_n);                                         // the next tile's rows: in flight during this tile's products
+
+    // ---- D^T[c_out][token] = sum_tap W_tap X_shifted^T: tap j reads the tile dir * (j - 2) rows further
+    f32x4 acc[NB][NG];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int t = 0; t < NG; ++t) acc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 5; ++tap) {
+      const int sh = a.dir * (tap - 2);
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        u32x4 bh[NG], bl[NG];
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+          const char* p = xt + (xrow[t] + sh) * XROW + 64 * j + 16 * g;
+          bh[t] = *reinterpret_cast<const u32x4*>(p);
+          bl[t] = *reinterpret_cast<const u32x4*>(p + 2 * K);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const char* wp = smem + ((tap * NB + nb) * KS + j) * 2048 + lane * 16;
+          const u32x4 wh = *reinterpret_cast<const u32x4*>(wp), wl = *reinterpret_cast<const u32x4*>(wp + 1024);
+#pragma unroll
+          for (int t = 0; t < NG; ++t) {
+            f32x4 v = acc[nb][t];
+            v = tc_mm32(wh, bl[t], v);
+            v = tc_mm32(wl, bh[t], v);
+            v = tc_mm32(wh, bh[t], v);
+            acc[nb][t] = v;
+          }
+        }
+      }
+    }
+    tc_wave_sync();                                         // (the tile is rewritten at the top of the next iteration)
+
+    // ---- epilogue: y[tok][16 nb + 4 g ..] = acc * os + bias + resid + resid2.  Full wave tiles: every load first, every store unconditional
+    // (a store behind a per-lane predicate sits in its own basic block behind s_waitcnt vmcnt(0): one memory round trip per store)
+    {
+      unsigned trow[NG];
+#pragma unroll
+      for (int t = 0; t < NG; ++t) trow[t] = (unsigned)min(tok0 + 16 * t + c, m_last);
+      f32x4 bq[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bq[nb] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + 16 * nb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (full) {
+        f32x4 rz[NB][NG];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int t = 0; t < NG; ++t) rz[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.resid) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < NG; ++t) rz[nb][t] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)trow[t] * a.ldr + 16 * nb + 4 * g);
+        }
+        if (a.resid2) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < NG; ++t) rz[nb][t] += *reinterpret_cast<const f32x4*>(a.resid2 + (size_t)trow[t] * a.ldr2 + 16 * nb + 4 * g);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int t = 0; t < NG; ++t) *reinterpret_cast<f32x4*>(a.Y + (size_t)trow[t] * a.ldy + 16 * nb + 4 * g) = acc[nb][t] * os + bq[nb] + rz[nb][t];
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int t = 0; t < NG; ++t) {
+            f32x4 v = acc[nb][t] * os + bq[nb];
+            if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)trow[t] * a.ldr + 16 * nb + 4 * g);
+            if (a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + (size_t)trow[t] * a.ldr2 + 16 * nb + 4 * g);
+            if (tok0 + 16 * t + c < a.M) *reinterpret_cast<f32x4*>(a.Y + (size_t)trow[t] * a.ldy + 16 * nb + 4 * g) = v;
+          }
+      }
+    }
+  }
+
+  amax = fmaxf(amax, __shfl_xor(amax, 32)); amax = fmaxf(amax, __shfl_xor(amax, 16)); amax = fmaxf(amax, __shfl_xor(amax, 8));
+  amax = fmaxf(amax, __shfl_xor(amax, 4)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 1));
+  // ONE atomic per block, behind a plain read of the slot (2048 same-address atomics at the tail of a 20-40 us launch cost 20 us: common.h)
+  __syncthreads();
+  record_amax_block<true>(a.amax_out, amax, reinterpret_cast<float*>(smem + WBYTES));
+  if (lane == 0) {
+    if (a.range_flag && (!(amax * s_in < 60000.f) || (amax > 0.f && amax * s_in < 0.125f))) atomicMax(a.range_flag, a.site + 1);
+  }
+}
+
+bool tkc_applicable(int M, int L, int N, int K, int* ng) {
+  int n = 0;
+  if (L >= 8 && 48 % L == 0) n = 3; else if (L >= 8 && 32 % L == 0) n = 2;
+  if (ng) *ng = n;
+  return n != 0 && M > 0 && M % L == 0 && (N == 32 || N == 64) && (K == 32 || K == 64);
+}
+
+namespace {
+template <int NG, int NB, int KS> size_t tkc_lds() { return (size_t)5 * NB * KS * 2048 + 4 * (size_t)TC_XROWS * (4 * 32 * KS + 16); }
+template <int NG, int NB, int KS> int tkc_go(const TkcArgs& a, int n_tiles, hipStream_t s) {
+  const size_t lds = tkc_lds<NG, NB, KS>();
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;         // blocks the LDS lets a CU hold (a block pays an 20-80 KB weight prologue: no more blocks than stay resident)
+  const int nb = std::min(n_tiles, per_cu * device_cu_count());
+  hipLaunchKernelGGL((tkc_kernel<NG, NB, KS>), dim3(nb), dim3(256), lds, s, a, n_tiles);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int launch_tkc(const TkcArgs& a, hipStream_t s) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  int ng = 0;
+  RAMP_REQUIRE(tkc_applicable(a.M, a.L, a.N, a.K, &ng), "tkc: C_in, C_out in {32, 64}, tokens per sample >= 8 dividing 48 or 32, whole samples");
+  RAMP_REQUIRE(a.X && a.W && a.Y && (a.dir == 1 || a.dir == -1), "tkc: bad operand");
+  RAMP_REQUIRE(al16(a.X) && al16(a.W) && al16(a.Y) && al16(a.bias) && al16(a.resid) && al16(a.resid2) && a.ldx % 4 == 0 && a.ldy % 4 == 0 &&
+               a.ldr % 4 == 0 && a.ldr2 % 4 == 0 && a.ldx >= a.K && a.ldy >= a.N, "tkc: operands must be 16-byte aligned");
+  RAMP_REQUIRE((long)a.M * a.ldx * 4 < (1l << 32), "tkc: 32-bit row offsets");
+  RAMP_REQUIRE(!ranges_overlap(a.Y, ((size_t)(a.M - 1) * a.ldy + a.N) * 4, a.X, ((size_t)(a.M - 1) * a.ldx + a.K) * 4), "tkc: the output must not overlap the operand");
+  const int T = 16 * ng, n_tiles = (a.M + 4 * T - 1) / (4 * T);
+#define TC_CASE(NGV) \
+  if (ng == NGV) { \
+    if (a.N == 64 && a.K == 64) return tkc_go<NGV, 4, 2>(a, n_tiles, s); \
+    if (a.N == 64 && a.K == 32) return tkc_go<NGV, 4, 1>(a, n_tiles, s); \
+    if (a.N == 32 && a.K == 64) return tkc_go<NGV, 2, 2>(a, n_tiles, s); \
+    return tkc_go<NGV, 2, 1>(a, n_tiles, s); \
+  }
+  TC_CASE(3) TC_CASE(2)
+#undef TC_CASE
+  RAMP_REQUIRE(false, "tkc: variant not built");
+}
+
+int init_tkc_attributes() {
+#define TC_ATTR(NGV, NBV, KSV) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tkc_kernel<NGV, NBV, KSV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tkc_lds<NGV, NBV, KSV>()))
+  TC_ATTR(3, 4, 2); TC_ATTR(3, 4, 1); TC_ATTR(3, 2, 2); TC_ATTR(3, 2, 1);
+  TC_ATTR(2, 4, 2); TC_ATTR(2, 4, 1); TC_ATTR(2, 2, 2); TC_ATTR(2, 2, 1);
+#undef TC_ATTR
+  return 0;
+}
+
+}  // namespace ramp

@@ -521,6 +521,48 @@ def test_tklb_dln1_with_layernorm_backward_against_float64_autograd(M):
     assert flag.value == 1, flag.value
 
 
+@pytest.mark.parametrize("L,R,N,K,extras", [(48, 3, 32, 32, True), (48, 9, 64, 64, True), (24, 7, 64, 32, False), (24, 8, 32, 64, True), (12, 33, 64, 64, True),
+                                            (16, 5, 64, 64, False), (32, 3, 32, 32, True), (8, 41, 64, 64, True), (48, 4096, 32, 32, True)])
+@pytest.mark.parametrize("backward", [False, True])
+def test_tkc_narrow_convolution_against_float64(L, R, N, K, extras, backward):
+    """The k = 5 convolutions with C_in, C_out in {32, 64} on sample-owning waves (tkc.hip, ramp_op_gemm_mode 5): Conv1d(padding 2) inside
+    every sample of L tokens (layers.py:280-297) and its input gradient (taps reversed), with bias + residual, against float64; sample counts
+    that leave the last wave / block partly empty; the recorded operand maximum is the true one, scaling from it leaves the result unchanged
+    to rounding, a stale maximum raises the range flag."""
+    M = L * R
+    g = rng(L * 1000 + R + N + K + backward)
+    A = (g.standard_normal((M, K), dtype=np.float32) * 1.7 + 0.1).astype(np.float32)
+    W = (g.standard_normal((5, N, K), dtype=np.float32) / np.sqrt(5 * K)).astype(np.float32)
+    bias = g.standard_normal(N, dtype=np.float32) if extras else None
+    resid = g.standard_normal((M, N), dtype=np.float32) if extras else None
+    shift0, step = (2, -1) if backward else (-2, 1)
+    ref = np.zeros((M, N))
+    A3 = A.reshape(R, L, K).astype(np.float64)
+    for j in range(5):
+        sh = shift0 + j * step
+        Ash = np.zeros_like(A3)
+        if sh >= 0:
+            Ash[:, :L - sh] = A3[:, sh:]
+        else:
+            Ash[:, -sh:] = A3[:, :L + sh]
+        ref += Ash.reshape(M, K) @ W[j].astype(np.float64).T
+    if extras:
+        ref += bias + resid
+    out = torch.full((M, N), float("nan"), device="cuda")
+    dA, dW = dev(A), dev(W)
+    db, dr = (dev(bias), dev(resid)) if extras else (None, None)
+    amax, flag = _lib.op_gemm(dA, dW, db, dr, out, M, N, K, 5, shift0, step, L, mode="fp16x3-tkc")
+    e = rel(out.cpu().numpy(), ref)
+    assert e < 3e-6 and flag == 0, (e, flag)
+    true_max = float(np.abs(A).max())
+    assert abs(amax - true_max) <= 1e-6 * true_max
+    out.fill_(float("nan"))
+    _, flag = _lib.op_gemm(dA, dW, db, dr, out, M, N, K, 5, shift0, step, L, mode="fp16x3-tkc", a_absmax_prev=amax)
+    assert rel(out.cpu().numpy(), ref) < 3e-6 and flag == 0
+    _, flag = _lib.op_gemm(dA, dW, db, dr, out, M, N, K, 5, shift0, step, L, mode="fp16x3-tkc", a_absmax_prev=true_max / 4096.0)
+    assert flag == 1
+
+
 def _attention_block_float64(qkv, Wo, bias, resid, rowbias, rowvar, L):
     """resid + to_out(softmax(q k^T / 8) v) + bias + per-row-variant constant in float64 (layers_attention_mini.py:101-127, 132)."""
     M = qkv.shape[0]
@@ -595,6 +637,8 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("token-owning d(ln1) with LayerNorm-1 backward (tklb)", 393216, 256, 768, 1, 1, 9, 0, False),
     ("self-attention fused with the out-projection, L = 48 (atk)", 393216, 256, 256, 1, 48, 10, 1, False),
     ("self-attention fused with the out-projection, L = 6 (atk)", 49152, 256, 256, 1, 6, 10, 1, False),
+    ("sample-owning 5-tap convolution 64x64 with bias and residual, L = 24 (tkc)", 196608, 64, 64, 5, 24, 12, 3, False),
+    ("sample-owning 5-tap convolution 32x32 input gradient, L = 48 (tkc)", 393216, 32, 32, 5, 48, 12, 4, False),
 ]
 
 

@@ -51,7 +51,7 @@ def test_ddpm_chain_free_running(tag, nwn, graph):
     assert np.array_equal(chain[:, :, 47], np.broadcast_to(synth.default_hard_conds(4, 48)[47], chain[:, :, 47].shape))
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "fp16x3-atk"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "fp16x3-atk", "fp16x3-tkc"])
 def test_ddpm_chain_every_gemm_mode(mode):
     """The same reference chain in each GEMM mode: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bf16x6 (three bf16 planes,
     six products) and fp16x3 (two scaled fp16 planes, three products; its first evaluation calibrates in bf16x6),

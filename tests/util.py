@@ -29,11 +29,12 @@ def dev(a):
 
 
 PLANS = {   # launch plans the parity tests force onto the small fixtures (ramp_launch_plan; row thresholds: 0 never, 1 always)
-    "": dict(ff_fused_rows=0, ffx_rows=0, tkl_rows=0, atk_rows=0),
-    "fusedff": dict(ff_fused_rows=1, ffx_rows=0, tkl_rows=0, atk_rows=0),   # FF1 -> GEGLU -> FF2 forward in one launch (gemm.hip, ff_fwd_kernel)
-    "ffx": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=0, atk_rows=0),       # token-owning fused feed-forward, forward and backward (ffx.hip)
-    "tok": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=0),       # + token-owning LN1 -> QKV, out-projection, d(o) (tkl.hip): round 3's bench plan
-    "atk": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1),       # + self-attention fused with the out-projection (atk.hip): the bench's plan
+    "": dict(ff_fused_rows=0, ffx_rows=0, tkl_rows=0, atk_rows=0, tkc_rows=0),
+    "fusedff": dict(ff_fused_rows=1, ffx_rows=0, tkl_rows=0, atk_rows=0, tkc_rows=0),   # FF1 -> GEGLU -> FF2 forward in one launch (gemm.hip, ff_fwd_kernel)
+    "ffx": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=0, atk_rows=0, tkc_rows=0),       # token-owning fused feed-forward, forward and backward (ffx.hip)
+    "tok": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=0, tkc_rows=0),       # + token-owning LN1 -> QKV, out-projection, d(o) (tkl.hip): round 3's bench plan
+    "atk": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=0),       # + self-attention fused with the out-projection (atk.hip)
+    "tkc": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=1),       # + the narrow k = 5 convolutions on sample-owning waves (tkc.hip): the bench's plan
 }
 
 
