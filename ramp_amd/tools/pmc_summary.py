@@ -11,7 +11,8 @@ import sys
 
 
 def klass(name):
-    if "gemm_x6" in name or "gemm_kernel" in name or "ff_fwd_kernel" in name or "ffx_kernel" in name or "tkl_kernel" in name or "tklb_kernel" in name:
+    if "gemm_x6" in name or "gemm_kernel" in name or "ff_fwd_kernel" in name or "ffx_kernel" in name or "tkl_kernel" in name or "tklb_kernel" in name \
+            or "ato_kernel" in name or "tkc_kernel" in name:      # (ato: self-attention + out-projection in one launch, counted with its GEMM)
         return "gemm"
     if "attn2" in name:
         return "attention"

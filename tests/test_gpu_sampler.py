@@ -463,9 +463,9 @@ def test_dynamic_replanning_loop_against_reference_run(impl):
 def test_dynamic_replanning_reference_run_embedded_in_a_large_batch(B):
     """The planner's numerics at the batches the large-launch kernels serve -- B = 768 candidates (73728 tokens at the first
     level) and BASELINE configs[3]'s full B = 8192 (6 x 1365 replicas + 2): the six candidates of the reference run
-    (replan_chain.npz, diffusion_model_dynamic.py:495-624) tiled over the batch.  Replicas tie with their originals and the
-    selection takes the FIRST minimum (torch.argmin), so the plan evolves exactly as in the reference run: every ranked batch's
-    first six rows, every selected index, every collision mask, every pursuer update -- through the captured ramp_replan graphs."""
+    (replan_chain.npz, diffusion_model_dynamic.py:495-624) tiled over the batch.  Replicas tie with their originals to rounding,
+    so the plan evolves as in the reference run: every ranked batch's first six rows, every selected candidate (the reference's, or a replica
+    of it), every collision mask, every pursuer update -- through the captured ramp_replan graphs."""
     from ramp_amd.models import DynamicGaussianDiffusionModel
     from util import NoiseInjector, StopReplan, make_fake_pursuit_env
     g = np.load(f"{GOLDEN}/replan_chain.npz")
@@ -490,7 +490,12 @@ def test_dynamic_replanning_reference_run_embedded_in_a_large_batch(B):
         assert tr.shape == (B, H, S)
         errs.append(float(np.abs(tr[:B0] - g[f"cost{j}/trajs"]).max()))
         assert float(np.abs(tr - tile(tr[:B0])).max()) < 1e-5                          # replicas stay with their originals
-        assert e["idx"] == int(g[f"cost{j}/idx"]), (j, e["idx"])                        # rank among the free ones: the winner is an original
+        # rank among the free ones: the winner is the reference's candidate or one of its replicas -- they tie to rounding, and since a wave
+        # of the fused attention kernel owns 48 / L samples, a replica at another position in its wave tile sums its keys in another order
+        # (1e-7): which of the tied copies has the smallest cost is not determined
+        n_free0 = int(g[f"cost{j}/free"].sum())
+        ref_idx = int(g[f"cost{j}/idx"])
+        assert (e["idx"] == ref_idx) if ref_idx < 0 or n_free0 == 0 else ((e["idx"] - ref_idx) % n_free0 == 0 and e["idx"] >= 0), (j, e["idx"], ref_idx)
         assert np.array_equal(e["free"].cpu().numpy(), tile(g[f"cost{j}/free"])), j
     for j, (t, st) in enumerate(log_env):
         assert t == int(g[f"env{j}/t"])
