@@ -185,7 +185,7 @@ def profile_gemm(dm, B, cloud, hard_conds):
     return {n: {"ms": ms[i], "flops": fl[i], "launches": int(cnt[i])} for i, n in enumerate(names)}
 
 
-PMC_FILE = "profiles/r03_pmc_traffic.json"
+PMC_FILE = "profiles/r04_pmc_traffic.json"
 SUSTAINED_FP32EQ_TFLOPS = 510.0        # profiles/r02_power_clocks.txt, r03_power_clocks.txt: the bare fp16x3 MFMA + LDS-read loop sustains 491-530 TFLOP/s (fp32-
                                        # equivalent) at the 1.4 kW socket limit, i.e. 0.59-0.64 of the 833.3 nominal ceiling
 STASH_BYTES_PER_ROW_EVAL = 4.0e6       # what ONE score evaluation must keep per network row for the input
