@@ -336,6 +336,11 @@ int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* 
  * divide 48 or 32 and M be whole samples.  Scaling arguments as ramp_op_tkl (the operand is the attention output o). */
 int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const float* resid, const float* rowbias, const int32_t* rowvar,
                 int32_t n_var, int32_t L, int32_t M, float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
+/* Backward of the self-attention itself on sample-owning waves (atk.hip, atb_kernel; the product path's replacement of the exact-fp32
+ * attention backward kernel on levels whose token count divides 48 or 32 -- CrossAttention.forward, layers_attention_mini.py:101-127,
+ * differentiated): dqkv (M, 768) = d[q | k | v] given dout (M, 256) = d(o) and qkv (M, 768); 4 heads x 64, samples of L tokens; fp16x3 products
+ * with exact per-wave operand scales (no call site, no range guard needed). */
+int ramp_op_atb(const float* qkv, const float* dout, float* dqkv, int32_t M, int32_t L, void* stream);
 /* d(ln1) = d(qkv) Wqkv^T with the LayerNorm-1 backward in its epilogue (tkl.hip, tklb_kernel; the product path's replacement of
  * the d(ln1) GEMM + ln_bwd pair, reference layers_attention_mini.py:132 differentiated): out = add + LNbwd(dqkv W^T; z, ln_g).
  * dqkv (M, 768), W (256, 768) = [Wq | Wk | Wv]^T rows, z / add / out (M, 256), device fp32.  Scaling arguments as ramp_op_tkl. */

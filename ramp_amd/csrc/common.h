@@ -200,6 +200,15 @@ struct AtoArgs {
   unsigned long long* stamps = nullptr; // diagnostic (ramp_bench_gemm): per wave 8 cycle sums
   int ablate = 0;                      // diagnostic twin (with stamps; wrong results): 2 no k / v DMA, 4 no ring DMA, 6 neither
 };
+// backward of the attention itself on sample-owning waves (atk.hip): dQKV (M, 768) = d[q | k | v] given dO (M, 256); fp16x3 products with
+// exact per-wave operand scales (no call site); same applicability as the forward kernel
+struct AtbArgs {
+  int M = 0, L = 0;
+  const float* QKV = nullptr;          // [M][768]
+  const float* dO = nullptr;           // [M][256]
+  float* dQKV = nullptr;               // [M][768]
+};
+int launch_atb(const AtbArgs& a, hipStream_t s);
 bool ato_applicable(int M, int L, int* ng);
 int launch_ato(const AtoArgs& a, hipStream_t s);
 int ato_pack(const float* W /*[256][256] fp32, device*/, float scale, unsigned short* out /*8 * 32 KB*/, hipStream_t s);

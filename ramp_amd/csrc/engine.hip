@@ -498,6 +498,9 @@ struct Run {
     return k.ato_w && c->atk_min_rows > 0 && M >= c->atk_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe && c->n_variants <= 4 &&
            ato_applicable(M, L, nullptr);
   }
+  bool use_atb(int M, int L) const {
+    return c->atk_min_rows > 0 && M >= c->atk_min_rows && c->gemm_mode == 2 && c->phase == 2 && c->x6_pipe && ato_applicable(M, L, nullptr);
+  }
   int ato(const STBlock& k, const float* qkv, const float* resid, float* Y, int M, int L, const float* rowbias, int rb_stride) {
     RAMP_REQUIRE(c->site < ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
     prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 256 + 16.0 * M * L * 64, {M, 256, 256, -4});
@@ -737,6 +740,10 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx, int s
       GemmArgs o = lin(dz1, D, k.wo_b, nullptr, c->t_o, D, Mb, D, D);                   // d(o)
       if (r.use_tkl(o)) CK(r.tkl(o, nullptr, nullptr)); else CK(r.gemm(o));
     }
+    if (r.use_atb(Mb, m.L)) {      // d(q, k, v) on sample-owning waves (atk.hip, atb_kernel): fp16x3 MFMAs, no LDS tile, two waves per SIMD
+      AtbArgs t; t.M = Mb; t.L = m.L; t.QKV = k.a_qkv; t.dO = c->t_o; t.dQKV = c->t_dqkv;
+      LAUNCH(c, r.s, CAT_ATTN, 32.0 * Rb * m.L * m.L * 64, launch_atb(t, r.s));
+    } else
     LAUNCH(c, r.s, CAT_ATTN, 32.0 * Rb * m.L * m.L * 64, launch_attn_bwd(k.a_qkv, c->t_o, c->t_dqkv, Rb, m.L, r.s));
     if (r.use_tklb(Mb, k.wqkv_b)) {      // d(ln1) and the LayerNorm-1 backward in one token-owning launch: dz = dz1 + LN1bwd(d(qkv) Wqkv^T)
       CK(r.tklb(c->t_dqkv, k.wqkv_b, zin, k.ln1_g, dz1, dz, Mb));
@@ -2233,6 +2240,12 @@ int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const floa
   return rc;
 }
 
+int ramp_op_atb(const float* qkv, const float* dout, float* dqkv, int32_t M, int32_t L, void* stream) {
+  RAMP_REQUIRE(qkv && dout && dqkv && M > 0 && L > 0, "bad arguments");
+  AtbArgs a; a.M = M; a.L = L; a.QKV = qkv; a.dO = dout; a.dQKV = dqkv;
+  return launch_atb(a, as_stream(stream));
+}
+
 int ramp_op_tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, int32_t M,
                  float absmax_prev, float* out, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
   RAMP_REQUIRE(dqkv && W && z && ln_g && add && out && M > 0, "bad arguments");
@@ -2320,7 +2333,31 @@ thread_local StressHook* g_stress = nullptr;
 
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 12, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 14, "bad arguments");
+  if (mode == 13 || mode == 14) {                      // attention backward: atb_kernel (13, atk.hip) / attn2_bwd_kernel (14, attention.hip); L = tokens per sample
+    hipStream_t sb = as_stream(stream);
+    DevArena arb;
+    RAMP_REQUIRE(L >= 1 && M % L == 0, "mode 13 / 14: M must be whole samples of L tokens");
+    float* Q = arb.alloc((size_t)M * 768); float* D = arb.alloc((size_t)M * 256); float* G = arb.alloc((size_t)M * 768);
+    RAMP_REQUIRE(Q && D && G, "hipMalloc failed");
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, Q, (long)M * 768, 1u, 1.5f);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, D, (long)M * 256, 3u, 1.f);
+    AtbArgs t; t.M = M; t.L = L; t.QKV = Q; t.dO = D; t.dQKV = G;
+    auto go = [&]() -> int { return mode == 13 ? launch_atb(t, sb) : launch_attn_bwd(Q, D, G, M / L, L, sb); };
+    for (int i = 0; i < warmup; ++i) CK(go());
+    hipEvent_t e0, e1;
+    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+    RAMP_HIP_CHECK(hipEventRecord(e0, sb));
+    int rcb = 0;
+    for (int i = 0; i < iters && rcb == 0; ++i) { rcb = go(); if (rcb == 0) STRESS(G, (size_t)M * 768, sb); }
+    RAMP_HIP_CHECK(hipEventRecord(e1, sb));
+    RAMP_HIP_CHECK(hipEventSynchronize(e1));
+    float msb = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&msb, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = msb * 1e3f / iters;
+    return rcb;
+  }
   if (mode == 12) {                                    // tkc.hip: k = 5 convolution with C_in, C_out in {32, 64} on sample-owning waves; flags 1 bias, 2 residual, 4 input gradient
     hipStream_t sc = as_stream(stream);
     DevArena arc;

@@ -521,6 +521,30 @@ def test_tklb_dln1_with_layernorm_backward_against_float64_autograd(M):
     assert flag.value == 1, flag.value
 
 
+@pytest.mark.parametrize("L,R", [(48, 4), (48, 9), (24, 7), (12, 33), (6, 131), (16, 5), (32, 3), (8, 40), (4, 9), (3, 50), (1, 100), (48, 1024)])
+def test_atb_attention_backward_against_float64_autograd(L, R):
+    """d(q, k, v) of softmax(q k^T / 8) v on sample-owning waves (atk.hip atb_kernel through ramp_op_atb: 16 x 16 fp16x3 MFMAs, operands turned
+    in registers by selection MFMAs, no LDS) against float64 autograd (CrossAttention.forward, layers_attention_mini.py:101-127): every level
+    length dividing 48 or 32, sample counts that leave the last wave / block partly empty."""
+    from ramp_amd import _lib
+    M = R * L
+    gen = torch.Generator(device="cpu").manual_seed(77 * L + R)
+    qkv = (torch.randn(M, 768, generator=gen) * 1.3).cuda()
+    qkv[:, 512:] = qkv[:, 512:] * 0.4 + 0.1
+    dout = torch.randn(M, 256, generator=gen).cuda()
+    x = qkv.double().clone().requires_grad_(True)
+    y = x.reshape(R, L, 3, 4, 64)
+    q, k, v = y[:, :, 0].transpose(1, 2), y[:, :, 1].transpose(1, 2), y[:, :, 2].transpose(1, 2)
+    o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).transpose(1, 2).reshape(M, 256)
+    (ref,) = torch.autograd.grad(o, x, dout.double())
+    got = torch.full((M, 768), float("nan"), device="cuda")
+    _lib.check(_lib.load().ramp_op_atb(_lib.ptr(qkv), _lib.ptr(dout), _lib.ptr(got), M, L, None), "ramp_op_atb")
+    ref = ref.cpu().numpy(); got = got.cpu().numpy()
+    for name, sl in (("dq", slice(0, 256)), ("dk", slice(256, 512)), ("dv", slice(512, 768))):
+        e = rel(got[:, sl], ref[:, sl])
+        assert e < 3e-6, (name, e)
+
+
 @pytest.mark.parametrize("L,R,N,K,extras", [(48, 3, 32, 32, True), (48, 9, 64, 64, True), (24, 7, 64, 32, False), (24, 8, 32, 64, True), (12, 33, 64, 64, True),
                                             (16, 5, 64, 64, False), (32, 3, 32, 32, True), (8, 41, 64, 64, True), (48, 4096, 32, 32, True)])
 @pytest.mark.parametrize("backward", [False, True])
@@ -639,6 +663,7 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("self-attention fused with the out-projection, L = 6 (atk)", 49152, 256, 256, 1, 6, 10, 1, False),
     ("sample-owning 5-tap convolution 64x64 with bias and residual, L = 24 (tkc)", 196608, 64, 64, 5, 24, 12, 3, False),
     ("sample-owning 5-tap convolution 32x32 input gradient, L = 48 (tkc)", 393216, 32, 32, 5, 48, 12, 4, False),
+    ("attention backward on sample-owning waves, L = 24 (atb)", 196608, 256, 256, 1, 24, 13, 0, False),
 ]
 
 
