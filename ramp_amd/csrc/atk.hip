@@ -24,6 +24,7 @@
 // Tokens past M are clamped for loads (finite garbage that is never stored).
 #include "common.h"
 #include "tokmma.h"
+#include "atkmma.h"
 
 #include <algorithm>
 
@@ -31,48 +32,15 @@ namespace ramp {
 
 namespace {
 
-typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-
 constexpr int AT_SLAB = 16 * 1024;                      // 4 output blocks of 16 x 2 k32 steps x 2 planes x 1 KB
 constexpr int AT_R = 3;                                 // ring slots: slab g + 2 is requested during slab g
 constexpr int AT_BIAS = AT_R * AT_SLAB;                 // bias (256 floats)
 constexpr int AT_RB = AT_BIAS + 256 * 4;                // row-variant constants (<= 4 x 256 floats)
-constexpr int AT_VG = 1024 + 64;                        // a group of 4 rows x 256 bytes + padding (bank spread)
-constexpr int AT_VW = 12 * AT_VG;                       // per wave and operand (T = 48: 12 groups)
 constexpr int AT_V = AT_RB + 4 * 256 * 4;               // per wave: the v rows of one head
 constexpr int AT_K = AT_V + 4 * AT_VW;                  // per wave: the k rows of one head
 constexpr size_t AT_LDS = (size_t)AT_K + 4 * AT_VW;
 static_assert(AT_LDS <= 160 * 1024, "LDS budget");
 
-__device__ __forceinline__ f32x4 mm32(const u32x4 a, const u32x4 b, const f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mm16(const u32x2 a, const u32x2 b, const f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4v, a), __builtin_bit_cast(half4v, b), c, 0, 0, 0);
-}
-// 2^(target - floor(log2 mx)): mx lands in [2^target, 2^(target + 1)); 1 for mx == 0 / non-finite
-__device__ __forceinline__ float pow2_scale(float mx, int target) {
-  float s = 1.f;
-  if (mx > 0.f && mx < 3.0e38f) {
-    const int eb = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu);
-    int sb = 254 + target - eb;
-    sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
-    s = __builtin_bit_cast(float, (unsigned)sb << 23);
-  }
-  return s;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-// four scaled floats -> two dwords of each plane: x = hi + lo (both RNE)
-__device__ __forceinline__ void split4s(const f32x4 a, float s, u32x2& hi, u32x2& lo) {
-  unsigned h0, h1, l0, l1;
-  split4(a * s, h0, h1, l0, l1);
-  hi = u32x2{h0, h1}; lo = u32x2{l0, l1};
-}
-__device__ __forceinline__ u32x4 cat2(const u32x2 a, const u32x2 b) { return u32x4{a[0], a[1], b[0], b[1]}; }
 
 }  // namespace
 

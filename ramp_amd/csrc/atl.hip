@@ -1,0 +1,644 @@
+// Backward of the transformer block's self-attention half as ONE launch of sample-owning waves:
+//
+//   dz = dz1 + LayerNorm1-backward( d(qkv) Wqkv^T ; z, gamma ),   d(qkv) = attention-backward(q, k, v, d(o))
+//
+// (CrossAttention.forward and BasicTransformerBlock.forward differentiated, layers_attention_mini.py:101-127, 132).  It replaces
+// atb_kernel / attn2_bwd_kernel + tklb_kernel (tkl.hip): d(qkv) -- 3 KB per token written and read again -- never reaches HBM.
+//
+// Dataflow = atb_kernel's (atk.hip) with ato_kernel's projection behind it.  A wave owns T = 48 (32) tokens = whole samples; per head it
+// computes P^T, dS^T and from them the three gradient tiles dV^T, dQ^T, dK^T [feature 4 g + i][token c] in accumulator registers; each
+// such tile IS the B operand of the projection d(ln1)^T[n][token] += W[n][k] d(qkv)^T[k][token], whose 256 x T accumulators stay in the
+// accumulation half of the register file for the whole tile (4 heads x 3 parts x 64 = the 768 k of the product).  The weight planes
+// (768 KB per tile) stream through a 3-slot LDS ring of 16 KB slabs in the order the gradient tiles are produced (abl_pack); q, k, v,
+// d(o) rows reach the wave through two wave-private LDS regions by LDS-DMA, so nothing waits in registers.  d(qkv) is the operand of
+// the d(ln1) call site: delayed power-of-two scale, recorded maximum, range guard like every other fp16x3 GEMM.  The LayerNorm backward
+// runs on the accumulators in the epilogue (two passes over the z rows: sums, then outputs).
+#include "common.h"
+#include "tokmma.h"
+#include "atkmma.h"
+
+#include <algorithm>
+
+namespace ramp {
+
+namespace {
+
+constexpr int AL_SLAB = 16 * 1024;                      // 8 output blocks of 16 x one k32 step x 2 planes x 1 KB
+constexpr int AL_R = 3;                                 // ring slots: slab g + 2 is requested during slab g
+constexpr int AL_NS = 48;                               // slabs per tile: head 4 x part 3 x k32 step 2 x output half 2
+constexpr int AL_GAM = AL_R * AL_SLAB;                  // LayerNorm gamma (256 floats)
+constexpr int AL_RA = AL_GAM + 1024;                    // per wave: operand region A (q -> d(o) -> k -> next q)
+constexpr int AL_RB = AL_RA + 4 * AT_VW;                // per wave: operand region B (k -> v -> q -> next k)
+constexpr size_t AL_LDS = (size_t)AL_RB + 4 * AT_VW;
+static_assert(AL_LDS <= 160 * 1024, "LDS budget");
+
+}  // namespace
+
+// ---- weight stream ----------------------------------------------------------------------------------------------------------------------
+// W [256 n][768 k] row-major (k = q | k | v features, 4 heads x 64 each) -> out [slab 48][nbl 8][plane 2][lane 64][8 halves]; slab
+// ((h * 3 + p) * 2 + j) * 2 + half serves head h, part p in the kernel's order (v, q, k), k32 step j of the head's 64 features and
+// output features 128 half + 16 nbl + (lane & 15); k order inside the step = the row order of two stacked accumulator tiles (ato_pack).
+__global__ void abl_pack_kernel(const float* __restrict__ W, unsigned short* __restrict__ out, float scale) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;            // (slab, nbl, lane): 48 * 8 * 64
+  if (idx >= AL_NS * 8 * 64) return;
+  const int lane = idx & 63, nbl = (idx >> 6) & 7, sl = idx >> 9;
+  const int half = sl & 1, j = (sl >> 1) & 1, hp = sl >> 2, p = hp % 3, h = hp / 3;
+  const int part = p == 0 ? 2 : p - 1;                       // v, q, k
+  const int n = 128 * half + 16 * nbl + (lane & 15), kq = lane >> 4;
+  _Float16 hi[8], lo[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int kl = e < 4 ? 4 * kq + e : 16 + 4 * kq + (e - 4);
+    const float x = W[(long)n * 768 + 256 * part + 64 * h + 32 * j + kl] * scale;
+    hi[e] = (_Float16)x;
+    lo[e] = (_Float16)(x - (float)hi[e]);
+  }
+  unsigned short* o = out + ((long)(sl * 8 + nbl) * 2) * 512 + lane * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { o[e] = __builtin_bit_cast(unsigned short, hi[e]); o[512 + e] = __builtin_bit_cast(unsigned short, lo[e]); }
+}
+int abl_pack(const float* W, float scale, unsigned short* out, hipStream_t s) {
+  RAMP_REQUIRE(W && out, "abl_pack: null operand");
+  hipLaunchKernelGGL(abl_pack_kernel, dim3(AL_NS * 8 * 64 / 256), dim3(256), 0, s, W, out, scale);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// Vector-memory order of a head: wait(0) | S^T / softmax: d(o), v pieces (two at each of its 4 NG points) | wait(0) | dP^T / dS^T: k pieces
+// | dV slabs: ring + q pieces | dQ slabs: ring + the NEXT head's q pieces | dK slabs: ring + the next head's k pieces.  Every slab issues 4
+// ring pieces (slab g + 2) and up to 3 operand pieces; a slab waits with vmcnt(4): its own pieces are older than the 4 ring pieces of
+// the slab before it.
+template <int NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void abl_kernel(AblArgs a, int n_tiles) {
+  constexpr int T = 16 * NG;
+  constexpr int GR = T / 4;                                 // 4-token groups = LDS-DMA pieces per operand
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int n_my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int n_steps = 4 * n_my;
+
+  const float s_in = scale_of(a.amax_in);
+  const float os = a.wsi / s_in;
+  float amax = 0.f;
+
+  reinterpret_cast<float*>(smem + AL_GAM)[tid] = a.ln_g[tid];     // (published by the first slab barrier; first read in the first epilogue)
+
+  unsigned kmask[NG];                                       // keys (16 kg + 4 g + i) in the sample of query 16 qg + c: bit 4 kg + i
+#pragma unroll
+  for (int qg = 0; qg < NG; ++qg) {
+    unsigned m = 0;
+#pragma unroll
+    for (int kg = 0; kg < NG; ++kg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m |= ((16 * kg + 4 * g + i) / a.L == (16 * qg + c) / a.L ? 1u : 0u) << (4 * kg + i);
+    kmask[qg] = m;
+  }
+  // selection operands (atb_kernel): as B operand of a k32 step whose A operand pairs two 16-wide blocks, sel[b] picks block b
+  u32x4 sel[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    unsigned w[4];
+#pragma unroll
+    for (int p2 = 0; p2 < 4; ++p2) {
+      unsigned v = 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int e = 2 * p2 + q;
+        if ((e >> 2) == b && 4 * g + (e & 3) == c) v |= 0x3c00u << (16 * q);
+      }
+      w[p2] = v;
+    }
+    sel[b] = u32x4{w[0], w[1], w[2], w[3]};
+  }
+  const u32x2 z2 = {0u, 0u};
+
+  // ---- weight ring (ato_kernel's): wave w copies bytes [4 w KB, +4 KB) of a 16 KB slab as 4 LDS-DMA pieces of 1 KB
+  const unsigned lane_w = (unsigned)(wave * 4096 + lane * 16);
+  int is_g = 0;
+  const char* ring_src = nullptr; unsigned ring_dst = 0;
+  auto ring_begin = [&]() __attribute__((always_inline)) {
+    ring_src = reinterpret_cast<const char*>(a.W) + (long)(is_g % AL_NS) * AL_SLAB;      // scalar
+    ring_dst = (unsigned)(uintptr_t)(smem + (is_g % AL_R) * AL_SLAB + wave * 4096);
+    ++is_g;
+  };
+#define AL_PIECE(C) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" \
+                                 :: "v"(lane_w), "s"(ring_src), "s"(ring_dst), "n"((C) * 1024) : "memory", "m0")
+  auto ring_piece = [&](int cpc) __attribute__((always_inline)) {
+    switch (cpc) { case 0: AL_PIECE(0); break; case 1: AL_PIECE(1); break; case 2: AL_PIECE(2); break; default: AL_PIECE(3); break; }
+  };
+  int gs = 0;                                               // slabs consumed
+  const char* rd = smem + lane * 16;
+
+  // ---- operand regions: one LDS-DMA instruction = the 256-byte head slices of 4 consecutive tokens ("group": 1 KB + 64 bytes of padding),
+  // lane -> row lane & 3, chunk lane >> 2 ([chunk][row]); read back with ds_read_b128 as T-layout rows (lane (c, g) = features 16 fb + 4 g ..
+  // of token 16 t + c): conflict-free (ato_kernel's k region)
+  const int m_last = a.M - 1;
+  const unsigned ra_dst = (unsigned)(uintptr_t)(smem + AL_RA + wave * AT_VW), rb_dst = (unsigned)(uintptr_t)(smem + AL_RB + wave * AT_VW);
+  const char* ra_rd = smem + AL_RA + wave * AT_VW + (c >> 2) * AT_VG + 64 * g + 16 * (c & 3);
+  const char* rb_rd = smem + AL_RB + wave * AT_VW + (c >> 2) * AT_VG + 64 * g + 16 * (c & 3);
+  auto op_piece = [&](unsigned dst, const char* base /*scalar: operand + head offset*/, unsigned stride, int tile, int gr) __attribute__((always_inline)) {
+    int tk0 = tile * (4 * T) + wave * T + (c & 3);
+    asm volatile("" : "+v"(tk0));
+    const unsigned off = (unsigned)min(tk0 + 4 * gr, m_last) * stride + 16u * (unsigned)(4 * g + (c >> 2));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(dst + gr * AT_VG) : "memory", "m0");
+  };
+  auto read_region = [&](const char* rdp, f32x4 (&raw)[4][NG]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NG; ++t)
+#pragma unroll
+      for (int fb = 0; fb < 4; ++fb) raw[fb][t] = *reinterpret_cast<const f32x4*>(rdp + 4 * t * AT_VG + 256 * fb);
+  };
+  const char* qkvb = reinterpret_cast<const char*>(a.QKV);
+  const char* dob = reinterpret_cast<const char*>(a.dO);
+
+  // exact power-of-two scale of an operand's first use in the head and its planes [token group][k32 step = feature-block pair]
+  auto finish = [&](const f32x4 (&raw)[4][NG], float& scale, u32x4 (&hi)[NG][2], u32x4 (&lo)[NG][2]) __attribute__((always_inline)) {
+    if (scale == 0.f) {
+      float mx = 0.f;
+#pragma unroll
+      for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int t = 0; t < NG; ++t) mx = amax4(raw[fb][t], mx);
+      scale = pow2_scale(wave_max(mx), 13);
+    }
+#pragma unroll
+    for (int t = 0; t < NG; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x2 h0, l0, h1, l1;
+        split4s(raw[2 * j][t], scale, h0, l0); split4s(raw[2 * j + 1][t], scale, h1, l1);
+        hi[t][j] = cat2(h0, h1); lo[t][j] = cat2(l0, l1);
+      }
+  };
+  // T-layout planes of one k32 step of ALL token groups -> planes with the feature on the lane and the tokens in the registers (atb_kernel)
+  auto turn = [&](const u32x4 (&hi)[NG][2], const u32x4 (&lo)[NG][2], int j, u32x4 (&oh)[2][2], u32x4 (&ol)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      u32x2 th[NG], tl[NG];
+#pragma unroll
+      for (int t = 0; t < NG; ++t) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        x = mm32(hi[t][j], sel[f], x);
+        x = mm32(lo[t][j], sel[f], x);
+        unsigned h0, h1, l0, l1;
+        split4(x, h0, h1, l0, l1);
+        th[t] = u32x2{h0, h1}; tl[t] = u32x2{l0, l1};
+      }
+      oh[f][0] = cat2(th[0], th[1]); ol[f][0] = cat2(tl[0], tl[1]);
+      oh[f][1] = NG == 3 ? cat2(th[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
+      ol[f][1] = NG == 3 ? cat2(tl[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+
+  // prologue: slabs 0, 1; the first head's q -> A, k -> B
+  ring_begin(); ring_piece(0); ring_piece(1); ring_piece(2); ring_piece(3);
+  ring_begin(); ring_piece(0); ring_piece(1); ring_piece(2); ring_piece(3);
+#pragma unroll
+  for (int gr = 0; gr < GR; ++gr) { op_piece(ra_dst, qkvb, 3072u, (int)blockIdx.x, gr); op_piece(rb_dst, qkvb + 1024, 3072u, (int)blockIdx.x, gr); }
+
+  f32x4 acc[16][NG];                                        // d(ln1)^T: [feature 16 nb + 4 g + i][token 16 t + c]
+
+#pragma unroll 1
+  for (int ti = 0; ti < n_my; ++ti) {
+  const int tile = (int)blockIdx.x + ti * (int)gridDim.x;
+  const long tok0 = (long)tile * (4 * T) + wave * T;
+  const bool full = tok0 + T <= a.M;                        // wave-uniform
+#pragma unroll
+  for (int nb = 0; nb < 16; ++nb)
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+      float z0, z1, z2r, z3;
+      asm volatile("v_accvgpr_write_b32 %0, 0\n\tv_accvgpr_write_b32 %1, 0\n\tv_accvgpr_write_b32 %2, 0\n\tv_accvgpr_write_b32 %3, 0" : "=a"(z0), "=a"(z1), "=a"(z2r), "=a"(z3));
+      acc[nb][t] = f32x4{z0, z1, z2r, z3};
+    }
+#pragma unroll 1
+  for (int h = 0; h < 4; ++h) {
+    const int hs = 4 * ti + h;
+    const int hs_n = hs + 1 < n_steps ? hs + 1 : hs;        // (the last head re-requests its own rows: unused)
+    const int tile_n = (int)blockIdx.x + (hs_n >> 2) * (int)gridDim.x, h_n = hs_n & 3;
+    const int hoff = 256 * h;
+#pragma unroll
+    for (int nb = 0; nb < 16; ++nb)
+#pragma unroll
+      for (int t = 0; t < NG; ++t) asm volatile("" : "+a"(acc[nb][t]));
+
+    float lm[NG];                                           // 0 for tokens past M (their gradients must not reach the recorded maximum)
+#pragma unroll
+    for (int t = 0; t < NG; ++t) lm[t] = (full || tok0 + 16 * t + c < a.M) ? 1.f : 0.f;
+
+    // the projection of one k32 step of a gradient part: two slabs (output features [0, 128), [128, 256)); B = the gradient tile's planes.
+    // Macro-step m = output block 8 half + m: first MFMA | this macro-step's LDS-DMA pieces | fragment reads of m + 1 | the other MFMAs
+    const char* op_base = nullptr; unsigned op_dst = 0, op_stride = 0; int op_tile = 0;
+    auto project = [&](const u32x4 (&bh)[NG], const u32x4 (&bl)[NG], int j) __attribute__((always_inline)) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // slab gs is complete in LDS; every wave has left slab gs - 1
+        ring_begin();                                       // slab gs + 2 goes into the slot of slab gs - 1
+        const char* sl = rd + (gs % AL_R) * AL_SLAB;
+        u32x4 wf[2][2];
+        wf[0][0] = *reinterpret_cast<const u32x4*>(sl); wf[0][1] = *reinterpret_cast<const u32x4*>(sl + 1024);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int nb = 8 * half + m;
+          const u32x4 wh = wf[m & 1][0], wl = wf[m & 1][1];
+          __builtin_amdgcn_sched_barrier(0);
+          acc[nb][0] = mm32(wh, bl[0], acc[nb][0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(m & 1)) ring_piece(m >> 1);
+          if (m == 1 || m == 4 || m == 7) {
+            const int gr = 3 * (2 * j + half) + m / 3;
+            if (gr < GR) op_piece(op_dst, op_base, op_stride, op_tile, gr);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (m + 1 < 8) {
+            wf[(m + 1) & 1][0] = *reinterpret_cast<const u32x4*>(sl + ((m + 1) * 2) * 1024);
+            wf[(m + 1) & 1][1] = *reinterpret_cast<const u32x4*>(sl + ((m + 1) * 2 + 1) * 1024);
+          }
+          acc[nb][0] = mm32(wl, bh[0], acc[nb][0]);
+          acc[nb][0] = mm32(wh, bh[0], acc[nb][0]);
+#pragma unroll
+          for (int t = 1; t < NG; ++t) {
+            f32x4 v = acc[nb][t];
+            v = mm32(wh, bl[t], v);
+            v = mm32(wl, bh[t], v);
+            v = mm32(wh, bh[t], v);
+            acc[nb][t] = v;
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * NG - 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ++gs;
+      }
+    };
+    // gradient tile of feature blocks 2 j, 2 j + 1: out^T[d][token] = sum over tokens' (A = turned operand) x (B = planes with the contracted token
+    // in the registers, [pair][free token group]); true scale -> recorded maximum -> planes at the call site's scale -> projection
+    auto contract_project = [&](const u32x4 (&ah)[2][2], const u32x4 (&al)[2][2], const u32x4 (&bh)[2][NG], const u32x4 (&bl)[2][NG], int j,
+                                float oscale) __attribute__((always_inline)) {
+      u32x4 gh[NG], gl[NG];
+#pragma unroll
+      for (int t = 0; t < NG; ++t) {
+        f32x4 o2[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int pr = 0; pr < (NG == 3 ? 2 : 1); ++pr) {
+            o = mm32(ah[f][pr], bl[pr][t], o);
+            o = mm32(al[f][pr], bh[pr][t], o);
+            o = mm32(ah[f][pr], bh[pr][t], o);
+          }
+          o2[f] = o * oscale;
+        }
+        amax = amax4(o2[0] * lm[t], amax); amax = amax4(o2[1] * lm[t], amax);
+        u32x2 h0, l0, h1, l1;
+        split4s(o2[0], s_in, h0, l0); split4s(o2[1], s_in, h1, l1);
+        gh[t] = cat2(h0, h1); gl[t] = cat2(l0, l1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      project(gh, gl, j);
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // q in A, k in B (and every older request)
+    float sq = 0.f, sk = 0.f, sv = 0.f, sdo = 0.f, sds = 0.f;
+    f32x4 pt[NG][NG], ds[NG][NG];                           // P^T, dS^T: [key group][query group], keys in the registers, query on the lane
+    // ---- S^T = K Q^T -> P^T (softmax over keys, masked to the query's sample)
+    {
+      u32x4 qh[NG][2], ql[NG][2], kh[NG][2], kl[NG][2];
+      { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sq, qh, ql); }
+      { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sk, kh, kl); }
+      __builtin_amdgcn_sched_barrier(0);
+      // both regions are free (their rows are planes): d(o) -> A, v -> B, two pieces at each of the 4 NG points below
+      auto p0_pieces = [&](int pt_i) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int p = 2 * pt_i + k2;
+          if (p < GR) op_piece(ra_dst, dob + hoff, 1024u, tile, p);
+          else op_piece(rb_dst, qkvb + 2048 + hoff, 3072u, tile, p - GR);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      const float ssc = 0.125f * 1.4426950408889634f / (sq * sk);
+#pragma unroll
+      for (int qg = 0; qg < NG; ++qg) {
+        f32x4 st[NG];
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) {
+          f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            x = mm32(kh[kg][j], ql[qg][j], x);
+            x = mm32(kl[kg][j], qh[qg][j], x);
+            x = mm32(kh[kg][j], qh[qg][j], x);
+          }
+          st[kg] = x;
+        }
+        p0_pieces(4 * qg);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = (kmask[qg] >> (4 * kg + i)) & 1u ? st[kg][i] * ssc : -3.0e38f;
+            st[kg][i] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        p0_pieces(4 * qg + 1);
+        float sum = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(st[kg][i] - mx); st[kg][i] = e; sum += e; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        p0_pieces(4 * qg + 2);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) pt[kg][qg] = st[kg] * inv;
+        p0_pieces(4 * qg + 3);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // d(o) in A, v in B
+    // ---- dP^T = V dO^T ; delta_q = sum_k P dP ; dS^T = P^T (dP^T - delta)
+    u32x4 doh[NG][2], dol[NG][2];
+    {
+      u32x4 vh[NG][2], vl[NG][2];
+      { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sv, vh, vl); }
+      { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sdo, doh, dol); }
+      __builtin_amdgcn_sched_barrier(0);
+      // A is free: k (for dQ) -> A, one piece at each of the 4 NG points below
+      auto p1_piece = [&](int p) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (p < GR) op_piece(ra_dst, qkvb + 1024 + hoff, 3072u, tile, p);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      const float dsc = 1.f / (sv * sdo);
+      float dmax = 0.f;
+#pragma unroll
+      for (int qg = 0; qg < NG; ++qg) {
+        f32x4 dp[NG];
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) {
+          f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            x = mm32(vh[kg][j], dol[qg][j], x);
+            x = mm32(vl[kg][j], doh[qg][j], x);
+            x = mm32(vh[kg][j], doh[qg][j], x);
+          }
+          dp[kg] = x * dsc;
+          if (kg < 2) p1_piece(4 * qg + kg);
+        }
+        float delta = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) delta += pt[kg][qg][i] * dp[kg][i];
+        delta += __shfl_xor(delta, 16);
+        delta += __shfl_xor(delta, 32);
+        p1_piece(4 * qg + 2);
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ds[kg][qg][i] = pt[kg][qg][i] * (dp[kg][i] - delta);
+          dmax = amax4(ds[kg][qg], dmax);
+        }
+        p1_piece(4 * qg + 3);
+      }
+      sds = pow2_scale(wave_max(dmax), 13);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // planes of P^T (x 2^13) and dS^T (x sds) as token-contracting B operands: [key-group pair][query group]
+    u32x4 sbh[2][NG], sbl[2][NG];
+    u32x4 pqh[2][NG], pql[2][NG];                           // P with the QUERY in the registers and the key on the lane: [query-group pair][key group]
+    {
+      u32x4 pbh[2][NG], pbl[2][NG];
+#pragma unroll
+      for (int qg = 0; qg < NG; ++qg) {
+        u32x2 ph[NG], pl[NG], sh[NG], sl[NG];
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) { split4s(pt[kg][qg], 8192.f, ph[kg], pl[kg]); split4s(ds[kg][qg], sds, sh[kg], sl[kg]); }
+        pbh[0][qg] = cat2(ph[0], ph[1]); pbl[0][qg] = cat2(pl[0], pl[1]);
+        sbh[0][qg] = cat2(sh[0], sh[1]); sbl[0][qg] = cat2(sl[0], sl[1]);
+        pbh[1][qg] = NG == 3 ? cat2(ph[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u}; pbl[1][qg] = NG == 3 ? cat2(pl[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
+        sbh[1][qg] = NG == 3 ? cat2(sh[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u}; sbl[1][qg] = NG == 3 ? cat2(sl[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      u32x2 tph[NG][NG], tpl[NG][NG];                       // [query group][key group]
+#pragma unroll
+      for (int qg = 0; qg < NG; ++qg)
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) {
+          const int pr = kg >> 1, b = kg & 1;
+          f32x4 x = {0.f, 0.f, 0.f, 0.f};
+          x = mm32(pbh[pr][qg], sel[b], x); x = mm32(pbl[pr][qg], sel[b], x);
+          unsigned h0, h1, l0, l1;
+          split4(x, h0, h1, l0, l1); tph[qg][kg] = u32x2{h0, h1}; tpl[qg][kg] = u32x2{l0, l1};
+        }
+#pragma unroll
+      for (int kg = 0; kg < NG; ++kg) {
+        pqh[0][kg] = cat2(tph[0][kg], tph[1][kg]); pql[0][kg] = cat2(tpl[0][kg], tpl[1][kg]);
+        pqh[1][kg] = NG == 3 ? cat2(tph[NG - 1][kg], z2) : u32x4{0u, 0u, 0u, 0u}; pql[1][kg] = NG == 3 ? cat2(tpl[NG - 1][kg], z2) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dV^T = dO^T P: A = d(o) turned (feature on the lane, queries in the registers), B = P (queries in the registers, key on the lane);
+    // its slabs carry this head's q rows -> B (for dK)
+    op_base = qkvb + hoff; op_dst = rb_dst; op_stride = 3072u; op_tile = tile;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u32x4 th[2][2], tl[2][2];
+      turn(doh, dol, j, th, tl);
+      contract_project(th, tl, pqh, pql, j, 1.f / (sdo * 8192.f));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dQ^T = K^T dS^T / 8: A = k turned, B = dS^T (keys in the registers, query on the lane); its slabs carry the NEXT head's q rows -> A
+    {
+      u32x4 kh[NG][2], kl[NG][2];
+      { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sk, kh, kl); }       // (k landed before the dV slabs' waits)
+      __builtin_amdgcn_sched_barrier(0);
+      op_base = qkvb + 256 * h_n; op_dst = ra_dst; op_stride = 3072u; op_tile = tile_n;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4 th[2][2], tl[2][2];
+        turn(kh, kl, j, th, tl);
+        contract_project(th, tl, sbh, sbl, j, 0.125f / (sk * sds));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dK^T = Q^T dS / 8: dS turned tile by tile (query in the registers, key on the lane); its slabs carry the next head's k rows -> B
+    {
+      u32x4 sqh[2][NG], sql[2][NG];                         // [query-group pair][key group]
+      {
+        u32x2 tsh[NG][NG], tsl[NG][NG];
+#pragma unroll
+        for (int qg = 0; qg < NG; ++qg)
+#pragma unroll
+          for (int kg = 0; kg < NG; ++kg) {
+            const int pr = kg >> 1, b = kg & 1;
+            f32x4 y = {0.f, 0.f, 0.f, 0.f};
+            y = mm32(sbh[pr][qg], sel[b], y); y = mm32(sbl[pr][qg], sel[b], y);
+            unsigned h0, h1, l0, l1;
+            split4(y, h0, h1, l0, l1); tsh[qg][kg] = u32x2{h0, h1}; tsl[qg][kg] = u32x2{l0, l1};
+          }
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) {
+          sqh[0][kg] = cat2(tsh[0][kg], tsh[1][kg]); sql[0][kg] = cat2(tsl[0][kg], tsl[1][kg]);
+          sqh[1][kg] = NG == 3 ? cat2(tsh[NG - 1][kg], z2) : u32x4{0u, 0u, 0u, 0u}; sql[1][kg] = NG == 3 ? cat2(tsl[NG - 1][kg], z2) : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      u32x4 qh[NG][2], ql[NG][2];
+      { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sq, qh, ql); }       // (q landed before the dQ slabs' waits)
+      __builtin_amdgcn_sched_barrier(0);
+      op_base = qkvb + 1024 + 256 * h_n; op_dst = rb_dst; op_stride = 3072u; op_tile = tile_n;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4 th[2][2], tl[2][2];
+        turn(qh, ql, j, th, tl);
+        contract_project(th, tl, sqh, sql, j, 0.125f / (sq * sds));
+      }
+    }
+  }
+    // ================= epilogue of the tile: dz = add + LNbwd(d(ln1); z, gamma)  (rowops.hip ln_bwd_kernel; tklb_kernel's epilogue) ==========
+    // lane (c, g) holds features 16 nb + 4 g + i of tokens 16 t + c: row sums = in-lane over (nb, i) + two shuffles over g.  Pass 1: the four
+    // sums of a row from ONE read of z (about a pivot, the row's first element: no cancellation in the variance); pass 2: z again (L2), outputs.
+    {
+      const float* gam = reinterpret_cast<const float*>(smem + AL_GAM) + 4 * g;
+      unsigned yoff[NG];
+      float piv[NG];
+      const char* zb = reinterpret_cast<const char*>(a.Z);
+      const char* ab = reinterpret_cast<const char*>(a.add);
+      char* yb = reinterpret_cast<char*>(a.Y);
+#pragma unroll
+      for (int t = 0; t < NG; ++t) {
+        const unsigned tk = (unsigned)min((int)tok0 + 16 * t + c, m_last);
+        yoff[t] = tk * 1024u + 16u * (unsigned)g;
+        piv[t] = *reinterpret_cast<const float*>(zb + tk * 1024u);
+      }
+      float s1[NG], s2[NG], t1[NG], t2[NG];
+#pragma unroll
+      for (int t = 0; t < NG; ++t) { s1[t] = 0.f; s2[t] = 0.f; t1[t] = 0.f; t2[t] = 0.f; }
+      f32x4 rz[2][2][NG];
+      auto rz_load = [&](int b2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int t = 0; t < NG; ++t) rz[b2 & 1][q][t] = *reinterpret_cast<const f32x4*>(zb + yoff[t] + 64 * (2 * b2 + q));
+      };
+      rz_load(0); rz_load(1);
+#pragma unroll
+      for (int b2 = 0; b2 < 8; ++b2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int nb = 2 * b2 + q;
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * nb);
+#pragma unroll
+          for (int t = 0; t < NG; ++t) {
+            const f32x4 gq = acc[nb][t] * os * gm;
+            const f32x4 zq = rz[b2 & 1][q][t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = zq[e] - piv[t];
+              s1[t] += d; s2[t] += d * d; t1[t] += gq[e]; t2[t] += gq[e] * d;
+            }
+          }
+        }
+        if (b2 + 2 < 8) rz_load(b2 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float mu[NG], rstd[NG], m1[NG], m2[NG];
+#pragma unroll
+      for (int t = 0; t < NG; ++t) {
+        s1[t] += __shfl_xor(s1[t], 16); s1[t] += __shfl_xor(s1[t], 32);
+        s2[t] += __shfl_xor(s2[t], 16); s2[t] += __shfl_xor(s2[t], 32);
+        t1[t] += __shfl_xor(t1[t], 16); t1[t] += __shfl_xor(t1[t], 32);
+        t2[t] += __shfl_xor(t2[t], 16); t2[t] += __shfl_xor(t2[t], 32);
+        const float ms = s1[t] * (1.f / 256.f);
+        const float var = fmaxf(s2[t] * (1.f / 256.f) - ms * ms, 0.f);
+        rstd[t] = 1.f / sqrtf(var + 1e-5f);
+        mu[t] = piv[t] + ms;
+        m1[t] = t1[t] * (1.f / 256.f);
+        m2[t] = rstd[t] * (t2[t] - ms * t1[t]) * (1.f / 256.f);     // mean of g x-hat
+      }
+      f32x4 ra[2][2][NG];
+      auto ra_load = [&](int b2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int t = 0; t < NG; ++t) {
+            rz[b2 & 1][q][t] = *reinterpret_cast<const f32x4*>(zb + yoff[t] + 64 * (2 * b2 + q));
+            ra[b2 & 1][q][t] = *reinterpret_cast<const f32x4*>(ab + yoff[t] + 64 * (2 * b2 + q));
+          }
+      };
+      // (every store of a full wave tile unconditional: a store behind a per-lane predicate sits in its own basic block behind vmcnt(0))
+      auto pass2 = [&](bool pred) __attribute__((always_inline)) {
+        ra_load(0); ra_load(1);
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int nb = 2 * b2 + q;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * nb);
+#pragma unroll
+            for (int t = 0; t < NG; ++t) {
+              const f32x4 gq = acc[nb][t] * os * gm;
+              const f32x4 zq = rz[b2 & 1][q][t];
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (gq[e] - m1[t] - (zq[e] - mu[t]) * rstd[t] * m2[t]) * rstd[t] + ra[b2 & 1][q][t][e];
+              if (!pred || tok0 + 16 * t + c < a.M) *reinterpret_cast<f32x4*>(yb + yoff[t] + 64 * nb) = o;
+            }
+          }
+          if (b2 + 2 < 8) ra_load(b2 + 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (full) pass2(false); else pass2(true);
+    }
+  }
+#undef AL_PIECE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the block
+
+  amax = wave_max(amax);
+  record_amax_block(a.amax_out, amax, reinterpret_cast<float*>(smem));      // (no LDS-DMA in flight: vmcnt(0) above; it starts with a barrier)
+  if (lane == 0) {
+    if (a.range_flag && (!(amax * s_in < 60000.f) || (amax > 0.f && amax * s_in < 0.125f))) atomicMax(a.range_flag, a.site + 1);
+  }
+}
+
+int launch_abl(const AblArgs& a, hipStream_t s) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  int ng = 0;
+  RAMP_REQUIRE(ato_applicable(a.M, a.L, &ng), "abl: tokens per sample must divide 48 or 32 (and M be whole samples)");
+  RAMP_REQUIRE(a.QKV && a.dO && a.W && a.Z && a.add && a.ln_g && a.Y, "abl: null operand");
+  RAMP_REQUIRE(al16(a.QKV) && al16(a.dO) && al16(a.W) && al16(a.Z) && al16(a.add) && al16(a.Y), "abl: operands must be 16-byte aligned");
+  RAMP_REQUIRE((long)a.M * 3072 < (1l << 32), "abl: 32-bit row offsets bound M to 1398100 tokens");
+  {
+    const size_t yb = (size_t)a.M * 1024;
+    RAMP_REQUIRE(!ranges_overlap(a.Y, yb, a.QKV, 3 * yb) && !ranges_overlap(a.Y, yb, a.dO, yb) && !ranges_overlap(a.Y, yb, a.Z, yb) && !ranges_overlap(a.Y, yb, a.add, yb),
+                 "abl: the output must not overlap the operands (other blocks still read them)");
+  }
+  const int T = 16 * ng, n_tiles = (a.M + 4 * T - 1) / (4 * T);
+  const int nb = std::min(n_tiles, device_cu_count());
+  if (ng == 3) hipLaunchKernelGGL((abl_kernel<3>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
+  else hipLaunchKernelGGL((abl_kernel<2>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int init_atl_attributes() {
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
+  return 0;
+}
+
+}  // namespace ramp

@@ -214,6 +214,25 @@ int launch_ato(const AtoArgs& a, hipStream_t s);
 int ato_pack(const float* W /*[256][256] fp32, device*/, float scale, unsigned short* out /*8 * 32 KB*/, hipStream_t s);
 int init_atk_attributes();
 
+// ---- attention backward + d(ln1) + LayerNorm-1 backward in one launch of sample-owning waves (atl.hip) ------------------------------
+// Y[m][:] = add[m][:] + LNbwd( d(qkv)[m][:] W^T ; Z[m][:], ln_g ),  d(qkv) = attention backward of (QKV, dO): see AtbArgs / TklbArgs.
+// d(qkv) is the operand of ONE call site (delayed scale, recorded maximum, range guard); L must divide 48 or 32 (ato_applicable).
+struct AblArgs {
+  int M = 0, L = 0;
+  const float* QKV = nullptr;          // [M][768]
+  const float* dO = nullptr;           // [M][256]
+  const unsigned short* W = nullptr;   // weight stream (abl_pack): 48 slabs x 16 KB
+  const float* Z = nullptr;            // [M][256]: the LayerNorm's input
+  const float* add = nullptr;          // [M][256]: the gradient that bypasses the block half
+  const float* ln_g = nullptr;         // [256]
+  float* Y = nullptr;                  // [M][256]
+  const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;
+  int* range_flag = nullptr;
+};
+int launch_abl(const AblArgs& a, hipStream_t s);
+int abl_pack(const float* W /*[256][768] fp32, device*/, float scale, unsigned short* out /*48 * 16 KB*/, hipStream_t s);
+int init_atl_attributes();
+
 // ---- Conv1d(k = 5, padding 2) with C_in, C_out in {32, 64} as sample-owning waves (tkc.hip) ---------------------------------------------
 // Y[m][n] = sum_tap sum_k X[m + dir (tap - 2)][k] W[tap][n][k] (+ bias[n]) (+ resid[m][n]) (+ resid2[m][n]); rows outside m's sample of L
 // tokens read as zero.  dir = +1: the forward convolution; -1: its input gradient (W = the transposed weight, same tap order).  fp16x3

@@ -114,6 +114,7 @@ struct STBlock {
   unsigned short *ffx_f = nullptr, *ffx_b = nullptr; float ffx_wsi_w1 = 1.f, ffx_wsi_w2 = 1.f;
   // self-attention fused with the output projection (atk.hip): the projection's weight stream
   unsigned short* ato_w = nullptr; float ato_wsi = 1.f;
+  unsigned short* abl_w = nullptr;       // weight stream of the fused attention backward + d(ln1) (atl.hip), scale = the wqkv_b planes'
 };
 struct ST {
   std::string name;
@@ -219,7 +220,7 @@ struct ramp_ctx {
   std::map<std::string, std::pair<float*, size_t>> dbg;
   int64_t launches = 0;
   // per-launch HIP-event profiler (eager mode only): category, algorithmic flops, start/stop events
-  bool prof_on = false, prof_dump = false; int ffx_ablate = 0; bool tklb_off = false;
+  bool prof_on = false, prof_dump = false; int ffx_ablate = 0; bool tklb_off = false; bool abl_on = true;
   std::vector<hipEvent_t> prof_ev; size_t prof_used = 0;
   std::vector<int> prof_cat; std::vector<double> prof_flops; std::vector<std::array<int, 4>> prof_shape;
 };
@@ -513,6 +514,24 @@ struct Run {
     c->launches++;
     return rc;
   }
+  // attention backward + d(ln1) + LayerNorm-1 backward in one launch of sample-owning waves (atl.hip): d(qkv) never reaches HBM;
+  // consumes the call site of the d(ln1) GEMM it contains
+  bool use_abl(const STBlock& k, int M, int L) const {
+    return c->abl_on && k.abl_w && use_atb(M, L) && use_tklb(M, k.wqkv_b);
+  }
+  int abl(const STBlock& k, const float* qkv, const float* dout, const float* z, const float* add, float* out, int M, int L) {
+    GemmArgs b; b.A = c->t_dqkv; b.lda = 768; b.W = k.wqkv_b; b.C = out; b.ldc = 256; b.M = M; b.N = 256; b.K = 768; b.taps = 1; b.L = 1;
+    const int kind = prep(b);                               // (the site's scale slots and the weight's scale; no operand is read through b)
+    if (kind < 0) return kind;
+    RAMP_REQUIRE(kind == 2, "abl: weight without fp16 fragment planes (use_abl must have been checked)");
+    prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 768 + 32.0 * M * L * 64, {M, 256, 768, -5});
+    AblArgs t; t.M = M; t.L = L; t.QKV = qkv; t.dO = dout; t.W = k.abl_w; t.Z = z; t.add = add; t.ln_g = k.ln1_g; t.Y = out;
+    t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.wsi = b.w_scale_inv; t.site = b.site_id; t.range_flag = b.range_flag;
+    int rc = launch_abl(t, s);
+    prof_post(c, s);
+    c->launches++;
+    return rc;
+  }
   // d(ln1) = d(qkv) Wqkv^T and the LayerNorm-1 backward behind it in one token-owning launch (tkl.hip, tklb_kernel); consumes
   // the call site of the d(ln1) GEMM it replaces
   bool use_tklb(int M, const float* W) const {
@@ -740,6 +759,9 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx, int s
       GemmArgs o = lin(dz1, D, k.wo_b, nullptr, c->t_o, D, Mb, D, D);                   // d(o)
       if (r.use_tkl(o)) CK(r.tkl(o, nullptr, nullptr)); else CK(r.gemm(o));
     }
+    if (r.use_abl(k, Mb, m.L)) {   // d(q, k, v), d(ln1) and the LayerNorm-1 backward in ONE launch: dz = dz1 + LN1bwd(attention-backward(d(o)) Wqkv^T)
+      CK(r.abl(k, k.a_qkv, c->t_o, zin, dz1, dz, Mb, m.L));
+    } else {
     if (r.use_atb(Mb, m.L)) {      // d(q, k, v) on sample-owning waves (atk.hip, atb_kernel): fp16x3 MFMAs, no LDS tile, two waves per SIMD
       AtbArgs t; t.M = Mb; t.L = m.L; t.QKV = k.a_qkv; t.dO = c->t_o; t.dQKV = c->t_dqkv;
       LAUNCH(c, r.s, CAT_ATTN, 32.0 * Rb * m.L * m.L * 64, launch_atb(t, r.s));
@@ -750,6 +772,7 @@ int st_backward(Run& r, ST& m, const float* x, const float* dy, float* dx, int s
     } else {
       CK(r.gemm(lin(c->t_dqkv, 768, k.wqkv_b, nullptr, c->t_dln, D, Mb, D, 768)));        // d(ln1)
       LAUNCH(c, r.s, CAT_ROW, 0, launch_ln_bwd(c->t_dln, zin, k.ln1_g, dz1, dz, Mb, r.s));           // dz (block input)
+    }
     }
   }
   CK(r.gemm(lin(dz, D, m.wpi_b, nullptr, c->t_xn, m.C, Mp, m.C, D)));                   // d(xn)
@@ -1105,7 +1128,8 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
       }
       c->ffx_ablate = av;
     }
-    c->tklb_off = getenv("RAMP_TKLB_OFF") != nullptr;       // diagnostic: d(ln1) + LN1 backward on the tile kernel + ln_bwd pair
+    c->tklb_off = getenv("RAMP_TKLB_OFF") != nullptr;
+    if (const char* e = getenv("RAMP_ABL")) c->abl_on = atoi(e) != 0;      // diagnostic: 0 = attention backward and d(ln1) as separate launches       // diagnostic: d(ln1) + LN1 backward on the tile kernel + ln_bwd pair
   }
   *out = c;
   return 0;
@@ -1331,6 +1355,10 @@ int ramp_finalize_weights(ramp_ctx* c) {
           float* q; CK(dev_alloc(c, &q, 8 * 8192 + 4));
           k.ato_w = reinterpret_cast<unsigned short*>(q); k.ato_wsi = eo.w_scale_inv;
           CK(ato_pack(k.wo_f, 1.f / eo.w_scale_inv, k.ato_w, 0));
+          const auto& eq = c->x6.at(k.wqkv_b);             // the same for the backward half (atl.hip): Wqkv^T in the order its gradient tiles appear
+          float* q2; CK(dev_alloc(c, &q2, 256 * 768 + 4));
+          k.abl_w = reinterpret_cast<unsigned short*>(q2);
+          CK(abl_pack(k.wqkv_b, 1.f / eq.w_scale_inv, k.abl_w, 0));
         }
     }
     if (c->gemm_mode == 2 && c->x6_pipe) {
@@ -1366,6 +1394,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
   CK(init_ffx_attributes());
   CK(init_tkl_attributes());
   CK(init_atk_attributes());
+  CK(init_atl_attributes());
   CK(init_tkc_attributes());
   c->finalized = true;
   return 0;
@@ -2244,6 +2273,39 @@ int ramp_op_atb(const float* qkv, const float* dout, float* dqkv, int32_t M, int
   RAMP_REQUIRE(qkv && dout && dqkv && M > 0 && L > 0, "bad arguments");
   AtbArgs a; a.M = M; a.L = L; a.QKV = qkv; a.dO = dout; a.dQKV = dqkv;
   return launch_atb(a, as_stream(stream));
+}
+
+int ramp_op_abl(const float* qkv, const float* dout, const float* W, const float* z, const float* ln_g, const float* add, int32_t M, int32_t L,
+                float absmax_prev, float* out, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  RAMP_REQUIRE(qkv && dout && W && z && ln_g && add && out && M > 0 && L > 0, "bad arguments");
+  hipStream_t s = as_stream(stream);
+  DevArena ar;
+  std::vector<float> hw((size_t)256 * 768);
+  RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
+  float mx = 0.f;
+  for (float v : hw) mx = std::max(mx, std::fabs(v));
+  float sc = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
+  unsigned short* stream_w = reinterpret_cast<unsigned short*>(ar.alloc((size_t)256 * 768 + 4));
+  float* slots = ar.alloc(4);
+  RAMP_REQUIRE(stream_w && slots, "hipMalloc failed");
+  CK(init_atl_attributes());
+  CK(abl_pack(W, sc, stream_w, s));
+  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
+  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
+  AblArgs a; a.M = M; a.L = L; a.QKV = qkv; a.dO = dout; a.W = stream_w; a.Z = z; a.add = add; a.ln_g = ln_g; a.Y = out;
+  a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
+  a.range_flag = reinterpret_cast<int*>(slots + 2);
+  int rc = launch_abl(a, s);
+  hipError_t e = hipStreamSynchronize(s);
+  float back[4] = {0, 0, 0, 0};
+  if (rc == 0 && e == hipSuccess) {
+    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
+    if (absmax_out_host) *absmax_out_host = back[1];
+    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
+  }
+  RAMP_HIP_CHECK(e);
+  return rc;
 }
 
 int ramp_op_tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, int32_t M,

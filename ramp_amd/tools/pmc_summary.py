@@ -14,7 +14,7 @@ def klass(name):
     if "gemm_x6" in name or "gemm_kernel" in name or "ff_fwd_kernel" in name or "ffx_kernel" in name or "tkl_kernel" in name or "tklb_kernel" in name \
             or "ato_kernel" in name or "tkc_kernel" in name:      # (ato: self-attention + out-projection in one launch, counted with its GEMM)
         return "gemm"
-    if "attn2" in name:
+    if "attn2" in name or "atb_kernel" in name:
         return "attention"
     if "gn_" in name or "ln_" in name or "expand_rows" in name or "combine_rows" in name:
         return "norm_rows"
