@@ -346,6 +346,13 @@ int ramp_op_atb(const float* qkv, const float* dout, float* dqkv, int32_t M, int
  * dqkv (M, 768), W (256, 768) = [Wq | Wk | Wv]^T rows, z / add / out (M, 256), device fp32.  Scaling arguments as ramp_op_tkl. */
 int ramp_op_tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, int32_t M,
                  float absmax_prev, float* out, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
+/* Attention backward, d(ln1) and the LayerNorm-1 backward as ONE launch (atl.hip, abl_kernel; the product path's replacement of
+ * ramp_op_atb + ramp_op_tklb on levels whose token count divides 48 or 32 -- BasicTransformerBlock.forward's `attn1(norm1(x)) + x`,
+ * layers_attention_mini.py:101-127 and :132, differentiated from d(o) back to the block input):
+ *   out = add + LNbwd( attention-backward(qkv, dout) W^T ; z, ln_g ).  Operands as ramp_op_atb / ramp_op_tklb; scaling arguments as
+ * ramp_op_tkl (the operand is d(qkv), which never reaches memory). */
+int ramp_op_abl(const float* qkv, const float* dout, const float* W, const float* z, const float* ln_g, const float* add, int32_t M, int32_t L,
+                float absmax_prev, float* out, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
 /* micro-benchmark (profiling tools only): one GEMM shape on the kernel `mode` names (as ramp_op_gemm_mode), operands
  * allocated and filled inside, weights packed once, `warmup` untimed then `iters` timed back-to-back launches on `stream`
  * between two HIP events; *avg_us = microseconds per launch.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue

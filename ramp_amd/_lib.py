@@ -117,6 +117,7 @@ PROTOTYPES = {
     "ramp_op_tkl": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_ato": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_atb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "ramp_op_abl": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_tklb": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_bench_gemm": (C.c_int, [C.c_int32] * 9 + [c_f32p, C.c_void_p]),
     "ramp_stress_gemm": (C.c_int, [C.c_int32] * 8 + [c_i64p, c_f32p, C.c_void_p]),

@@ -2395,7 +2395,48 @@ thread_local StressHook* g_stress = nullptr;
 
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 14, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 16, "bad arguments");
+  if (mode == 15 || mode == 16) {                      // attention backward + d(ln1) + LN1 backward: abl_kernel (15, atl.hip) / atb_kernel + tklb_kernel (16)
+    hipStream_t sb = as_stream(stream);
+    DevArena arb;
+    RAMP_REQUIRE(L >= 1 && M % L == 0, "mode 15 / 16: M must be whole samples of L tokens");
+    float* Q = arb.alloc((size_t)M * 768); float* D = arb.alloc((size_t)M * 256); float* G = arb.alloc((size_t)M * 768);
+    float* Z = arb.alloc((size_t)M * 256); float* Ad = arb.alloc((size_t)M * 256); float* Y = arb.alloc((size_t)M * 256);
+    float* Wq = arb.alloc((size_t)256 * 768); float* gam = arb.alloc(256); float* slots = arb.alloc(4);
+    unsigned short* ws = reinterpret_cast<unsigned short*>(arb.alloc((size_t)256 * 768 + 4));
+    unsigned short* pl = reinterpret_cast<unsigned short*>(arb.alloc((size_t)256 * 768 + 4));
+    RAMP_REQUIRE(Q && D && G && Z && Ad && Y && Wq && gam && slots && ws && pl, "hipMalloc failed");
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, Q, (long)M * 768, 1u, 1.5f);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, D, (long)M * 256, 3u, 1.f);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, Z, (long)M * 256, 5u, 1.f);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, Ad, (long)M * 256, 7u, 1.f);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(64), dim3(256), 0, sb, Wq, 256l * 768, 9u, 1.f / 16.f);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(1), dim3(256), 0, sb, gam, 256l, 11u, 1.f);
+    CK(init_atl_attributes()); CK(init_tkl_attributes());
+    CK(abl_pack(Wq, 16384.f, ws, sb));
+    CK(launch_pack_h3(Wq, pl, 256, 768, 16384.f, sb));
+    const float host[4] = {4.f, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, sb));
+    AblArgs t; t.M = M; t.L = L; t.QKV = Q; t.dO = D; t.W = ws; t.Z = Z; t.add = Ad; t.ln_g = gam; t.Y = Y;
+    t.amax_in = slots; t.amax_out = slots + 1; t.wsi = 1.f / 16384.f; t.range_flag = nullptr;
+    AtbArgs tb; tb.M = M; tb.L = L; tb.QKV = Q; tb.dO = D; tb.dQKV = G;
+    TklbArgs tl; tl.M = M; tl.X = G; tl.Z = Z; tl.add = Ad; tl.Y = Y; tl.W = pl; tl.ln_g = gam;
+    tl.amax_in = slots; tl.amax_out = slots + 1; tl.wsi = 1.f / 16384.f;
+    auto go = [&]() -> int { if (mode == 15) return launch_abl(t, sb); int rc = launch_atb(tb, sb); return rc ? rc : launch_tklb(tl, sb); };
+    for (int i = 0; i < warmup; ++i) CK(go());
+    hipEvent_t e0, e1;
+    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+    RAMP_HIP_CHECK(hipEventRecord(e0, sb));
+    int rcb = 0;
+    for (int i = 0; i < iters && rcb == 0; ++i) { rcb = go(); if (rcb == 0) STRESS(Y, (size_t)M * 256, sb); }
+    RAMP_HIP_CHECK(hipEventRecord(e1, sb));
+    RAMP_HIP_CHECK(hipEventSynchronize(e1));
+    float msb = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&msb, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = msb * 1e3f / iters;
+    return rcb;
+  }
   if (mode == 13 || mode == 14) {                      // attention backward: atb_kernel (13, atk.hip) / attn2_bwd_kernel (14, attention.hip); L = tokens per sample
     hipStream_t sb = as_stream(stream);
     DevArena arb;

@@ -545,6 +545,57 @@ def test_atb_attention_backward_against_float64_autograd(L, R):
         assert e < 3e-6, (name, e)
 
 
+@pytest.mark.parametrize("L,R", [(48, 4), (48, 9), (24, 7), (12, 33), (6, 131), (16, 5), (32, 3), (8, 40), (4, 9), (3, 50), (1, 100), (48, 1024)])
+def test_abl_attention_backward_with_ln1_backward_against_float64_autograd(L, R):
+    """The backward of `attn1(norm1(x)) + x` from d(o) to the block input in ONE launch (atl.hip abl_kernel through ramp_op_abl: attention
+    backward on sample-owning waves, its gradient tiles projected through Wqkv^T into resident accumulators, LayerNorm backward in the
+    epilogue; d(qkv) never reaches memory) against float64 autograd of LayerNorm -> QKV -> softmax attention (layers_attention_mini.py:
+    101-127, 132): every level length dividing 48 or 32, sample counts that leave the last wave / block partly empty; the recorded operand
+    maximum is max |d(qkv)|, scaling from it leaves the result unchanged to rounding, a stale maximum raises the range flag."""
+    import ctypes as C
+    from ramp_amd import _lib
+    M = R * L
+    gen = torch.Generator(device="cpu").manual_seed(91 * L + R)
+    z = (torch.randn(M, 256, generator=gen) * 1.5 + 0.3)
+    ln_g = 1.0 + 0.2 * torch.randn(256, generator=gen)
+    ln_b = 0.1 * torch.randn(256, generator=gen)
+    Wqkv = torch.randn(768, 256, generator=gen) / 16.0            # forward weight (768, 256); the kernel takes its transpose (256, 768)
+    dout = torch.randn(M, 256, generator=gen)
+    add = torch.randn(M, 256, generator=gen)
+    zd = z.double().clone().requires_grad_(True)
+    ln = torch.nn.functional.layer_norm(zd, (256,), ln_g.double(), ln_b.double(), 1e-5)
+    qkv64 = ln @ Wqkv.double().t()
+    qkv64.retain_grad()
+    y = qkv64.reshape(R, L, 3, 4, 64)
+    q, k, v = y[:, :, 0].transpose(1, 2), y[:, :, 1].transpose(1, 2), y[:, :, 2].transpose(1, 2)
+    o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).transpose(1, 2).reshape(M, 256)
+    o.backward(dout.double())
+    ref = (zd.grad + add.double()).numpy()
+    true_max = float(qkv64.grad.abs().max())
+    qkv = qkv64.detach().float().cuda()
+    Wb = Wqkv.t().contiguous().cuda()
+    dout_d, z_d, g_d, add_d = dout.cuda(), z.cuda(), ln_g.cuda(), add.cuda()
+    lib = _lib.load()
+
+    def run(prev):
+        got = torch.full((M, 256), float("nan"), device="cuda")
+        amax, flag = C.c_float(0), C.c_int32(0)
+        _lib.check(lib.ramp_op_abl(_lib.ptr(qkv), _lib.ptr(dout_d), _lib.ptr(Wb), _lib.ptr(z_d), _lib.ptr(g_d), _lib.ptr(add_d),
+                                   M, L, prev, _lib.ptr(got), C.byref(amax), C.byref(flag), None), "ramp_op_abl")
+        return got.cpu().numpy(), amax.value, flag.value
+
+    got0, amax0, flag0 = run(0.0)
+    assert flag0 == 0 or true_max < 0.125 or true_max >= 60000, flag0
+    assert abs(amax0 - true_max) <= 2e-5 * true_max, (amax0, true_max)
+    got1, amax1, flag1 = run(amax0)
+    assert flag1 == 0
+    for got in (got0, got1):
+        e = rel(got, ref)
+        assert e < 4e-6, e
+    _, _, flag2 = run(amax0 / 4096.0)                             # a stale maximum: the operand leaves the fp16 planes' range
+    assert flag2 == 1
+
+
 @pytest.mark.parametrize("L,R,N,K,extras", [(48, 3, 32, 32, True), (48, 9, 64, 64, True), (24, 7, 64, 32, False), (24, 8, 32, 64, True), (12, 33, 64, 64, True),
                                             (16, 5, 64, 64, False), (32, 3, 32, 32, True), (8, 41, 64, 64, True), (48, 4096, 32, 32, True)])
 @pytest.mark.parametrize("backward", [False, True])
