@@ -324,7 +324,7 @@ void ato_kernel(AtoArgs a, int n_tiles) {
         __builtin_amdgcn_sched_barrier(0);
         const float inv = 8192.f * __builtin_amdgcn_rcpf(sum);               // (the sum's rcp: 1 ulp, a common factor of the column)
 #pragma unroll
-        for (int kg = 0; kg < NG; ++kg) { unsigned h0, h1, l0, l1; split4(st[kg] * inv, h0, h1, l0, l1); ph[kg][qg] = u32x2{h0, h1}; pl[kg][qg] = u32x2{l0, l1}; }
+        for (int kg = 0; kg < NG; ++kg) { unsigned h0, h1, l0, l1; split4m(st[kg] * inv, h0, h1, l0, l1); ph[kg][qg] = u32x2{h0, h1}; pl[kg][qg] = u32x2{l0, l1}; }
         __builtin_amdgcn_sched_barrier(0);
         dma_k_piece(4 * qg + 3);
         __builtin_amdgcn_sched_barrier(0);
@@ -636,7 +636,7 @@ void atb_kernel(AtbArgs a, int n_tiles) {
         x = mm32(hi[t][j], sel[f], x);
         x = mm32(lo[t][j], sel[f], x);
         unsigned h0, h1, l0, l1;
-        split4(x, h0, h1, l0, l1);
+        split4m(x, h0, h1, l0, l1);
         th[t] = u32x2{h0, h1}; tl[t] = u32x2{l0, l1};
       }
       oh[f][0] = cat2(th[0], th[1]); ol[f][0] = cat2(tl[0], tl[1]);
@@ -795,8 +795,8 @@ void atb_kernel(AtbArgs a, int n_tiles) {
           x = mm32(pbh[pr][qg], sel[b], x); x = mm32(pbl[pr][qg], sel[b], x);
           y = mm32(sbh[pr][qg], sel[b], y); y = mm32(sbl[pr][qg], sel[b], y);
           unsigned h0, h1, l0, l1;
-          split4(x, h0, h1, l0, l1); tph[qg][kg] = u32x2{h0, h1}; tpl[qg][kg] = u32x2{l0, l1};
-          split4(y, h0, h1, l0, l1); tsh[qg][kg] = u32x2{h0, h1}; tsl[qg][kg] = u32x2{l0, l1};
+          split4m(x, h0, h1, l0, l1); tph[qg][kg] = u32x2{h0, h1}; tpl[qg][kg] = u32x2{l0, l1};
+          split4m(y, h0, h1, l0, l1); tsh[qg][kg] = u32x2{h0, h1}; tsl[qg][kg] = u32x2{l0, l1};
         }
 #pragma unroll
       for (int kg = 0; kg < NG; ++kg) {

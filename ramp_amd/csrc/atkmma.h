@@ -28,10 +28,35 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
-// four scaled floats -> two dwords of each plane: x = hi + lo (both RNE)
+// two (scaled) floats -> one dword of each fp16 plane: x s = hi + lo, both rounded to nearest even.  lo comes from v_fma_mix{lo,hi}_f16
+// (fp32 fma of x, s and the fp16 hi read in place, rounded to fp16 once): the same bits as (half)(x s - (float)hi) in 4 instructions per
+// pair instead of 7 (hipcc does not form the mixed-precision fma itself)
+__device__ __forceinline__ void split2m(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+  const half2v h = __builtin_convertvector(f32x2{x0 * s, x1 * s}, half2v);
+  hi = __builtin_bit_cast(unsigned, h);
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(l) : "v"(x0), "v"(x1), "v"(s), "v"(hi));
+  lo = l;
+}
+__device__ __forceinline__ void split2m(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const half2v h = __builtin_convertvector(f32x2{x0, x1}, half2v);
+  hi = __builtin_bit_cast(unsigned, h);
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(l) : "v"(x0), "v"(x1), "v"(hi));
+  lo = l;
+}
+// four floats -> two dwords of each plane
+__device__ __forceinline__ void split4m(const f32x4 a, unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
+  split2m(a[0], a[1], h0, l0); split2m(a[2], a[3], h1, l1);
+}
+// four scaled floats -> two dwords of each plane: x s = hi + lo
 __device__ __forceinline__ void split4s(const f32x4 a, float s, u32x2& hi, u32x2& lo) {
   unsigned h0, h1, l0, l1;
-  split4(a * s, h0, h1, l0, l1);
+  split2m(a[0], a[1], s, h0, l0); split2m(a[2], a[3], s, h1, l1);
   hi = u32x2{h0, h1}; lo = u32x2{l0, l1};
 }
 __device__ __forceinline__ u32x4 cat2(const u32x2 a, const u32x2 b) { return u32x4{a[0], a[1], b[0], b[1]}; }

@@ -27,7 +27,8 @@ constexpr int AL_SLAB = 16 * 1024;                      // 8 output blocks of 16
 constexpr int AL_R = 3;                                 // ring slots: slab g + 2 is requested during slab g
 constexpr int AL_NS = 48;                               // slabs per tile: head 4 x part 3 x k32 step 2 x output half 2
 constexpr int AL_GAM = AL_R * AL_SLAB;                  // LayerNorm gamma (256 floats)
-constexpr int AL_RA = AL_GAM + 1024;                    // per wave: operand region A (q -> d(o) -> k -> next q)
+constexpr int AL_SEL = AL_GAM + 1024;                   // the two selection operands: [b 2][lane 64][16 bytes]
+constexpr int AL_RA = AL_SEL + 2048;                    // per wave: operand region A (q -> d(o) -> k -> next q)
 constexpr int AL_RB = AL_RA + 4 * AT_VW;                // per wave: operand region B (k -> v -> q -> next k)
 constexpr size_t AL_LDS = (size_t)AL_RB + 4 * AT_VW;
 static_assert(AL_LDS <= 160 * 1024, "LDS budget");
@@ -68,7 +69,8 @@ int abl_pack(const float* W, float scale, unsigned short* out, hipStream_t s) {
 // | dV slabs: ring + q pieces | dQ slabs: ring + the NEXT head's q pieces | dK slabs: ring + the next head's k pieces.  Every slab issues 4
 // ring pieces (slab g + 2) and up to 3 operand pieces; a slab waits with vmcnt(4): its own pieces are older than the 4 ring pieces of
 // the slab before it.
-template <int NG>
+// STAMP (diagnostic twin, ramp_bench_gemm only): per-wave s_memtime sums of the phases
+template <int NG, bool STAMP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void abl_kernel(AblArgs a, int n_tiles) {
   constexpr int T = 16 * NG;
@@ -76,13 +78,20 @@ void abl_kernel(AblArgs a, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, g = lane >> 4;
+  // (c, g and what follows from them are re-derived from an opaque copy of the lane index at the top of every head and epilogue: left visible,
+  // hipcc hoists some thirty lane-invariant addresses and offsets out of both loops and spills them)
+  int c = lane & 15, g = lane >> 4;
   const int n_my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int n_steps = 4 * n_my;
 
   const float s_in = scale_of(a.amax_in);
   const float os = a.wsi / s_in;
   float amax = 0.f;
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  const unsigned long long t_start = STAMP ? __builtin_amdgcn_s_memtime() : 0, r_start = STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (tlast) tk[k] += t - tlast; tlast = t; }
+  };
 
   reinterpret_cast<float*>(smem + AL_GAM)[tid] = a.ln_g[tid];     // (published by the first slab barrier; first read in the first epilogue)
 
@@ -96,27 +105,30 @@ void abl_kernel(AblArgs a, int n_tiles) {
       for (int i = 0; i < 4; ++i) m |= ((16 * kg + 4 * g + i) / a.L == (16 * qg + c) / a.L ? 1u : 0u) << (4 * kg + i);
     kmask[qg] = m;
   }
-  // selection operands (atb_kernel): as B operand of a k32 step whose A operand pairs two 16-wide blocks, sel[b] picks block b
-  u32x4 sel[2];
+  // selection operands (atb_kernel): as B operand of a k32 step whose A operand pairs two 16-wide blocks, sel[b] picks block b.  Kept in LDS
+  // (a lane's 2 x 16 bytes, read back where an operand is turned): 8 registers less over the whole kernel
+  if (wave == 0) {
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    unsigned w[4];
+    for (int b = 0; b < 2; ++b) {
+      unsigned w[4];
 #pragma unroll
-    for (int p2 = 0; p2 < 4; ++p2) {
-      unsigned v = 0;
+      for (int p2 = 0; p2 < 4; ++p2) {
+        unsigned v = 0;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int e = 2 * p2 + q;
-        if ((e >> 2) == b && 4 * g + (e & 3) == c) v |= 0x3c00u << (16 * q);
+        for (int q = 0; q < 2; ++q) {
+          const int e = 2 * p2 + q;
+          if ((e >> 2) == b && 4 * g + (e & 3) == c) v |= 0x3c00u << (16 * q);
+        }
+        w[p2] = v;
       }
-      w[p2] = v;
+      *reinterpret_cast<u32x4*>(smem + AL_SEL + b * 1024 + lane * 16) = u32x4{w[0], w[1], w[2], w[3]};
     }
-    sel[b] = u32x4{w[0], w[1], w[2], w[3]};
   }
+  const char* selp = nullptr;
   const u32x2 z2 = {0u, 0u};
 
   // ---- weight ring (ato_kernel's): wave w copies bytes [4 w KB, +4 KB) of a 16 KB slab as 4 LDS-DMA pieces of 1 KB
-  const unsigned lane_w = (unsigned)(wave * 4096 + lane * 16);
+  unsigned lane_w = (unsigned)(wave * 4096 + lane * 16);
   int is_g = 0;
   const char* ring_src = nullptr; unsigned ring_dst = 0;
   auto ring_begin = [&]() __attribute__((always_inline)) {
@@ -130,15 +142,25 @@ void abl_kernel(AblArgs a, int n_tiles) {
     switch (cpc) { case 0: AL_PIECE(0); break; case 1: AL_PIECE(1); break; case 2: AL_PIECE(2); break; default: AL_PIECE(3); break; }
   };
   int gs = 0;                                               // slabs consumed
-  const char* rd = smem + lane * 16;
+  const char* rd = nullptr;
 
   // ---- operand regions: one LDS-DMA instruction = the 256-byte head slices of 4 consecutive tokens ("group": 1 KB + 64 bytes of padding),
   // lane -> row lane & 3, chunk lane >> 2 ([chunk][row]); read back with ds_read_b128 as T-layout rows (lane (c, g) = features 16 fb + 4 g ..
   // of token 16 t + c): conflict-free (ato_kernel's k region)
   const int m_last = a.M - 1;
   const unsigned ra_dst = (unsigned)(uintptr_t)(smem + AL_RA + wave * AT_VW), rb_dst = (unsigned)(uintptr_t)(smem + AL_RB + wave * AT_VW);
-  const char* ra_rd = smem + AL_RA + wave * AT_VW + (c >> 2) * AT_VG + 64 * g + 16 * (c & 3);
-  const char* rb_rd = smem + AL_RB + wave * AT_VW + (c >> 2) * AT_VG + 64 * g + 16 * (c & 3);
+  const char* ra_rd = nullptr;
+  const char* rb_rd = nullptr;
+  auto derive = [&]() __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    c = ln & 15; g = ln >> 4;
+    lane_w = (unsigned)(wave * 4096 + ln * 16);
+    rd = smem + ln * 16;
+    selp = smem + AL_SEL + ln * 16;
+    ra_rd = smem + AL_RA + wave * AT_VW + (c >> 2) * AT_VG + 64 * g + 16 * (c & 3);
+    rb_rd = smem + AL_RB + wave * AT_VW + (c >> 2) * AT_VG + 64 * g + 16 * (c & 3);
+  };
   auto op_piece = [&](unsigned dst, const char* base /*scalar: operand + head offset*/, unsigned stride, int tile, int gr) __attribute__((always_inline)) {
     int tk0 = tile * (4 * T) + wave * T + (c & 3);
     asm volatile("" : "+v"(tk0));
@@ -178,13 +200,14 @@ void abl_kernel(AblArgs a, int n_tiles) {
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       u32x2 th[NG], tl[NG];
+      const u32x4 self = *reinterpret_cast<const u32x4*>(selp + f * 1024);
 #pragma unroll
       for (int t = 0; t < NG; ++t) {
         f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        x = mm32(hi[t][j], sel[f], x);
-        x = mm32(lo[t][j], sel[f], x);
+        x = mm32(hi[t][j], self, x);
+        x = mm32(lo[t][j], self, x);
         unsigned h0, h1, l0, l1;
-        split4(x, h0, h1, l0, l1);
+        split4m(x, h0, h1, l0, l1);
         th[t] = u32x2{h0, h1}; tl[t] = u32x2{l0, l1};
       }
       oh[f][0] = cat2(th[0], th[1]); ol[f][0] = cat2(tl[0], tl[1]);
@@ -220,14 +243,11 @@ void abl_kernel(AblArgs a, int n_tiles) {
     const int hs_n = hs + 1 < n_steps ? hs + 1 : hs;        // (the last head re-requests its own rows: unused)
     const int tile_n = (int)blockIdx.x + (hs_n >> 2) * (int)gridDim.x, h_n = hs_n & 3;
     const int hoff = 256 * h;
+    derive();
 #pragma unroll
     for (int nb = 0; nb < 16; ++nb)
 #pragma unroll
       for (int t = 0; t < NG; ++t) asm volatile("" : "+a"(acc[nb][t]));
-
-    float lm[NG];                                           // 0 for tokens past M (their gradients must not reach the recorded maximum)
-#pragma unroll
-    for (int t = 0; t < NG; ++t) lm[t] = (full || tok0 + 16 * t + c < a.M) ? 1.f : 0.f;
 
     // the projection of one k32 step of a gradient part: two slabs (output features [0, 128), [128, 256)); B = the gradient tile's planes.
     // Macro-step m = output block 8 half + m: first MFMA | this macro-step's LDS-DMA pieces | fragment reads of m + 1 | the other MFMAs
@@ -237,6 +257,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
       for (int half = 0; half < 2; ++half) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // slab gs is complete in LDS; every wave has left slab gs - 1
+        stamp(5);
         ring_begin();                                       // slab gs + 2 goes into the slot of slab gs - 1
         const char* sl = rd + (gs % AL_R) * AL_SLAB;
         u32x4 wf[2][2];
@@ -273,6 +294,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
           __builtin_amdgcn_sched_barrier(0);
         }
         ++gs;
+        stamp(6);
       }
     };
     // gradient tile of feature blocks 2 j, 2 j + 1: out^T[d][token] = sum over tokens' (A = turned operand) x (B = planes with the contracted token
@@ -294,16 +316,19 @@ void abl_kernel(AblArgs a, int n_tiles) {
           }
           o2[f] = o * oscale;
         }
-        amax = amax4(o2[0] * lm[t], amax); amax = amax4(o2[1] * lm[t], amax);
+        if (full || tok0 + 16 * t + c < a.M) { amax = amax4(o2[0], amax); amax = amax4(o2[1], amax); }      // (tokens past M: not in the recorded maximum)
         u32x2 h0, l0, h1, l1;
         split4s(o2[0], s_in, h0, l0); split4s(o2[1], s_in, h1, l1);
         gh[t] = cat2(h0, h1); gl[t] = cat2(l0, l1);
       }
       __builtin_amdgcn_sched_barrier(0);
+      stamp(4);
       project(gh, gl, j);
     };
 
+    stamp(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // q in A, k in B (and every older request)
+    stamp(0);
     float sq = 0.f, sk = 0.f, sv = 0.f, sdo = 0.f, sds = 0.f;
     f32x4 pt[NG][NG], ds[NG][NG];                           // P^T, dS^T: [key group][query group], keys in the registers, query on the lane
     // ---- S^T = K Q^T -> P^T (softmax over keys, masked to the query's sample)
@@ -366,7 +391,9 @@ void abl_kernel(AblArgs a, int n_tiles) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    stamp(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // d(o) in A, v in B
+    stamp(2);
     // ---- dP^T = V dO^T ; delta_q = sum_k P dP ; dS^T = P^T (dP^T - delta)
     u32x4 doh[NG][2], dol[NG][2];
     {
@@ -438,10 +465,11 @@ void abl_kernel(AblArgs a, int n_tiles) {
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg) {
           const int pr = kg >> 1, b = kg & 1;
+          const u32x4 selb = *reinterpret_cast<const u32x4*>(selp + b * 1024);
           f32x4 x = {0.f, 0.f, 0.f, 0.f};
-          x = mm32(pbh[pr][qg], sel[b], x); x = mm32(pbl[pr][qg], sel[b], x);
+          x = mm32(pbh[pr][qg], selb, x); x = mm32(pbl[pr][qg], selb, x);
           unsigned h0, h1, l0, l1;
-          split4(x, h0, h1, l0, l1); tph[qg][kg] = u32x2{h0, h1}; tpl[qg][kg] = u32x2{l0, l1};
+          split4m(x, h0, h1, l0, l1); tph[qg][kg] = u32x2{h0, h1}; tpl[qg][kg] = u32x2{l0, l1};
         }
 #pragma unroll
       for (int kg = 0; kg < NG; ++kg) {
@@ -450,6 +478,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    stamp(3);
     // ---- dV^T = dO^T P: A = d(o) turned (feature on the lane, queries in the registers), B = P (queries in the registers, key on the lane);
     // its slabs carry this head's q rows -> B (for dK)
     op_base = qkvb + hoff; op_dst = rb_dst; op_stride = 3072u; op_tile = tile;
@@ -484,10 +513,11 @@ void abl_kernel(AblArgs a, int n_tiles) {
 #pragma unroll
           for (int kg = 0; kg < NG; ++kg) {
             const int pr = kg >> 1, b = kg & 1;
+            const u32x4 selb = *reinterpret_cast<const u32x4*>(selp + b * 1024);
             f32x4 y = {0.f, 0.f, 0.f, 0.f};
-            y = mm32(sbh[pr][qg], sel[b], y); y = mm32(sbl[pr][qg], sel[b], y);
+            y = mm32(sbh[pr][qg], selb, y); y = mm32(sbl[pr][qg], selb, y);
             unsigned h0, h1, l0, l1;
-            split4(y, h0, h1, l0, l1); tsh[qg][kg] = u32x2{h0, h1}; tsl[qg][kg] = u32x2{l0, l1};
+            split4m(y, h0, h1, l0, l1); tsh[qg][kg] = u32x2{h0, h1}; tsl[qg][kg] = u32x2{l0, l1};
           }
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg) {
@@ -509,103 +539,91 @@ void abl_kernel(AblArgs a, int n_tiles) {
     }
   }
     // ================= epilogue of the tile: dz = add + LNbwd(d(ln1); z, gamma)  (rowops.hip ln_bwd_kernel; tklb_kernel's epilogue) ==========
-    // lane (c, g) holds features 16 nb + 4 g + i of tokens 16 t + c: row sums = in-lane over (nb, i) + two shuffles over g.  Pass 1: the four
-    // sums of a row from ONE read of z (about a pivot, the row's first element: no cancellation in the variance); pass 2: z again (L2), outputs.
+    // lane (c, g) holds features 16 nb + 4 g + i of tokens 16 t + c: row sums = in-lane over (nb, i) + two shuffles over g.  One token group
+    // at a time, so that its 64 z values per lane stay in registers between the sums and the outputs (z is read once); the next group's z
+    // rows are requested before this group's outputs.
     {
+      derive();
       const float* gam = reinterpret_cast<const float*>(smem + AL_GAM) + 4 * g;
-      unsigned yoff[NG];
-      float piv[NG];
       const char* zb = reinterpret_cast<const char*>(a.Z);
       const char* ab = reinterpret_cast<const char*>(a.add);
       char* yb = reinterpret_cast<char*>(a.Y);
+      int tk0 = (int)tok0 + c;
+      asm volatile("" : "+v"(tk0));
+      f32x4 zr[2][16];
+      auto z_load = [&](int t) __attribute__((always_inline)) {
+        const unsigned off = (unsigned)min(tk0 + 16 * t, m_last) * 1024u + 16u * (unsigned)g;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) zr[t & 1][nb] = *reinterpret_cast<const f32x4*>(zb + off + 64 * nb);
+      };
+      z_load(0);
 #pragma unroll
       for (int t = 0; t < NG; ++t) {
-        const unsigned tk = (unsigned)min((int)tok0 + 16 * t + c, m_last);
-        yoff[t] = tk * 1024u + 16u * (unsigned)g;
-        piv[t] = *reinterpret_cast<const float*>(zb + tk * 1024u);
-      }
-      float s1[NG], s2[NG], t1[NG], t2[NG];
+        const unsigned yoff = (unsigned)min(tk0 + 16 * t, m_last) * 1024u + 16u * (unsigned)g;
+        f32x4 ad[2][4];
+        auto a_load = [&](int b4) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < NG; ++t) { s1[t] = 0.f; s2[t] = 0.f; t1[t] = 0.f; t2[t] = 0.f; }
-      f32x4 rz[2][2][NG];
-      auto rz_load = [&](int b2) __attribute__((always_inline)) {
+          for (int q = 0; q < 4; ++q) ad[b4 & 1][q] = *reinterpret_cast<const f32x4*>(ab + yoff + 64 * (4 * b4 + q));
+        };
+        a_load(0);
+        if (t + 1 < NG) z_load(t + 1);
+        a_load(1);
+        __builtin_amdgcn_sched_barrier(0);
+        // the four sums of the row about a pivot (the lane's first element of the row's first feature block, taken from lane group 0)
+        const float piv = __shfl(zr[t & 1][0][0], c);
+        float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int t = 0; t < NG; ++t) rz[b2 & 1][q][t] = *reinterpret_cast<const f32x4*>(zb + yoff[t] + 64 * (2 * b2 + q));
-      };
-      rz_load(0); rz_load(1);
-#pragma unroll
-      for (int b2 = 0; b2 < 8; ++b2) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int nb = 2 * b2 + q;
+        for (int nb = 0; nb < 16; ++nb) {
           const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * nb);
+          const f32x4 gq = acc[nb][t] * os * gm;
 #pragma unroll
-          for (int t = 0; t < NG; ++t) {
-            const f32x4 gq = acc[nb][t] * os * gm;
-            const f32x4 zq = rz[b2 & 1][q][t];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float d = zq[e] - piv[t];
-              s1[t] += d; s2[t] += d * d; t1[t] += gq[e]; t2[t] += gq[e] * d;
-            }
+          for (int e = 0; e < 4; ++e) {
+            const float d = zr[t & 1][nb][e] - piv;
+            zr[t & 1][nb][e] = d;
+            s1 += d; s2 += d * d; t1 += gq[e]; t2 += gq[e] * d;
           }
         }
-        if (b2 + 2 < 8) rz_load(b2 + 2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      float mu[NG], rstd[NG], m1[NG], m2[NG];
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
+        t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
+        const float ms = s1 * (1.f / 256.f);
+        const float var = fmaxf(s2 * (1.f / 256.f) - ms * ms, 0.f);
+        const float rstd = 1.f / sqrtf(var + 1e-5f);
+        const float m1 = t1 * (1.f / 256.f);
+        const float m2 = rstd * (t2 - ms * t1) * (1.f / 256.f);     // mean of g x-hat
+        const float r2 = rstd * rstd * m2;
+        // out = (g - m1 - x-hat m2) rstd + add, x-hat = (d - ms) rstd
+        // (every store of a full wave tile unconditional: a store behind a per-lane predicate sits in its own basic block behind vmcnt(0))
+        auto pass2 = [&](bool pred) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < NG; ++t) {
-        s1[t] += __shfl_xor(s1[t], 16); s1[t] += __shfl_xor(s1[t], 32);
-        s2[t] += __shfl_xor(s2[t], 16); s2[t] += __shfl_xor(s2[t], 32);
-        t1[t] += __shfl_xor(t1[t], 16); t1[t] += __shfl_xor(t1[t], 32);
-        t2[t] += __shfl_xor(t2[t], 16); t2[t] += __shfl_xor(t2[t], 32);
-        const float ms = s1[t] * (1.f / 256.f);
-        const float var = fmaxf(s2[t] * (1.f / 256.f) - ms * ms, 0.f);
-        rstd[t] = 1.f / sqrtf(var + 1e-5f);
-        mu[t] = piv[t] + ms;
-        m1[t] = t1[t] * (1.f / 256.f);
-        m2[t] = rstd[t] * (t2[t] - ms * t1[t]) * (1.f / 256.f);     // mean of g x-hat
-      }
-      f32x4 ra[2][2][NG];
-      auto ra_load = [&](int b2) __attribute__((always_inline)) {
+          for (int b4 = 0; b4 < 4; ++b4) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int t = 0; t < NG; ++t) {
-            rz[b2 & 1][q][t] = *reinterpret_cast<const f32x4*>(zb + yoff[t] + 64 * (2 * b2 + q));
-            ra[b2 & 1][q][t] = *reinterpret_cast<const f32x4*>(ab + yoff[t] + 64 * (2 * b2 + q));
-          }
-      };
-      // (every store of a full wave tile unconditional: a store behind a per-lane predicate sits in its own basic block behind vmcnt(0))
-      auto pass2 = [&](bool pred) __attribute__((always_inline)) {
-        ra_load(0); ra_load(1);
-#pragma unroll
-        for (int b2 = 0; b2 < 8; ++b2) {
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int nb = 2 * b2 + q;
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * nb);
-#pragma unroll
-            for (int t = 0; t < NG; ++t) {
+            for (int q = 0; q < 4; ++q) {
+              const int nb = 4 * b4 + q;
+              const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * nb);
               const f32x4 gq = acc[nb][t] * os * gm;
-              const f32x4 zq = rz[b2 & 1][q][t];
               f32x4 o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (gq[e] - m1[t] - (zq[e] - mu[t]) * rstd[t] * m2[t]) * rstd[t] + ra[b2 & 1][q][t][e];
-              if (!pred || tok0 + 16 * t + c < a.M) *reinterpret_cast<f32x4*>(yb + yoff[t] + 64 * nb) = o;
+              for (int e = 0; e < 4; ++e) o[e] = (gq[e] - m1) * rstd - (zr[t & 1][nb][e] - ms) * r2 + ad[b4 & 1][q][e];
+              if (!pred || tk0 + 16 * t < a.M) *reinterpret_cast<f32x4*>(yb + yoff + 64 * nb) = o;
             }
+            if (b4 + 2 < 4) a_load(b4 + 2);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          if (b2 + 2 < 8) ra_load(b2 + 2);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      if (full) pass2(false); else pass2(true);
+        };
+        if (full) pass2(false); else pass2(true);
+      }
     }
+    stamp(7);
   }
 #undef AL_PIECE
+  if (STAMP && a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((long)blockIdx.x * 4 + wave) * 10;
+    for (int k = 0; k < 8; ++k) o[k] = tk[k];
+    o[8] = __builtin_amdgcn_s_memtime() - t_start;          // shader cycles of the whole kernel ..
+    o[9] = __builtin_amdgcn_s_memrealtime() - r_start;      // .. over 100 MHz ticks: the clock it ran at
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the block
 
   amax = wave_max(amax);
@@ -629,7 +647,11 @@ int launch_abl(const AblArgs& a, hipStream_t s) {
   }
   const int T = 16 * ng, n_tiles = (a.M + 4 * T - 1) / (4 * T);
   const int nb = std::min(n_tiles, device_cu_count());
-  if (ng == 3) hipLaunchKernelGGL((abl_kernel<3>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
+  if (a.stamps) {
+    RAMP_REQUIRE(ng == 3, "abl: the stamped twin exists for T = 48");
+    hipLaunchKernelGGL((abl_kernel<3, true>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
+  }
+  else if (ng == 3) hipLaunchKernelGGL((abl_kernel<3>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
   else hipLaunchKernelGGL((abl_kernel<2>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
@@ -638,6 +660,7 @@ int launch_abl(const AblArgs& a, hipStream_t s) {
 int init_atl_attributes() {
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
   return 0;
 }
 

@@ -228,6 +228,7 @@ struct AblArgs {
   float* Y = nullptr;                  // [M][256]
   const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;
   int* range_flag = nullptr;
+  unsigned long long* stamps = nullptr; // diagnostic (ramp_bench_gemm): per wave 8 phase sums + 2 totals
 };
 int launch_abl(const AblArgs& a, hipStream_t s);
 int abl_pack(const float* W /*[256][768] fp32, device*/, float scale, unsigned short* out /*48 * 16 KB*/, hipStream_t s);

@@ -2422,6 +2422,14 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     AtbArgs tb; tb.M = M; tb.L = L; tb.QKV = Q; tb.dO = D; tb.dQKV = G;
     TklbArgs tl; tl.M = M; tl.X = G; tl.Z = Z; tl.add = Ad; tl.Y = Y; tl.W = pl; tl.ln_g = gam;
     tl.amax_in = slots; tl.amax_out = slots + 1; tl.wsi = 1.f / 16384.f;
+    unsigned long long* stamps = nullptr;
+    if (flags & 256) {
+      RAMP_REQUIRE(mode == 15, "stamps: mode 15");
+      stamps = reinterpret_cast<unsigned long long*>(arb.alloc(256 * 4 * 10 * 2));
+      RAMP_REQUIRE(stamps, "hipMalloc failed");
+      RAMP_HIP_CHECK(hipMemsetAsync(stamps, 0, 256 * 4 * 10 * 8, sb));
+      t.stamps = stamps;
+    }
     auto go = [&]() -> int { if (mode == 15) return launch_abl(t, sb); int rc = launch_atb(tb, sb); return rc ? rc : launch_tklb(tl, sb); };
     for (int i = 0; i < warmup; ++i) CK(go());
     hipEvent_t e0, e1;
@@ -2435,6 +2443,18 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     RAMP_HIP_CHECK(hipEventElapsedTime(&msb, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_us = msb * 1e3f / iters;
+    if (rcb == 0 && stamps) {
+      std::vector<unsigned long long> hst(256 * 4 * 10);
+      RAMP_HIP_CHECK(hipMemcpy(hst.data(), stamps, hst.size() * 8, hipMemcpyDeviceToHost));
+      double sm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int nw = 0;
+      for (int w = 0; w < 1024; ++w) if (hst[w * 10 + 8]) { ++nw; for (int j = 0; j < 10; ++j) sm[j] += (double)hst[w * 10 + j]; }
+      const int n_tiles = (M + 191) / 192;
+      const double tiles = std::max(1, nw) * (double)((n_tiles + 255) / 256);
+      fprintf(stderr, "[abl stamps] per wave tile (s_memtime ticks, %d waves): head-start waits %.0f, S^T + softmax %.0f, d(o) / v waits %.0f, dP + dS + planes + P turned %.0f, "
+              "turn + contract (x 24) %.0f, slab waits + barriers (x 48) %.0f, slab bodies %.0f, epilogue + loop tops %.0f; whole kernel %.0f per tile; shader clock %.0f MHz\n",
+              nw, sm[0] / tiles, sm[1] / tiles, sm[2] / tiles, sm[3] / tiles, sm[4] / tiles, sm[5] / tiles, sm[6] / tiles, sm[7] / tiles, sm[8] / tiles,
+              sm[9] > 0 ? sm[8] / sm[9] * 100.0 : 0.0);
+    }
     return rcb;
   }
   if (mode == 13 || mode == 14) {                      // attention backward: atb_kernel (13, atk.hip) / attn2_bwd_kernel (14, attention.hip); L = tokens per sample

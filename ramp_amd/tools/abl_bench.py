@@ -10,7 +10,7 @@ from ramp_amd import _lib
 lib = _lib.load()
 cases = ((48, 4096), (48, 8192), (24, 8192), (12, 8192), (6, 8192))
 if len(sys.argv) > 1:
-    cases = cases[:int(sys.argv[1])]
+    cases = cases[:int(sys.argv[1])] if sys.argv[1].isdigit() else cases
 for L, R in cases:
     M = L * R
     row = []
@@ -22,3 +22,7 @@ for L, R in cases:
             best = min(best, us.value)
         row.append(best)
     print(f"L={L:3d} rows={R:5d} tokens={M:7d}: abl {row[0]:8.1f} us   atb + tklb {row[1]:8.1f} us   x{row[1] / row[0]:.2f}", flush=True)
+if "--stamps" in sys.argv:
+    us = C.c_float(0)
+    _lib.check(lib.ramp_bench_gemm(48 * 8192, 256, 256, 1, 48, 15, 256, 2, 5, C.byref(us), None), "ramp_bench_gemm")
+    print(f"stamped twin: {us.value:.1f} us", flush=True)
