@@ -303,8 +303,7 @@ void ato_kernel(AtoArgs a, int n_tiles) {
             st[kg][i] = v;
             mx = fmaxf(mx, v);
           }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = gmax(mx);
         __builtin_amdgcn_sched_barrier(0);
         dma_k_piece(4 * qg + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -317,8 +316,7 @@ void ato_kernel(AtoArgs a, int n_tiles) {
             st[kg][i] = e;
             sum += e;
           }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = gsum(sum);
         __builtin_amdgcn_sched_barrier(0);
         dma_k_piece(4 * qg + 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -700,15 +698,13 @@ void atb_kernel(AtbArgs a, int n_tiles) {
             st[kg][i] = v;
             mx = fmaxf(mx, v);
           }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = gmax(mx);
         float sum = 0.f;
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg)
 #pragma unroll
           for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(st[kg][i] - mx); st[kg][i] = e; sum += e; }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = gsum(sum);
         const float inv = 1.f / sum;
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg) pt[kg][qg] = st[kg] * inv;
@@ -743,8 +739,7 @@ void atb_kernel(AtbArgs a, int n_tiles) {
         for (int kg = 0; kg < NG; ++kg)
 #pragma unroll
           for (int i = 0; i < 4; ++i) delta += pt[kg][qg][i] * dp[kg][i];
-        delta += __shfl_xor(delta, 16);
-        delta += __shfl_xor(delta, 32);
+        delta = gsum(delta);
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg) {
 #pragma unroll

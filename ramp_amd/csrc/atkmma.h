@@ -23,10 +23,40 @@ __device__ __forceinline__ float pow2_scale(float mx, int target) {
   }
   return s;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+// cross-lane reductions without LDS round trips (ds_bpermute: ~100 cycles of latency each, and these chains are serial).  A 16-lane row by
+// DPP (one instruction per step; s_nop 1 = the two wait states between a VALU write and a DPP read of the same register), the four rows by
+// v_permlane16_swap / v_permlane32_swap (gfx950): swapping a value with a copy of itself leaves [r0, r0, r2, r2] and [r1, r1, r3, r3] -- the
+// two operands of the xor-16 step in every lane; likewise the two halves for xor 32.  Same values, same order as the __shfl_xor chains.
+// (inline asm: this toolchain's __builtin_amdgcn_permlane16_swap / 32_swap hands back its first result twice; s_nop 1 on either side = the
+// wait states the hazard recogniser puts around the instruction when it emits it itself)
+__device__ __forceinline__ void rows_swap(float v, float& a, float& b) {      // a = [r0, r0, r2, r2], b = [r1, r1, r3, r3] of v's 16-lane rows
+  a = v; b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void halves_swap(float v, float& a, float& b) {    // a = [lower half, lower half], b = [upper half, upper half]
+  a = v; b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float gmax(float v) {          // max over the lanes c, c + 16, c + 32, c + 48, in all of them
+  float a, b;
+  rows_swap(v, a, b); v = fmaxf(a, b);
+  halves_swap(v, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float gsum(float v) {          // sum over the lanes c, c + 16, c + 32, c + 48: (own + xor 16) + (the same of xor 32)
+  float a, b;
+  rows_swap(v, a, b); v = a + b;
+  halves_swap(v, a, b); return a + b;
+}
+__device__ __forceinline__ float wave_max(float v) {      // max over the wave (v >= 0), in every lane
+  // (s_nop 4: a VALU write of EXEC -- v_cmpx of a branch around this call -- needs 5 wait states before a DPP instruction, and the hazard
+  // recogniser does not look into inline asm; the trailing s_nop 1 covers the permlane swap that reads the result)
+  asm("s_nop 4\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+      : "+v"(v));
+  return gmax(v);
 }
 // two (scaled) floats -> one dword of each fp16 plane: x s = hi + lo, both rounded to nearest even.  lo comes from v_fma_mix{lo,hi}_f16
 // (fp32 fma of x, s and the fp16 hi read in place, rounded to fp16 once): the same bits as (half)(x s - (float)hi) in 4 instructions per

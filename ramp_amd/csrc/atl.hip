@@ -33,6 +33,59 @@ constexpr int AL_RB = AL_RA + 4 * AT_VW;                // per wave: operand reg
 constexpr size_t AL_LDS = (size_t)AL_RB + 4 * AT_VW;
 static_assert(AL_LDS <= 160 * 1024, "LDS budget");
 
+// ---- the LDS-DMA schedule of a head, simulated at compile time (the kernel's issue order, request by request) -----------------------
+// Phases: 0 softmax side (4 NG points: d(o) -> A) | 1 dV (v -> B, then k -> A) | 2 dP / dS (2 NG points: first half of q -> B) | 3 dQ (rest of
+// q -> B, then the next head's q -> A) | 4 dK (the next head's k -> B).  A part phase (1, 3, 4) has two k32 steps of 12 points: 6 in the turn +
+// contraction, 3 in each of its two slabs (macro-steps 1, 4, 7); every slab also issues the 4 ring pieces of slab g + 2 (macro-steps 0, 2, 4, 6).
+// Point p of a phase issues piece p of the phase's stream list, if there is one.  The result: for every consumer the number of requests
+// issued BEHIND its data, i.e. the vmcnt it may wait with.
+struct AblSched {
+  int slab[12];                                         // per slab of the head (-1: requested in the head before, landed at its start)
+  int w_do, w_v, w_k, w_q;                              // before the region reads of d(o) (dV), v (dP), k (dQ), q (dK)
+};
+constexpr int abl_phase_pieces(int ph, int GR) { return ph == 0 ? GR : ph == 1 ? 2 * GR : ph == 2 ? GR / 2 : ph == 3 ? GR / 2 + GR : GR; }
+constexpr AblSched abl_make_sched(int NG) {
+  const int GR = 4 * NG;
+  AblSched r = {};
+  int issued = 0, sl = 0;
+  int ring_mark[AL_R] = {0, 0, 0};
+  int mk_do = 0, mk_v = 0, mk_k = 0, mk_q = 0;
+  for (int p = 0; p < 4 * NG; ++p) if (p < abl_phase_pieces(0, GR)) { ++issued; if (p == GR - 1) mk_do = issued; }
+  for (int ph = 1; ph <= 4; ++ph) {
+    if (ph == 1) r.w_do = issued - mk_do;
+    if (ph == 2) {
+      r.w_v = issued - mk_v;
+      for (int p = 0; p < 2 * NG; ++p) if (p < abl_phase_pieces(2, GR)) ++issued;
+      continue;
+    }
+    if (ph == 3) r.w_k = issued - mk_k;
+    if (ph == 4) r.w_q = issued - mk_q;
+    const int np = abl_phase_pieces(ph, GR);
+    int p = 0;
+    auto pt = [&]() {
+      if (p < np) {
+        ++issued;
+        if (ph == 1 && p == GR - 1) mk_v = issued;
+        if (ph == 1 && p == 2 * GR - 1) mk_k = issued;
+        if (ph == 3 && p == GR / 2 - 1) mk_q = issued;
+      }
+      ++p;
+    };
+    for (int j = 0; j < 2; ++j) {
+      for (int k = 0; k < 6; ++k) pt();
+      for (int half = 0; half < 2; ++half) {
+        r.slab[sl] = sl >= 2 ? issued - ring_mark[sl % AL_R] : -1;
+        for (int m = 0; m < 8; ++m) {
+          if (!(m & 1)) { ++issued; if (m == 6) ring_mark[(sl + 2) % AL_R] = issued; }
+          if (m == 1 || m == 4 || m == 7) pt();
+        }
+        ++sl;
+      }
+    }
+  }
+  return r;
+}
+
 }  // namespace
 
 // ---- weight stream ----------------------------------------------------------------------------------------------------------------------
@@ -65,10 +118,10 @@ int abl_pack(const float* W, float scale, unsigned short* out, hipStream_t s) {
   return 0;
 }
 
-// Vector-memory order of a head: wait(0) | S^T / softmax: d(o), v pieces (two at each of its 4 NG points) | wait(0) | dP^T / dS^T: k pieces
-// | dV slabs: ring + q pieces | dQ slabs: ring + the NEXT head's q pieces | dK slabs: ring + the next head's k pieces.  Every slab issues 4
-// ring pieces (slab g + 2) and up to 3 operand pieces; a slab waits with vmcnt(4): its own pieces are older than the 4 ring pieces of
-// the slab before it.
+// Order of a head (wave-local): [q (A), k (B) -> planes] S^T, softmax -> P^T | P turned | [d(o) (A) -> planes] dV^T and its 4 slabs | [v (B)]
+// dP^T, dS^T | [k (A)] dQ^T and its 4 slabs | dS turned, [q (B)] dK^T and its 4 slabs.  dV comes before dS because it needs neither v nor dS:
+// that leaves the softmax phase only d(o) to fetch and gives v the whole dV phase to arrive.  Every slab issues the 4 ring pieces of slab
+// g + 2; the operand pieces ride on the "points" of all phases (see the schedule in the kernel).
 // STAMP (diagnostic twin, ramp_bench_gemm only): per-wave s_memtime sums of the phases
 template <int NG, bool STAMP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -84,7 +137,8 @@ void abl_kernel(AblArgs a, int n_tiles) {
   const int n_my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int n_steps = 4 * n_my;
 
-  const float s_in = scale_of(a.amax_in);
+  // (wave-uniform, said so: a loaded value otherwise occupies a vector register for the whole kernel)
+  const float s_in = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(a.amax_in))));
   const float os = a.wsi / s_in;
   float amax = 0.f;
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -195,27 +249,6 @@ void abl_kernel(AblArgs a, int n_tiles) {
         hi[t][j] = cat2(h0, h1); lo[t][j] = cat2(l0, l1);
       }
   };
-  // T-layout planes of one k32 step of ALL token groups -> planes with the feature on the lane and the tokens in the registers (atb_kernel)
-  auto turn = [&](const u32x4 (&hi)[NG][2], const u32x4 (&lo)[NG][2], int j, u32x4 (&oh)[2][2], u32x4 (&ol)[2][2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      u32x2 th[NG], tl[NG];
-      const u32x4 self = *reinterpret_cast<const u32x4*>(selp + f * 1024);
-#pragma unroll
-      for (int t = 0; t < NG; ++t) {
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        x = mm32(hi[t][j], self, x);
-        x = mm32(lo[t][j], self, x);
-        unsigned h0, h1, l0, l1;
-        split4m(x, h0, h1, l0, l1);
-        th[t] = u32x2{h0, h1}; tl[t] = u32x2{l0, l1};
-      }
-      oh[f][0] = cat2(th[0], th[1]); ol[f][0] = cat2(tl[0], tl[1]);
-      oh[f][1] = NG == 3 ? cat2(th[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
-      ol[f][1] = NG == 3 ? cat2(tl[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
-    }
-  };
-
   // prologue: slabs 0, 1; the first head's q -> A, k -> B
   ring_begin(); ring_piece(0); ring_piece(1); ring_piece(2); ring_piece(3);
   ring_begin(); ring_piece(0); ring_piece(1); ring_piece(2); ring_piece(3);
@@ -249,17 +282,51 @@ void abl_kernel(AblArgs a, int n_tiles) {
 #pragma unroll
       for (int t = 0; t < NG; ++t) asm volatile("" : "+a"(acc[nb][t]));
 
+    // ---- the head's LDS-DMA schedule (abl_make_sched): the pieces ride on "points" spread over every phase of the head, because a CU sustains
+    // ~1 KB per wave and ~360 cycles and a wave that issues faster than that stalls with all of its MFMA work behind it; a consumer waits
+    // with vmcnt(requests issued behind its data).  Phase and point index are literals after unrolling.
+    constexpr AblSched SC = abl_make_sched(NG);
+#define AL_WAIT(N) do { switch (N) { \
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break; \
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;   case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break; \
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;   case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break; \
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;   case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break; \
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;   case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break; \
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break; case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break; \
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break; case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break; \
+      case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break; case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break; \
+      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break; case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break; \
+      case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break; case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break; \
+      case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break; case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break; \
+      case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break; case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break; \
+      default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break; } } while (0)
+    auto point = [&](int ph, int p) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (ph == 0) { if (p < GR) op_piece(ra_dst, dob + hoff, 1024u, tile, p); }                              // d(o)      -> A
+      else if (ph == 1) {
+        if (p < GR) op_piece(rb_dst, qkvb + 2048 + hoff, 3072u, tile, p);                                     // v         -> B
+        else if (p < 2 * GR) op_piece(ra_dst, qkvb + 1024 + hoff, 3072u, tile, p - GR);                       // k again   -> A
+      }
+      else if (ph == 2) { if (p < GR / 2) op_piece(rb_dst, qkvb + hoff, 3072u, tile, p); }                    // q again   -> B, first half
+      else if (ph == 3) {
+        if (p < GR / 2) op_piece(rb_dst, qkvb + hoff, 3072u, tile, GR / 2 + p);                               // q again   -> B, the rest
+        else if (p < GR / 2 + GR) op_piece(ra_dst, qkvb + 256 * h_n, 3072u, tile_n, p - GR / 2);              // next q    -> A
+      }
+      else { if (p < GR) op_piece(rb_dst, qkvb + 1024 + 256 * h_n, 3072u, tile_n, p); }                       // next k    -> B
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
     // the projection of one k32 step of a gradient part: two slabs (output features [0, 128), [128, 256)); B = the gradient tile's planes.
     // Macro-step m = output block 8 half + m: first MFMA | this macro-step's LDS-DMA pieces | fragment reads of m + 1 | the other MFMAs
-    const char* op_base = nullptr; unsigned op_dst = 0, op_stride = 0; int op_tile = 0;
-    auto project = [&](const u32x4 (&bh)[NG], const u32x4 (&bl)[NG], int j) __attribute__((always_inline)) {
+    auto project = [&](const u32x4 (&bh)[NG], const u32x4 (&bl)[NG], int ph, int j) __attribute__((always_inline)) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const int sl_i = 4 * (ph == 1 ? 0 : ph == 3 ? 1 : 2) + 2 * j + half;      // slab of the head (12 per head: the ring slot index is head-local)
+        if (SC.slab[sl_i] >= 0) AL_WAIT(SC.slab[sl_i]);         // (slabs 0, 1 of a head: requested in the head before, landed at its start)
         __builtin_amdgcn_s_barrier();                       // slab gs is complete in LDS; every wave has left slab gs - 1
         stamp(5);
         ring_begin();                                       // slab gs + 2 goes into the slot of slab gs - 1
-        const char* sl = rd + (gs % AL_R) * AL_SLAB;
+        const char* sl = rd + (sl_i % AL_R) * AL_SLAB;
         u32x4 wf[2][2];
         wf[0][0] = *reinterpret_cast<const u32x4*>(sl); wf[0][1] = *reinterpret_cast<const u32x4*>(sl + 1024);
 #pragma unroll
@@ -270,10 +337,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
           acc[nb][0] = mm32(wh, bl[0], acc[nb][0]);
           __builtin_amdgcn_sched_barrier(0);
           if (!(m & 1)) ring_piece(m >> 1);
-          if (m == 1 || m == 4 || m == 7) {
-            const int gr = 3 * (2 * j + half) + m / 3;
-            if (gr < GR) op_piece(op_dst, op_base, op_stride, op_tile, gr);
-          }
+          if (m == 1 || m == 4 || m == 7) point(ph, 12 * j + 6 + 3 * half + m / 3);
           __builtin_amdgcn_sched_barrier(0);
           if (m + 1 < 8) {
             wf[(m + 1) & 1][0] = *reinterpret_cast<const u32x4*>(sl + ((m + 1) * 2) * 1024);
@@ -297,11 +361,32 @@ void abl_kernel(AblArgs a, int n_tiles) {
         stamp(6);
       }
     };
-    // gradient tile of feature blocks 2 j, 2 j + 1: out^T[d][token] = sum over tokens' (A = turned operand) x (B = planes with the contracted token
-    // in the registers, [pair][free token group]); true scale -> recorded maximum -> planes at the call site's scale -> projection
-    auto contract_project = [&](const u32x4 (&ah)[2][2], const u32x4 (&al)[2][2], const u32x4 (&bh)[2][NG], const u32x4 (&bl)[2][NG], int j,
-                                float oscale) __attribute__((always_inline)) {
+    // one k32 step (feature blocks 2 j, 2 j + 1) of a gradient part: the T-layout operand turned (feature on the lane, tokens in the registers;
+    // atb_kernel), out^T[d][token] = sum over tokens' (A = turned operand) x (B = planes with the contracted token in the registers, [pair][free
+    // token group]); true scale -> recorded maximum -> planes at the call site's scale -> projection.  6 points.
+    auto part_step = [&](int ph, const u32x4 (&xh)[NG][2], const u32x4 (&xl)[NG][2], const u32x4 (&bh)[2][NG], const u32x4 (&bl)[2][NG], int j,
+                         float oscale) __attribute__((always_inline)) {
+      u32x4 ah[2][2], al[2][2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        u32x2 th[NG], tl[NG];
+        const u32x4 self = *reinterpret_cast<const u32x4*>(selp + f * 1024);
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+          f32x4 x = {0.f, 0.f, 0.f, 0.f};
+          x = mm32(xh[t][j], self, x);
+          x = mm32(xl[t][j], self, x);
+          unsigned h0, h1, l0, l1;
+          split4m(x, h0, h1, l0, l1);
+          th[t] = u32x2{h0, h1}; tl[t] = u32x2{l0, l1};
+        }
+        ah[f][0] = cat2(th[0], th[1]); al[f][0] = cat2(tl[0], tl[1]);
+        ah[f][1] = NG == 3 ? cat2(th[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
+        al[f][1] = NG == 3 ? cat2(tl[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
+        point(ph, 12 * j + f);
+      }
       u32x4 gh[NG], gl[NG];
+      float omax = 0.f;
 #pragma unroll
       for (int t = 0; t < NG; ++t) {
         f32x4 o2[2];
@@ -314,40 +399,33 @@ void abl_kernel(AblArgs a, int n_tiles) {
             o = mm32(al[f][pr], bh[pr][t], o);
             o = mm32(ah[f][pr], bh[pr][t], o);
           }
-          o2[f] = o * oscale;
+          o2[f] = o;
         }
-        if (full || tok0 + 16 * t + c < a.M) { amax = amax4(o2[0], amax); amax = amax4(o2[1], amax); }      // (tokens past M: not in the recorded maximum)
+        point(ph, 12 * j + 2 + t);
+        if (full || tok0 + 16 * t + c < a.M) { omax = amax4(o2[0], omax); omax = amax4(o2[1], omax); }      // (tokens past M: not in the recorded maximum)
         u32x2 h0, l0, h1, l1;
-        split4s(o2[0], s_in, h0, l0); split4s(o2[1], s_in, h1, l1);
+        split4s(o2[0], oscale * s_in, h0, l0); split4s(o2[1], oscale * s_in, h1, l1);      // (powers of two: one exact scaling)
         gh[t] = cat2(h0, h1); gl[t] = cat2(l0, l1);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      amax = fmaxf(amax, omax * oscale);
+      if (NG == 2) point(ph, 12 * j + 4);
+      point(ph, 12 * j + 5);
       stamp(4);
-      project(gh, gl, j);
+      project(gh, gl, ph, j);
     };
 
     stamp(7);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // q in A, k in B (and every older request)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // q in A, k in B (and every older request: the ring slabs of this head's first two)
     stamp(0);
     float sq = 0.f, sk = 0.f, sv = 0.f, sdo = 0.f, sds = 0.f;
-    f32x4 pt[NG][NG], ds[NG][NG];                           // P^T, dS^T: [key group][query group], keys in the registers, query on the lane
-    // ---- S^T = K Q^T -> P^T (softmax over keys, masked to the query's sample)
+    f32x4 pt[NG][NG];                                       // P^T: [key group][query group], keys in the registers, query on the lane
+    // ---- S^T = K Q^T -> P^T (softmax over keys, masked to the query's sample); d(o) -> A, one piece at each of its 4 NG points
     {
       u32x4 qh[NG][2], ql[NG][2], kh[NG][2], kl[NG][2];
       { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sq, qh, ql); }
       { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sk, kh, kl); }
       __builtin_amdgcn_sched_barrier(0);
-      // both regions are free (their rows are planes): d(o) -> A, v -> B, two pieces at each of the 4 NG points below
-      auto p0_pieces = [&](int pt_i) __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          const int p = 2 * pt_i + k2;
-          if (p < GR) op_piece(ra_dst, dob + hoff, 1024u, tile, p);
-          else op_piece(rb_dst, qkvb + 2048 + hoff, 3072u, tile, p - GR);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
+      // (both regions are free: their rows are planes)
       const float ssc = 0.125f * 1.4426950408889634f / (sq * sk);
 #pragma unroll
       for (int qg = 0; qg < NG; ++qg) {
@@ -363,7 +441,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
           }
           st[kg] = x;
         }
-        p0_pieces(4 * qg);
+        point(0, 4 * qg);
         float mx = -3.0e38f;
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg)
@@ -373,90 +451,34 @@ void abl_kernel(AblArgs a, int n_tiles) {
             st[kg][i] = v;
             mx = fmaxf(mx, v);
           }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        p0_pieces(4 * qg + 1);
+        mx = gmax(mx);
+        point(0, 4 * qg + 1);
         float sum = 0.f;
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg)
 #pragma unroll
           for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(st[kg][i] - mx); st[kg][i] = e; sum += e; }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        p0_pieces(4 * qg + 2);
+        sum = gsum(sum);
+        point(0, 4 * qg + 2);
         const float inv = 1.f / sum;
 #pragma unroll
         for (int kg = 0; kg < NG; ++kg) pt[kg][qg] = st[kg] * inv;
-        p0_pieces(4 * qg + 3);
+        point(0, 4 * qg + 3);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     stamp(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // d(o) in A, v in B
-    stamp(2);
-    // ---- dP^T = V dO^T ; delta_q = sum_k P dP ; dS^T = P^T (dP^T - delta)
-    u32x4 doh[NG][2], dol[NG][2];
-    {
-      u32x4 vh[NG][2], vl[NG][2];
-      { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sv, vh, vl); }
-      { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sdo, doh, dol); }
-      __builtin_amdgcn_sched_barrier(0);
-      // A is free: k (for dQ) -> A, one piece at each of the 4 NG points below
-      auto p1_piece = [&](int p) __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (p < GR) op_piece(ra_dst, qkvb + 1024 + hoff, 3072u, tile, p);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      const float dsc = 1.f / (sv * sdo);
-      float dmax = 0.f;
-#pragma unroll
-      for (int qg = 0; qg < NG; ++qg) {
-        f32x4 dp[NG];
-#pragma unroll
-        for (int kg = 0; kg < NG; ++kg) {
-          f32x4 x = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            x = mm32(vh[kg][j], dol[qg][j], x);
-            x = mm32(vl[kg][j], doh[qg][j], x);
-            x = mm32(vh[kg][j], doh[qg][j], x);
-          }
-          dp[kg] = x * dsc;
-          if (kg < 2) p1_piece(4 * qg + kg);
-        }
-        float delta = 0.f;
-#pragma unroll
-        for (int kg = 0; kg < NG; ++kg)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) delta += pt[kg][qg][i] * dp[kg][i];
-        delta += __shfl_xor(delta, 16);
-        delta += __shfl_xor(delta, 32);
-        p1_piece(4 * qg + 2);
-#pragma unroll
-        for (int kg = 0; kg < NG; ++kg) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) ds[kg][qg][i] = pt[kg][qg][i] * (dp[kg][i] - delta);
-          dmax = amax4(ds[kg][qg], dmax);
-        }
-        p1_piece(4 * qg + 3);
-      }
-      sds = pow2_scale(wave_max(dmax), 13);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // planes of P^T (x 2^13) and dS^T (x sds) as token-contracting B operands: [key-group pair][query group]
-    u32x4 sbh[2][NG], sbl[2][NG];
-    u32x4 pqh[2][NG], pql[2][NG];                           // P with the QUERY in the registers and the key on the lane: [query-group pair][key group]
+    // ---- P with the QUERY in the registers and the key on the lane (turned tile by tile by the selection MFMA): dV's B operand
+    u32x4 pqh[2][NG], pql[2][NG];                           // [query-group pair][key group]
     {
       u32x4 pbh[2][NG], pbl[2][NG];
 #pragma unroll
       for (int qg = 0; qg < NG; ++qg) {
-        u32x2 ph[NG], pl[NG], sh[NG], sl[NG];
+        u32x2 ph[NG], pl[NG];
 #pragma unroll
-        for (int kg = 0; kg < NG; ++kg) { split4s(pt[kg][qg], 8192.f, ph[kg], pl[kg]); split4s(ds[kg][qg], sds, sh[kg], sl[kg]); }
+        for (int kg = 0; kg < NG; ++kg) split4s(pt[kg][qg], 8192.f, ph[kg], pl[kg]);
         pbh[0][qg] = cat2(ph[0], ph[1]); pbl[0][qg] = cat2(pl[0], pl[1]);
-        sbh[0][qg] = cat2(sh[0], sh[1]); sbl[0][qg] = cat2(sl[0], sl[1]);
         pbh[1][qg] = NG == 3 ? cat2(ph[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u}; pbl[1][qg] = NG == 3 ? cat2(pl[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
-        sbh[1][qg] = NG == 3 ? cat2(sh[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u}; sbl[1][qg] = NG == 3 ? cat2(sl[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
       }
       __builtin_amdgcn_sched_barrier(0);
       u32x2 tph[NG][NG], tpl[NG][NG];                       // [query group][key group]
@@ -478,32 +500,81 @@ void abl_kernel(AblArgs a, int n_tiles) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    stamp(3);
-    // ---- dV^T = dO^T P: A = d(o) turned (feature on the lane, queries in the registers), B = P (queries in the registers, key on the lane);
-    // its slabs carry this head's q rows -> B (for dK)
-    op_base = qkvb + hoff; op_dst = rb_dst; op_stride = 3072u; op_tile = tile;
+    AL_WAIT(SC.w_do);                                       // d(o) in A
+    stamp(2);
+    // ---- dV^T = dO^T P: A = d(o) turned (feature on the lane, queries in the registers), B = P (queries in the registers, key on the lane).
+    // It needs neither v nor dS, so it comes first: its phases carry v -> B (for dP) and k -> A (for dQ)
+    u32x4 doh[NG][2], dol[NG][2];
+    { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sdo, doh, dol); }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      u32x4 th[2][2], tl[2][2];
-      turn(doh, dol, j, th, tl);
-      contract_project(th, tl, pqh, pql, j, 1.f / (sdo * 8192.f));
+    for (int j = 0; j < 2; ++j) part_step(1, doh, dol, pqh, pql, j, 1.f / (sdo * 8192.f));
+    __builtin_amdgcn_sched_barrier(0);
+    AL_WAIT(SC.w_v);                                        // v in B
+    // ---- dP^T = V dO^T ; delta_q = sum_k P dP ; dS^T = P^T (dP^T - delta); the first half of q -> B (for dK) at its points
+    f32x4 ds[NG][NG];
+    {
+      u32x4 vh[NG][2], vl[NG][2];
+      { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sv, vh, vl); }
+      __builtin_amdgcn_sched_barrier(0);
+      const float dsc = 1.f / (sv * sdo);
+      float dmax = 0.f;
+#pragma unroll
+      for (int qg = 0; qg < NG; ++qg) {
+        f32x4 dp[NG];
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) {
+          f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            x = mm32(vh[kg][j], dol[qg][j], x);
+            x = mm32(vl[kg][j], doh[qg][j], x);
+            x = mm32(vh[kg][j], doh[qg][j], x);
+          }
+          dp[kg] = x * dsc;
+        }
+        point(2, 2 * qg);
+        float delta = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) delta += pt[kg][qg][i] * dp[kg][i];
+        delta = gsum(delta);
+#pragma unroll
+        for (int kg = 0; kg < NG; ++kg) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ds[kg][qg][i] = pt[kg][qg][i] * (dp[kg][i] - delta);
+          dmax = amax4(ds[kg][qg], dmax);
+        }
+        point(2, 2 * qg + 1);
+      }
+      sds = pow2_scale(wave_max(dmax), 13);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- dQ^T = K^T dS^T / 8: A = k turned, B = dS^T (keys in the registers, query on the lane); its slabs carry the NEXT head's q rows -> A
+    // planes of dS^T (x sds) as the token-contracting B operand of dQ: [key-group pair][query group]
+    u32x4 sbh[2][NG], sbl[2][NG];
+#pragma unroll
+    for (int qg = 0; qg < NG; ++qg) {
+      u32x2 sh[NG], sl2[NG];
+#pragma unroll
+      for (int kg = 0; kg < NG; ++kg) split4s(ds[kg][qg], sds, sh[kg], sl2[kg]);
+      sbh[0][qg] = cat2(sh[0], sh[1]); sbl[0][qg] = cat2(sl2[0], sl2[1]);
+      sbh[1][qg] = NG == 3 ? cat2(sh[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u}; sbl[1][qg] = NG == 3 ? cat2(sl2[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(3);
+    // ---- dQ^T = K^T dS^T / 8: A = k turned, B = dS^T (keys in the registers, query on the lane); its phases carry the rest of q -> B and the
+    // NEXT head's q -> A
+    AL_WAIT(SC.w_k);                                        // k in A
     {
       u32x4 kh[NG][2], kl[NG][2];
-      { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sk, kh, kl); }       // (k landed before the dV slabs' waits)
+      { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sk, kh, kl); }
       __builtin_amdgcn_sched_barrier(0);
-      op_base = qkvb + 256 * h_n; op_dst = ra_dst; op_stride = 3072u; op_tile = tile_n;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        u32x4 th[2][2], tl[2][2];
-        turn(kh, kl, j, th, tl);
-        contract_project(th, tl, sbh, sbl, j, 0.125f / (sk * sds));
-      }
+      for (int j = 0; j < 2; ++j) part_step(3, kh, kl, sbh, sbl, j, 0.125f / (sk * sds));
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- dK^T = Q^T dS / 8: dS turned tile by tile (query in the registers, key on the lane); its slabs carry the next head's k rows -> B
+    // ---- dK^T = Q^T dS / 8: dS turned tile by tile (query in the registers, key on the lane); its phases carry the next head's k -> B
     {
       u32x4 sqh[2][NG], sql[2][NG];                         // [query-group pair][key group]
       {
@@ -526,17 +597,14 @@ void abl_kernel(AblArgs a, int n_tiles) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      AL_WAIT(SC.w_q);                                      // q in B
       u32x4 qh[NG][2], ql[NG][2];
-      { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sq, qh, ql); }       // (q landed before the dQ slabs' waits)
+      { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sq, qh, ql); }
       __builtin_amdgcn_sched_barrier(0);
-      op_base = qkvb + 1024 + 256 * h_n; op_dst = rb_dst; op_stride = 3072u; op_tile = tile_n;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        u32x4 th[2][2], tl[2][2];
-        turn(qh, ql, j, th, tl);
-        contract_project(th, tl, sqh, sql, j, 0.125f / (sq * sds));
-      }
+      for (int j = 0; j < 2; ++j) part_step(4, qh, ql, sqh, sql, j, 0.125f / (sq * sds));
     }
+#undef AL_WAIT
   }
     // ================= epilogue of the tile: dz = add + LNbwd(d(ln1); z, gamma)  (rowops.hip ln_bwd_kernel; tklb_kernel's epilogue) ==========
     // lane (c, g) holds features 16 nb + 4 g + i of tokens 16 t + c: row sums = in-lane over (nb, i) + two shuffles over g.  One token group
@@ -583,10 +651,10 @@ void abl_kernel(AblArgs a, int n_tiles) {
             s1 += d; s2 += d * d; t1 += gq[e]; t2 += gq[e] * d;
           }
         }
-        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-        t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
-        t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
+        s1 = gsum(s1);
+        s2 = gsum(s2);
+        t1 = gsum(t1);
+        t2 = gsum(t2);
         const float ms = s1 * (1.f / 256.f);
         const float var = fmaxf(s2 * (1.f / 256.f) - ms * ms, 0.f);
         const float rstd = 1.f / sqrtf(var + 1e-5f);
