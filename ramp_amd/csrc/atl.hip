@@ -366,30 +366,38 @@ void abl_kernel(AblArgs a, int n_tiles) {
     // token group]); true scale -> recorded maximum -> planes at the call site's scale -> projection.  6 points.
     auto part_step = [&](int ph, const u32x4 (&xh)[NG][2], const u32x4 (&xl)[NG][2], const u32x4 (&bh)[2][NG], const u32x4 (&bl)[2][NG], int j,
                          float oscale) __attribute__((always_inline)) {
+      // software-pipelined by hand: the MFMAs of unit u + 1 are issued before the vector work on unit u's result (split into planes, maximum),
+      // so that the two pipes overlap -- written one after the other, hipcc runs every unit MFMA -> wait -> split -> MFMA on one accumulator
+      const u32x4 sel0 = *reinterpret_cast<const u32x4*>(selp), sel1 = *reinterpret_cast<const u32x4*>(selp + 1024);
+      auto tmm = [&](int u) __attribute__((always_inline)) -> f32x4 {      // unit u = f NG + t of the turn
+        const int f = u / NG, t = u % NG;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        x = mm32(xh[t][j], f ? sel1 : sel0, x);
+        x = mm32(xl[t][j], f ? sel1 : sel0, x);
+        return x;
+      };
+      u32x2 th[2][NG], tl[2][NG];
+      {
+        f32x4 xc = tmm(0);
+#pragma unroll
+        for (int u = 0; u < 2 * NG; ++u) {
+          f32x4 xn = xc;
+          if (u + 1 < 2 * NG) xn = tmm(u + 1);
+          unsigned h0, h1, l0, l1;
+          split4m(xc, h0, h1, l0, l1);
+          th[u / NG][u % NG] = u32x2{h0, h1}; tl[u / NG][u % NG] = u32x2{l0, l1};
+          if ((u + 1) % NG == 0) point(ph, 12 * j + u / NG);
+          xc = xn;
+        }
+      }
       u32x4 ah[2][2], al[2][2];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        u32x2 th[NG], tl[NG];
-        const u32x4 self = *reinterpret_cast<const u32x4*>(selp + f * 1024);
-#pragma unroll
-        for (int t = 0; t < NG; ++t) {
-          f32x4 x = {0.f, 0.f, 0.f, 0.f};
-          x = mm32(xh[t][j], self, x);
-          x = mm32(xl[t][j], self, x);
-          unsigned h0, h1, l0, l1;
-          split4m(x, h0, h1, l0, l1);
-          th[t] = u32x2{h0, h1}; tl[t] = u32x2{l0, l1};
-        }
-        ah[f][0] = cat2(th[0], th[1]); al[f][0] = cat2(tl[0], tl[1]);
-        ah[f][1] = NG == 3 ? cat2(th[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
-        al[f][1] = NG == 3 ? cat2(tl[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
-        point(ph, 12 * j + f);
+        ah[f][0] = cat2(th[f][0], th[f][1]); al[f][0] = cat2(tl[f][0], tl[f][1]);
+        ah[f][1] = NG == 3 ? cat2(th[f][NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
+        al[f][1] = NG == 3 ? cat2(tl[f][NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
       }
-      u32x4 gh[NG], gl[NG];
-      float omax = 0.f;
-#pragma unroll
-      for (int t = 0; t < NG; ++t) {
-        f32x4 o2[2];
+      auto cmm = [&](int t, f32x4 (&o2)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
           f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -401,11 +409,24 @@ void abl_kernel(AblArgs a, int n_tiles) {
           }
           o2[f] = o;
         }
-        point(ph, 12 * j + 2 + t);
-        if (full || tok0 + 16 * t + c < a.M) { omax = amax4(o2[0], omax); omax = amax4(o2[1], omax); }      // (tokens past M: not in the recorded maximum)
-        u32x2 h0, l0, h1, l1;
-        split4s(o2[0], oscale * s_in, h0, l0); split4s(o2[1], oscale * s_in, h1, l1);      // (powers of two: one exact scaling)
-        gh[t] = cat2(h0, h1); gl[t] = cat2(l0, l1);
+      };
+      u32x4 gh[NG], gl[NG];
+      float omax = 0.f;
+      {
+        f32x4 oc[2];
+        cmm(0, oc);
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+          f32x4 on[2] = {oc[0], oc[1]};
+          if (t + 1 < NG) cmm(t + 1, on);
+          const float live = (full || tok0 + 16 * t + c < a.M) ? 1.f : 0.f;      // (tokens past M: not in the recorded maximum; no branch)
+          omax = fmaxf(omax, live * amax4(oc[1], amax4(oc[0], 0.f)));
+          u32x2 h0, l0, h1, l1;
+          split4s(oc[0], oscale * s_in, h0, l0); split4s(oc[1], oscale * s_in, h1, l1);      // (powers of two: one exact scaling)
+          gh[t] = cat2(h0, h1); gl[t] = cat2(l0, l1);
+          point(ph, 12 * j + 2 + t);
+          oc[0] = on[0]; oc[1] = on[1];
+        }
       }
       amax = fmaxf(amax, omax * oscale);
       if (NG == 2) point(ph, 12 * j + 4);

@@ -517,7 +517,7 @@ struct Run {
   // attention backward + d(ln1) + LayerNorm-1 backward in one launch of sample-owning waves (atl.hip): d(qkv) never reaches HBM;
   // consumes the call site of the d(ln1) GEMM it contains
   bool use_abl(const STBlock& k, int M, int L) const {
-    return c->abl_on && k.abl_w && use_atb(M, L) && use_tklb(M, k.wqkv_b);
+    return c->abl_on && k.abl_w && use_atb(M, L) && !c->tklb_off && c->tkl_min_rows > 0 && has_h3(k.wqkv_b, 256, 768);      // (from atk_rows tokens on)
   }
   int abl(const STBlock& k, const float* qkv, const float* dout, const float* z, const float* add, float* out, int M, int L) {
     GemmArgs b; b.A = c->t_dqkv; b.lda = 768; b.W = k.wqkv_b; b.C = out; b.ldc = 256; b.M = M; b.N = 256; b.K = 768; b.taps = 1; b.L = 1;
