@@ -499,8 +499,9 @@ def main():
             "traffic": traffic, "traffic_source": traffic_src,
             "hbm_frac": (traffic / (avg_us * 1e-6) / 1e12 / PEAK_HBM_TBS) if traffic else None,
             "kernel": "the split-precision GEMM class: ramp::ffx_kernel<fwd|bwd> (token-owning fused LN3 -> FF1 -> GEGLU -> FF2 and its "
-                      "input gradient, 45 % of the class's time), ramp::tkl_kernel<*> (token-owning LN1 -> QKV, out-projection, d(o)), "
-                      "ramp::gemm_x6p*_kernel<*, NP=2> (fp16x3 tile kernels: k5/k1/stride-2 convs, d(ln1), proj_in/out; NP=3 = bf16x6 "
+                      "input gradient, 48 % of the class's time), ramp::tkl_kernel<*> (token-owning LN1 -> QKV, d(o)), ramp::ato_kernel / ramp::abl_kernel "
+                      "(sample-owning self-attention + out-projection forward; attention backward + d(ln1) + LayerNorm backward), ramp::tkc_kernel "
+                      "(narrow k5 convs), ramp::gemm_x6p*_kernel<*, NP=2> (fp16x3 tile kernels: k5/k1/stride-2 convs, proj_in/out; NP=3 = bf16x6 "
                       "in a calibration evaluation) + gemm_kernel<*> (exact fp32, N = 32 layers), forward and dX",
             "peak_note": "achieved = ALGORITHMIC fp32 FLOPs of the GEMM launches / their summed HIP-event time; peak = the pipe "
                          "the kernel executes on, fp16 dense MFMA 2500 TFLOP/s, divided by the 3 fp16 products it spends per "

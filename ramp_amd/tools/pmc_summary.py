@@ -12,7 +12,7 @@ import sys
 
 def klass(name):
     if "gemm_x6" in name or "gemm_kernel" in name or "ff_fwd_kernel" in name or "ffx_kernel" in name or "tkl_kernel" in name or "tklb_kernel" in name \
-            or "ato_kernel" in name or "tkc_kernel" in name:      # (ato: self-attention + out-projection in one launch, counted with its GEMM)
+            or "ato_kernel" in name or "abl_kernel" in name or "tkc_kernel" in name:      # (ato / abl: attention fused with a GEMM, counted with it)
         return "gemm"
     if "attn2" in name or "atb_kernel" in name:
         return "attention"

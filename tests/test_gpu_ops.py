@@ -715,6 +715,8 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("sample-owning 5-tap convolution 64x64 with bias and residual, L = 24 (tkc)", 196608, 64, 64, 5, 24, 12, 3, False),
     ("sample-owning 5-tap convolution 32x32 input gradient, L = 48 (tkc)", 393216, 32, 32, 5, 48, 12, 4, False),
     ("attention backward on sample-owning waves, L = 24 (atb)", 196608, 256, 256, 1, 24, 13, 0, False),
+    ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 48 (abl)", 393216, 256, 768, 1, 48, 15, 0, False),
+    ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 12 (abl)", 98304, 256, 768, 1, 12, 15, 0, False),
 ]
 
 
