@@ -421,7 +421,7 @@ struct Run {
     TkcArgs t; t.M = a.M; t.L = a.L; t.N = a.N; t.K = a.K; t.dir = a.shift_step; t.X = a.A; t.ldx = a.lda; t.W = w.planes; t.bias = a.bias;
     t.resid = a.resid; t.ldr = a.ldr; t.resid2 = a.resid2; t.ldr2 = a.ldr2; t.Y = a.C; t.ldy = a.ldc;
     t.amax_in = c->phase == 2 ? c->obs_in + c->site : nullptr; t.amax_out = c->obs_out + c->site; t.wsi = w.wsi; t.site = c->site;
-    t.range_flag = c->range_flag;
+    t.range_flag = c->phase == 2 ? c->range_flag : nullptr;      // (the guard judges the DELAYED scale; the calibration evaluation runs unscaled)
     c->site++;
     int rc = launch_tkc(t, s);
     prof_post(c, s);
