@@ -12,7 +12,8 @@
 // (768 KB per tile) stream through a 3-slot LDS ring of 16 KB slabs in the order the gradient tiles are produced (abl_pack); q, k, v,
 // d(o) rows reach the wave through two wave-private LDS regions by LDS-DMA, so nothing waits in registers.  d(qkv) is the operand of
 // the d(ln1) call site: delayed power-of-two scale, recorded maximum, range guard like every other fp16x3 GEMM.  The LayerNorm backward
-// runs on the accumulators in the epilogue (two passes over the z rows: sums, then outputs).
+// runs on the accumulators in the epilogue, one 16-token group at a time (its z rows stay in registers between the row sums and the outputs).
+// The points / waits of a head are described by abl_make_sched below: keep it in step with the kernel's issue order when either changes.
 #include "common.h"
 #include "tokmma.h"
 #include "atkmma.h"
