@@ -43,6 +43,7 @@ static_assert(AL_LDS <= 160 * 1024, "LDS budget");
 struct AblSched {
   int slab[12];                                         // per slab of the head (-1: requested in the head before, landed at its start)
   int w_do, w_v, w_k, w_q;                              // before the region reads of d(o) (dV), v (dP), k (dQ), q (dK)
+  int ops;                                              // operand pieces that found a point (must be all 6 streams x GR)
 };
 constexpr int abl_phase_pieces(int ph, int GR) { return ph == 0 ? GR : ph == 1 ? 2 * GR : ph == 2 ? GR / 2 : ph == 3 ? GR / 2 + GR : GR; }
 constexpr AblSched abl_make_sched(int NG) {
@@ -51,12 +52,12 @@ constexpr AblSched abl_make_sched(int NG) {
   int issued = 0, sl = 0;
   int ring_mark[AL_R] = {0, 0, 0};
   int mk_do = 0, mk_v = 0, mk_k = 0, mk_q = 0;
-  for (int p = 0; p < 4 * NG; ++p) if (p < abl_phase_pieces(0, GR)) { ++issued; if (p == GR - 1) mk_do = issued; }
+  for (int p = 0; p < 4 * NG; ++p) if (p < abl_phase_pieces(0, GR)) { ++issued; ++r.ops; if (p == GR - 1) mk_do = issued; }
   for (int ph = 1; ph <= 4; ++ph) {
     if (ph == 1) r.w_do = issued - mk_do;
     if (ph == 2) {
       r.w_v = issued - mk_v;
-      for (int p = 0; p < 2 * NG; ++p) if (p < abl_phase_pieces(2, GR)) ++issued;
+      for (int p = 0; p < 2 * NG; ++p) if (p < abl_phase_pieces(2, GR)) { ++issued; ++r.ops; }
       continue;
     }
     if (ph == 3) r.w_k = issued - mk_k;
@@ -65,7 +66,7 @@ constexpr AblSched abl_make_sched(int NG) {
     int p = 0;
     auto pt = [&]() {
       if (p < np) {
-        ++issued;
+        ++issued; ++r.ops;
         if (ph == 1 && p == GR - 1) mk_v = issued;
         if (ph == 1 && p == 2 * GR - 1) mk_k = issued;
         if (ph == 3 && p == GR / 2 - 1) mk_q = issued;
@@ -86,6 +87,7 @@ constexpr AblSched abl_make_sched(int NG) {
   }
   return r;
 }
+static_assert(abl_make_sched(3).ops == 6 * 12 && abl_make_sched(2).ops == 6 * 8, "every operand piece of a head needs a point");
 
 }  // namespace
 
