@@ -1,3 +1,5 @@
+"""Where does abl_kernel (atl.hip, through ramp_op_abl) differ from float64 autograd?  abl_debug.py L R: error per 16-token group and per
+16-feature block of the output, the recorded maximum against max |d(qkv)|, and atb_kernel on the same operands for comparison."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, numpy as np
