@@ -150,7 +150,8 @@ typedef struct ramp_sample_params {
   const int32_t* apply_apf;      /* 1 on iterations where the APF hook fires              */
   const float* noise_scale;      /* noise_std_extra_schedule_fn(t) per iteration (scripts: 0.5); NULL = 1.0 */
   int32_t clip_denoised;
-  int32_t reserved0;
+  int32_t predict_x0;            /* predict_epsilon=False (the reference constructor's default, diffusion_model_static.py:28, 109-118):
+                                  * 1 = the guidance-combined network output IS x0 (then clamped); 0 = it is epsilon */
   /* hard conditioning (sample_functions.py:5-10) */
   int32_t n_hard;                /* number of conditioned waypoints                       */
   const int32_t* hard_idx_host;  /* host (n_hard) waypoint indices                        */
@@ -167,6 +168,12 @@ typedef struct ramp_sample_params {
   int32_t reserved2;
   uint64_t philox_seed;
   uint64_t philox_offset;        /* in groups of four elements */
+  /* noise_mode 1 in a job that is ONE SHARD of a larger one (the sample batch split over GPUs): this call's B
+   * trajectories are samples [philox_sample0, philox_sample0 + B) of a job of philox_total trajectories whose noise block is
+   * (n_steps+1, philox_total, H, S) -- every shard draws exactly the elements the unsharded job draws for its samples, so
+   * N shards reproduce the 1-GPU job of the same total.  philox_total == 0 means "this call is the whole job" (= B, 0). */
+  int64_t philox_sample0;
+  int64_t philox_total;
 } ramp_sample_params;
 
 /* noise: device (n_steps+1, B, H, S) for DDPM — noise[0] = x_T, noise[1+j] the randn_like of
@@ -205,7 +212,7 @@ typedef struct ramp_replan_params {
   const float* sqrt_recip; const float* sqrt_recipm1;
   const float* sqrt_a_t; const float* sqrt_1m_a_t; const float* sqrt_a_prev; const float* dir_coef;
   float q_sqrt_a, q_sqrt_1m_a;     /* q_sample at t[0]: sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod */
-  int32_t n_hard; int32_t reserved0;
+  int32_t n_hard; int32_t predict_x0;   /* predict_x0: as in ramp_sample_params */
   const int32_t* hard_idx_host;    /* host (n_hard)                                        */
   const float* hard_val;           /* device (n_hard, B, S)                                */
   int32_t sm_window_last;          /* 3: smoothing before the last DDIM step               */
@@ -289,9 +296,10 @@ int ramp_traj_metrics(const float* traj, int32_t B, int32_t H, int32_t S, const 
 /* Metrics.compute_variance_waypoints (metrics.py:8-19): sum over waypoints of the unbiased variance of all B*B entries
  * of triu(cdist(p, p), 1).  scratch: device, 2 * H * ceil(B/256) doubles; out: device, 1 double. */
 int ramp_waypoint_variance(const float* traj, int32_t B, int32_t H, int32_t S, double* scratch, double* out, void* stream);
-/* one p_mean_variance evaluation given eps (diffusion_model_static.py:161-172) */
+/* one p_mean_variance evaluation given eps (diffusion_model_static.py:161-172); predict_x0 != 0: predict_epsilon=False,
+ * x0 = the combined network output (diffusion_model_static.py:109-118) */
 int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32_t n_rp, double w0, double w1,
-                  float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip,
+                  float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip, int32_t predict_x0,
                   float* x0_out, float* mean_out, float* ecomb_out, void* stream);
 /* the DDIM update of ddim_p_sample given x0 (diffusion_model_static.py:321-333 / _dynamic.py:436-447), eta = 0:
  * x_out = sqrt_a_prev * x0 + dir_coef * (x - sqrt_a_t * x0) / sqrt_1m_a_t */
@@ -409,6 +417,10 @@ int ramp_set_calibration_reuse(ramp_ctx* ctx, int32_t on);
  * per category since ramp_profile(ctx, 1); arrays of length 5. */
 int ramp_profile(ramp_ctx* ctx, int32_t enable);
 int ramp_profile_read(ramp_ctx* ctx, double* ms, double* flops, int64_t* count);
+/* the same launches of category 0 by KERNEL (arrays of length n <= 9): 0 ffx_kernel forward, 1 ffx_kernel backward (the token-owning
+ * fused feed-forward: the dominant kernel, bench.py's roofline.frac), 2 tkl_kernel, 3 tklb_kernel, 4 ato_kernel, 5 abl_kernel,
+ * 6 tkc_kernel, 7 tkw_kernel, 8 every other launch of the class (tile kernels, exact-fp32 layers) */
+int ramp_profile_read_kernels(ramp_ctx* ctx, int32_t n, double* ms, double* flops, int64_t* count);
 int ramp_workspace_bytes(ramp_ctx* ctx, int64_t* bytes);
 int ramp_launch_count(ramp_ctx* ctx, int64_t* kernels_last_score);
 

@@ -26,6 +26,8 @@ What is captured:
   compose_3d.npz              3-D compose (w1 = w2 = 5) DDPM T=25: B independent n_samples=1 runs stacked
   apf_cases.npz               avoidance() in/out pairs (hits, no-hit early-out, window clipped at ends)
   cost_cases.npz              compute_collision_with_pointcloud / compute_trajectory_costs
+  boundary_cases.npz          public helper methods of the sampler class + predict_epsilon=False (one p_mean_variance, a DDPM chain)
+  unet2d_h48_outlier.npz      the 2-D score evaluation with outlier-channel weights (8 rows of every to_out / ff.net.2 x 2^9)
 """
 from __future__ import annotations
 
@@ -65,9 +67,11 @@ def quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
-def build_unet(state_dim, horizon, obstacle_3d, seed=0):
+def build_unet(state_dim, horizon, obstacle_3d, seed=0, outliers=False):
     sp = make_unet_spec(state_dim, horizon, obstacle_3d=obstacle_3d)
     sd = synth.make_unet_state_dict(sp, seed=seed)
+    if outliers:
+        sd = synth.add_outlier_channels(sd)
     m = quiet(TemporalUnetInference, n_support_points=horizon, state_dim=state_dim, unet_input_dim=32,
               dim_mults=UNET_DIM_MULTS[1], obstacle_3d=obstacle_3d)
     ref_sd = m.state_dict()
@@ -419,6 +423,74 @@ def gen_compose3d(m3, sp3):
     save("compose_3d.npz", chain=chain, noise=noise, clouds=clouds, latents=lats, T=T, w1=5.0, w2=5.0)
 
 
+def gen_boundary(m2, sp2):
+    """The sampler classes' public helpers and the constructor default predict_epsilon=False
+    (diffusion_model_static.py:96-147, 149-186, 259-333): in/out pairs of predict_start_from_noise,
+    predict_noise_from_start, q_posterior, deep_repeat_tensor, one static ddim_p_sample step (with / without the APF hook),
+    one p_mean_variance and a T = 25 DDPM chain of a predict_epsilon=False wrapper (the network output IS x0)."""
+    H, S, B = sp2.horizon, sp2.state_dim, 3
+    cloud = synth.make_cloud(6, 64, 2, seed=42)
+    pts = torch.from_numpy(cloud)
+    arrs = dict(cloud=cloud)
+    x = synth.make_noise((B, H, S), seed=31); z = synth.make_noise((B, H, S), seed=32)
+    t = torch.full((B,), 9, dtype=torch.long)
+    arrs.update(x=x, z=z, t=9)
+    for pe in (True, False):
+        dm = quiet(StaticGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=25,
+                   predict_epsilon=pe)
+        dm.eval()
+        tag = "eps" if pe else "x0"
+        arrs[f"psn_{tag}"] = dm.predict_start_from_noise(torch.from_numpy(x), t, torch.from_numpy(z)).numpy()
+        arrs[f"pns_{tag}"] = dm.predict_noise_from_start(torch.from_numpy(x), t, torch.from_numpy(z)).numpy()
+        qm, qv, qlv = dm.q_posterior(x_start=torch.from_numpy(z), x_t=torch.from_numpy(x), t=t)
+        arrs[f"q_mean_{tag}"] = qm.numpy(); arrs[f"q_var_{tag}"] = qv.numpy(); arrs[f"q_logvar_{tag}"] = qlv.numpy()
+        m2.reset_cache()
+        dm.ddim = True
+        mean, _, _, x0, ec = dm.p_mean_variance(torch.from_numpy(x.copy()), None, None, t,
+                                                traj_normalized=torch.zeros(H, S), obstacle_pts=pts.unsqueeze(0))
+        arrs[f"pmv_mean_{tag}"] = mean.detach().numpy(); arrs[f"pmv_x0_{tag}"] = x0.detach().numpy()
+        arrs[f"pmv_ecomb_{tag}"] = ec.detach().numpy()
+    dm = quiet(StaticGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=25, predict_epsilon=True)
+    xr, tr, trj, obr = dm.deep_repeat_tensor(torch.from_numpy(x), torch.arange(B), torch.from_numpy(z), pts.unsqueeze(0), 2)
+    arrs.update(rep_x=xr.numpy(), rep_t=tr.numpy(), rep_traj=trj.numpy(), rep_obst_shape=np.asarray(obr.shape))
+    # one static DDIM step of T = 100 / K = 5 at t = 40 (forward_t = 2: the APF hook's first step), with and without the hook
+    hc = {k: torch.from_numpy(v)[None].repeat(B, 1) for k, v in synth.default_hard_conds(S, H).items()}
+    xs = synth.make_noise((B, H, S), seed=33) * np.float32(0.5)
+    arrs["ddim_x"] = xs
+    for apf in (False, True):
+        dm = quiet(StaticGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=100,
+                   predict_epsilon=True, compose=False, use_apf=apf)
+        dm.eval()
+        m2.reset_cache()
+        out = dm.ddim_p_sample(torch.from_numpy(xs.copy()), hc, None, torch.full((B,), 40, dtype=torch.long), pts.unsqueeze(0),
+                               traj_normalized=torch.zeros(H, S), forward_t=2, eta=0.0, use_clipped_model_output=True)
+        arrs["ddim_out_apf" if apf else "ddim_out"] = out.detach().numpy()
+    # predict_epsilon=False (the constructor default): a DDPM chain (T = 25: the exponential schedule of a T = 5 wrapper has
+    # beta_4 = 1 + 1 ulp and NaN posterior coefficients in the reference itself)
+    T, Bc = 25, 2
+    dm = quiet(StaticGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=T,
+               predict_epsilon=False, compose=False, use_apf=False)
+    dm.eval(); dm.ddim = False
+    m2.reset_cache()
+    noise = synth.make_noise((T + 1, Bc, H, S), seed=34)
+    hc1 = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(S, H).items()}
+    with NoiseInjector([torch.from_numpy(n) for n in noise]) as inj:
+        chain = dm.run_inference(None, hc1, n_samples=Bc, horizon=H, return_chain=True, traj_normalized=torch.zeros(H, S),
+                                 obstacle_pts=pts, sample_fn=ddpm_sample_fn, guide=None, n_guide_steps=1, t_start_guide=7,
+                                 noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=0)
+        assert inj.used == T + 1
+    arrs.update(x0_chain=chain.detach().numpy(), x0_noise=noise)
+    m2.reset_cache()
+    save("boundary_cases.npz", **arrs)
+
+
+def gen_outlier_unet():
+    """One tapped score evaluation of the 2-D net whose transformer output projections carry outlier channels
+    (synth.add_outlier_channels: 8 rows of every attn1.to_out / ff.net.2 scaled by 2^9) -- trained-transformer statistics."""
+    m, sp, _ = build_unet(4, 48, False, outliers=True)
+    gen_unet("2d_h48_outlier", m, sp, synth.make_cloud(6, 64, 2, seed=42), 4, 7, seed=10)
+
+
 def gen_apf():
     arrs = {}
     cloud = synth.make_cloud(6, 64, 2, seed=42).reshape(-1, 2)
@@ -700,6 +772,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "h40":
         m40, sp40, _ = build_unet(4, 40, False)
         gen_horizon40(m40, sp40); return
+    if len(sys.argv) > 1 and sys.argv[1] == "boundary":
+        m2, sp2, _ = build_unet(4, 48, False)
+        gen_boundary(m2, sp2); return
+    if len(sys.argv) > 1 and sys.argv[1] == "outlier":
+        gen_outlier_unet(); return
     if len(sys.argv) > 1 and sys.argv[1] == "cost":
         gen_cost(); return
     if len(sys.argv) > 1 and sys.argv[1] == "apf":
@@ -726,6 +803,8 @@ def main():
     print("metrics"); gen_metrics()
     print("compat"); gen_compat()
     print("horizon 40"); m40, sp40, _ = build_unet(4, 40, False); gen_horizon40(m40, sp40)
+    print("boundary helpers / predict_epsilon=False"); gen_boundary(m2, sp2)
+    print("outlier-channel weights"); gen_outlier_unet()
     print("done")
 
 

@@ -40,17 +40,18 @@ class RampSampleParams(C.Structure):
                 ("t", c_i32p), ("sqrt_recip", c_f32p), ("sqrt_recipm1", c_f32p), ("coef1", c_f32p),
                 ("coef2", c_f32p), ("stdv", c_f32p), ("use_noise", c_i32p), ("sqrt_a_t", c_f32p),
                 ("sqrt_1m_a_t", c_f32p), ("sqrt_a_prev", c_f32p), ("dir_coef", c_f32p), ("apply_apf", c_i32p),
-                ("noise_scale", c_f32p), ("clip_denoised", C.c_int32), ("reserved0", C.c_int32),
+                ("noise_scale", c_f32p), ("clip_denoised", C.c_int32), ("predict_x0", C.c_int32),
                 ("n_hard", C.c_int32), ("hard_idx_host", c_i32p), ("hard_val", C.c_void_p),
                 ("apf", RampApfParams), ("use_graph", C.c_int32), ("reserved", C.c_int32),
-                ("noise_mode", C.c_int32), ("reserved2", C.c_int32), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64)]
+                ("noise_mode", C.c_int32), ("reserved2", C.c_int32), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
+                ("philox_sample0", C.c_int64), ("philox_total", C.c_int64)]
 
 
 class RampReplanParams(C.Structure):
     _fields_ = [("B", C.c_int32), ("n_rp", C.c_int32), ("n_steps", C.c_int32), ("clip_denoised", C.c_int32),
                 ("w", C.c_double), ("t", c_i32p), ("sqrt_recip", c_f32p), ("sqrt_recipm1", c_f32p), ("sqrt_a_t", c_f32p),
                 ("sqrt_1m_a_t", c_f32p), ("sqrt_a_prev", c_f32p), ("dir_coef", c_f32p), ("q_sqrt_a", C.c_float),
-                ("q_sqrt_1m_a", C.c_float), ("n_hard", C.c_int32), ("reserved0", C.c_int32), ("hard_idx_host", c_i32p),
+                ("q_sqrt_1m_a", C.c_float), ("n_hard", C.c_int32), ("predict_x0", C.c_int32), ("hard_idx_host", c_i32p),
                 ("hard_val", C.c_void_p), ("sm_window_last", C.c_int32), ("sm_window_final", C.c_int32),
                 ("sm_dt", C.c_float), ("sm_max_vel", C.c_float), ("static_pts", C.c_void_p), ("n_static", C.c_int32),
                 ("n_dyn", C.c_int32), ("thr_static", C.c_double), ("thr_pred", C.c_double), ("strength_static", C.c_double),
@@ -107,7 +108,7 @@ PROTOTYPES = {
     "ramp_traj_costs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ramp_cfg_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
-                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
+                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
     "ramp_ddim_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -132,6 +133,7 @@ PROTOTYPES = {
     "ramp_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64, c_i64p, C.c_void_p]),
     "ramp_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "ramp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64p]),
+    "ramp_profile_read_kernels": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64p]),
     "ramp_set_fallback": (C.c_int, [C.c_void_p, C.c_int32]),
     "ramp_set_calibration_reuse": (C.c_int, [C.c_void_p, C.c_int32]),
     "ramp_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
@@ -156,10 +158,13 @@ def load() -> C.CDLL:
     # NEEDED libamdhip64.so.7 then resolves to the copy already mapped.  Loaded the other way round the second
     # runtime finds no device.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
-        raise RampHipError(f"{LIB_PATH} not found: build it with `python -m ramp_amd.build` "
+    # RAMP_HIP_LIB: another build of the same library for a same-box A/B (ramp_amd/tools/ab_libs.sh); the in-tree one is never
+    # overwritten, so later runs cannot pick up a stale alternate by accident
+    path = os.environ.get("RAMP_HIP_LIB") or LIB_PATH
+    if not os.path.exists(path):
+        raise RampHipError(f"{path} not found: build it with `python -m ramp_amd.build` "
                            "(hipcc --offload-arch=gfx950). The RAMP sampler has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
@@ -174,7 +179,7 @@ def check(rc: int, what: str = "") -> None:
         raise RampHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
-GEMM_MODES = {"fp32": 0, "bf16x6": 1, "bf16x6-lds": 2, "fp16x3": 3, "fp16x3-dma": 4, "fp16x3-tkc": 5}       # ramp_op_gemm_mode
+GEMM_MODES = {"fp32": 0, "bf16x6": 1, "bf16x6-lds": 2, "fp16x3": 3, "fp16x3-tkc": 5}       # ramp_op_gemm_mode
 
 
 def op_gemm(A, W, bias, resid, out, M, N, K, taps, shift0, step, L, mode="fp32", a_absmax_prev=0.0):

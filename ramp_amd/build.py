@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libramp_hip.so")
-SOURCES = ["gemm.hip", "gemm_q.hip", "ffx.hip", "tkl.hip", "atk.hip", "atl.hip", "tkc.hip", "rowops.hip", "attention.hip", "sampler.hip", "scene.hip", "metrics.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "ffx.hip", "tkl.hip", "atk.hip", "atl.hip", "tkc.hip", "rowops.hip", "attention.hip", "sampler.hip", "scene.hip", "metrics.hip", "engine.hip"]
 # default GEMM mode 2 = fp16x3 split with delayed operand scaling, 1 = bf16x6 split (both fp32-accurate, see gemm.hip);
 # 0 = exact fp32 MFMA
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DRAMP_DEFAULT_GEMM_MODE=2"]

@@ -526,10 +526,7 @@ void ato_kernel(AtoArgs a, int n_tiles) {
 
   amax = wave_max(amax);
   if (touch == 1.2345e-30f && a.amax_out) a.amax_out[0] = touch;      // (keeps the touches alive; never true in practice)
-  record_amax_block(a.amax_out, amax, reinterpret_cast<float*>(smem));      // (no LDS-DMA in flight: vmcnt(0) above)
-  if (lane == 0) {
-    if (a.range_flag && (!(amax * s_in < 60000.f) || (amax > 0.f && amax * s_in < 0.125f))) atomicMax(a.range_flag, a.site + 1);
-  }
+  record_amax_block_guarded(a.amax_out, amax, reinterpret_cast<float*>(smem), a.range_flag, s_in, a.site);      // (no LDS-DMA in flight: vmcnt(0) above)
 }
 
 // ---- attention backward on sample-owning waves ---------------------------------------------------------------------------------------------
@@ -846,7 +843,9 @@ bool ato_applicable(int M, int L, int* ng) {
   int n = 0;
   if (L >= 1 && 48 % L == 0) n = 3; else if (L >= 1 && 32 % L == 0) n = 2;
   if (ng) *ng = n;
-  return n != 0 && M > 0 && M % L == 0;
+  // (the kernels address rows with 32-bit byte offsets into qkv, 3072 bytes per token: launches past that bound stay on the
+  //  attention + tile / token-owning pair instead of failing)
+  return n != 0 && M > 0 && M % L == 0 && (long)M * 3072 < (1l << 32);
 }
 
 int launch_ato(const AtoArgs& a, hipStream_t s) {

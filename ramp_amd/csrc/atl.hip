@@ -719,10 +719,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the block
 
   amax = wave_max(amax);
-  record_amax_block(a.amax_out, amax, reinterpret_cast<float*>(smem));      // (no LDS-DMA in flight: vmcnt(0) above; it starts with a barrier)
-  if (lane == 0) {
-    if (a.range_flag && (!(amax * s_in < 60000.f) || (amax > 0.f && amax * s_in < 0.125f))) atomicMax(a.range_flag, a.site + 1);
-  }
+  record_amax_block_guarded(a.amax_out, amax, reinterpret_cast<float*>(smem), a.range_flag, s_in, a.site);      // (no LDS-DMA in flight: vmcnt(0) above; it starts with a barrier)
 }
 
 int launch_abl(const AblArgs& a, hipStream_t s) {

@@ -57,6 +57,24 @@ __device__ __forceinline__ void record_amax_block(float* slot, float wave_amax, 
   __syncthreads();
   if (threadIdx.x == 0) record_amax<READ_FIRST>(slot, fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3])));
 }
+// The same with the range guard of the delayed scale s_in behind it.  Overflow (a scaled element at 60000 or beyond) is judged per
+// wave on the rows that wave staged; "the operand shrank" (largest scaled element below 2^-3) on the BLOCK's maximum: the waves of
+// the sample-owning kernels hold 4-8 samples each, and per-sample operands (input gradients) legitimately differ by more than the
+// 2^8 window from sample to sample -- a wave of small samples must not send the whole job to the bf16x6 kernels.
+template <bool READ_FIRST = false>
+__device__ __forceinline__ void record_amax_block_guarded(float* slot, float wave_amax, float* scratch, int* range_flag, float s_in, int site) {
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    scratch[threadIdx.x >> 6] = wave_amax;
+    if (range_flag && !(wave_amax * s_in < 60000.f)) atomicMax(range_flag, site + 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float bm = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    record_amax<READ_FIRST>(slot, bm);
+    if (range_flag && bm > 0.f && bm * s_in < 0.125f) atomicMax(range_flag, site + 1);
+  }
+}
 #endif
 // compute units of the current device (hipDeviceProp_t::multiProcessorCount, cached per device): the token-owning kernels
 // launch one 4-wave block per CU
@@ -80,7 +98,6 @@ struct GemmArgs {
   int site_id = 0;
   int geglu_group = 64;                                     // EPI_GEGLU_FWD weight tiling: [group a-rows | group g-rows]
   const float* Amul = nullptr; int lda_mul = 0; int a_period = 0;   // optional: A_eff[m][k] = A[m][k % a_period] * Amul[m][k]
-  const unsigned short* Ap = nullptr; long ap_plane = 0;    // optional: A already split into two scaled fp16 planes, row-major [2][M][K] (gemm_q.hip)
   int ablate = 0;                                           // diagnostic kernel variant (ramp_bench_gemm only)
   int three_ok = 1;                                         // launch plan: a third resident block where it measured faster
   int tile_pref = 0;                                        // tuning override (micro-benchmarks): 0 auto, 1 force the 128 x 128 tile, 3 force 3 blocks / CU
@@ -112,11 +129,6 @@ int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_split3(const float* in, unsigned short* out, long n, hipStream_t s);   // fp32 -> 3 bf16 planes
 int launch_pack_x6(const float* W, unsigned short* out, long rows, int K, hipStream_t s);   // fp32 [rows][K] -> MFMA-fragment-packed planes
 int launch_pack_h3(const float* W, unsigned short* out, long rows, int K, float scale, hipStream_t s);   // same, two fp16 planes
-int launch_split_planes(const float* A, int lda, unsigned short* out, long plane, int M, int K, const float* absmax_in,
-                        float* absmax_out, int* range_flag, int site_id, hipStream_t s);   // fp32 -> the Ap format
-bool gemm_h3q_applicable(const GemmArgs& a);
-int launch_gemm_h3q(const GemmArgs& a, hipStream_t s);   // fp16x3, both operands through an LDS-DMA ring (gemm_q.hip)
-int init_gemm_q_attributes();
 int launch_ff_fwd(const GemmArgs& ff1, const GemmArgs& ff2, hipStream_t s);   // fused FF1 -> GEGLU -> FF2 (gemm.hip)
 int init_gemm_attributes();        // raise the dynamic-LDS limit of every GEMM instantiation (once)
 int init_attention_attributes();   // same for the attention kernels
@@ -325,6 +337,7 @@ struct CfgMeanArgs {
   int B = 0, HS = 0, n_rp = 2;
   float w0 = 0, w1 = 0, w0p1 = 1; // n_rp=2: e=w0p1*v0 - w0*v1 (w0p1 = float(1+w)) ; n_rp=3: e=v2+w0*(v0-v2)+w1*(v1-v2)
   float sqrt_recip = 0, sqrt_recipm1 = 0, coef1 = 0, coef2 = 0; int clip = 1;
+  int predict_x0 = 0;           // predict_epsilon=False (the reference constructor's default): the combined network output IS x0
 };
 int launch_cfg_mean(const CfgMeanArgs& a, hipStream_t s);
 
@@ -338,6 +351,10 @@ int launch_ddim_finish(const float* x_in, const float* x0, float sqrt_a_t, float
 int launch_hard_cond(float* x, HardConds hc, int B, int H, int S, hipStream_t s);
 // out[0..n) ~ N(0, 1): Philox4x32-10 + Box-Muller, rec = device {seed, offset in groups of four elements} (sampler.hip)
 int launch_philox_normal(float* out, long n, const unsigned long long* rec, hipStream_t s);
+// the same stream addressed by GLOBAL sample index: out is this shard's (n_blocks, B, HS) noise block of a job whose whole
+// noise block is (n_blocks, B_total, HS); local sample b is global sample sample0 + b, i.e. out[(j B + b) HS + e] = element
+// (j B_total + sample0 + b) HS + e of the stream (HS % 4 == 0).  B_total == B, sample0 == 0 is launch_philox_normal.
+int launch_philox_normal_sharded(float* out, int n_blocks, int B, int HS, long sample0, long B_total, const unsigned long long* rec, hipStream_t s);
 
 struct ApfArgs {
   float* traj = nullptr;        // (B,H,S) modified in place (xy channels only)

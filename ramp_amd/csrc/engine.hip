@@ -412,6 +412,7 @@ struct Run {
     if (!(a.taps == 5 && !a.A2 && !a.Amul && !a.C2 && !a.rowbias && a.epi == EPI_LINEAR && a.a_stride == 1 && a.c_rstride == 1 && a.c_roff == 0)) return nullptr;
     if (!((a.shift0 == -2 && a.shift_step == 1) || (a.shift0 == 2 && a.shift_step == -1))) return nullptr;
     if (!tkc_applicable(a.M, a.L, a.N, a.K, nullptr)) return nullptr;
+    if (!((long)a.M * a.lda * 4 < (1l << 32))) return nullptr;      // (32-bit row offsets: larger launches keep the tile kernels)
     auto it = c->tkc_w.find(a.W);
     return it == c->tkc_w.end() ? nullptr : &it->second;
   }
@@ -483,7 +484,7 @@ struct Run {
     const int kind = prep(b);
     if (kind < 0) return kind;
     RAMP_REQUIRE(kind == 2, "tkl: weight without fp16 fragment planes (use_tkl must have been checked)");
-    prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K, {a.M, a.N, a.K, ln_g ? -1 : 1});
+    prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K, {a.M, a.N, a.K, ln_g ? -11 : -10});
     TklArgs t; t.M = a.M; t.N = a.N; t.X = a.A; t.Y = a.C; t.ldy = a.ldc; t.W = b.Wx; t.bias = a.bias; t.resid = a.resid; t.ldr = a.ldr;
     t.rowbias = a.rowbias; t.rowvar = a.rowvar; t.row0 = a.row0; t.rb_stride = a.rb_stride; t.L = a.L; t.n_var = a.rowbias ? c->n_variants : 0;
     t.ln_g = ln_g; t.ln_b = ln_b; t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.wsi = b.w_scale_inv; t.site = b.site_id;
@@ -524,7 +525,7 @@ struct Run {
     const int kind = prep(b);                               // (the site's scale slots and the weight's scale; no operand is read through b)
     if (kind < 0) return kind;
     RAMP_REQUIRE(kind == 2, "abl: weight without fp16 fragment planes (use_abl must have been checked)");
-    prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 768 + 32.0 * M * L * 64, {M, 256, 768, -5});
+    prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 768 + 32.0 * M * L * 64, {M, 256, 768, -6});
     AblArgs t; t.M = M; t.L = L; t.QKV = qkv; t.dO = dout; t.W = k.abl_w; t.Z = z; t.add = add; t.ln_g = k.ln1_g; t.Y = out;
     t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.wsi = b.w_scale_inv; t.site = b.site_id; t.range_flag = b.range_flag;
     int rc = launch_abl(t, s);
@@ -542,7 +543,7 @@ struct Run {
     const int kind = prep(b);
     if (kind < 0) return kind;
     RAMP_REQUIRE(kind == 2, "tklb: weight without fp16 fragment planes (use_tklb must have been checked)");
-    prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 768, {M, 256, 768, -1});
+    prof_pre(c, s, CAT_GEMM, 2.0 * M * 256 * 768, {M, 256, 768, -12});
     TklbArgs t; t.M = M; t.X = dqkv; t.Z = z; t.add = add; t.Y = out; t.W = b.Wx; t.ln_g = ln_g;
     t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.wsi = b.w_scale_inv; t.site = b.site_id; t.range_flag = b.range_flag;
     int rc = launch_tklb(t, s);
@@ -1388,7 +1389,6 @@ int ramp_finalize_weights(ramp_ctx* c) {
     for (auto& u : c->ups) { CK(reg(u.w_f, 4ul * u.C * u.C, u.C)); CK(reg(u.w_b, 4ul * u.C * u.C, u.C)); }
   }
   RAMP_HIP_CHECK(hipDeviceSynchronize());
-  CK(init_gemm_q_attributes());
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
   CK(init_attention_attributes());
   CK(init_ffx_attributes());
@@ -1544,7 +1544,8 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
   HardConds hc; hc.idx = c->s_hard_idx; hc.val = c->s_hard_val; hc.n = p->n_hard;
   // noise_mode 1: the job's whole noise block is drawn here, inside the (captured) job, from the device record {seed, offset}
   if (p->noise_mode == 1)
-    LAUNCH(c, s, CAT_SAMPLER, 0, launch_philox_normal(c->s_noise, (long)((p->ddim ? 1 : (size_t)p->n_steps + 1) * n), c->s_philox, s));
+    LAUNCH(c, s, CAT_SAMPLER, 0, launch_philox_normal_sharded(c->s_noise, p->ddim ? 1 : p->n_steps + 1, B, (int)HS, (long)p->philox_sample0,
+                                                              p->philox_total > 0 ? (long)p->philox_total : (long)B, c->s_philox, s));
   // x_T = noise[0]; apply_hard_conditioning; chain[0]
   RAMP_HIP_CHECK(hipMemcpyAsync(c->s_x, c->s_noise, n * 4, hipMemcpyDeviceToDevice, s));
   LAUNCH(c, s, CAT_SAMPLER, 0, launch_hard_cond(c->s_x, hc, B, H, S, s));
@@ -1579,7 +1580,7 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
       RAMP_HIP_CHECK(hipMemcpyAsync(c->obs + 2 * ramp_ctx::MAX_SITES, c->obs, ramp_ctx::MAX_SITES * 4, hipMemcpyDeviceToDevice, s));
     CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = shared ? 1 : p->n_rp;
     m.w0 = (float)p->w0; m.w1 = (float)p->w1; m.w0p1 = (float)(1.0 + p->w0);
-    m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised;
+    m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised; m.predict_x0 = p->predict_x0 != 0;
     float* chain_j = chain ? c->s_chain + (size_t)(j + 1) * n : nullptr;
     const bool apf = p->apf.cloud != nullptr && p->apply_apf && p->apply_apf[j];
     if (!p->ddim) {
@@ -1620,6 +1621,8 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
                 void* stream) {
   RAMP_REQUIRE(c && p, "null argument");
   RAMP_REQUIRE(p->noise_mode == 0 || p->noise_mode == 1, "noise_mode must be 0 (injected) or 1 (Philox inside the job)");
+  RAMP_REQUIRE(p->philox_total == 0 || (p->philox_sample0 >= 0 && p->philox_sample0 + p->B <= p->philox_total), "philox shard outside the job (philox_sample0 + B <= philox_total)");
+  RAMP_REQUIRE(p->noise_mode == 0 || (c->cfg.horizon * c->cfg.state_dim) % 4 == 0, "noise_mode 1 needs H * S to be a multiple of 4");
   RAMP_REQUIRE(noise || p->noise_mode == 1, "null noise (only a job that draws its own, noise_mode 1, may omit it)");
   RAMP_REQUIRE(p->B > 0 && p->n_steps > 0 && p->n_rp >= 1 && p->n_rp <= 3, "bad sample dims");
   RAMP_REQUIRE(p->t && p->sqrt_recip && p->sqrt_recipm1, "missing schedule arrays");
@@ -1670,7 +1673,8 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
     else { put(p->coef1, 4 * p->n_steps); put(p->coef2, 4 * p->n_steps); put(p->stdv, 4 * p->n_steps); put(p->use_noise, 4 * p->n_steps); }
     if (p->apply_apf) put(p->apply_apf, 4 * p->n_steps);
     if (p->noise_scale) put(p->noise_scale, 4 * p->n_steps);
-    put(&p->clip_denoised, 4); put(&p->n_hard, 4);
+    put(&p->clip_denoised, 4); put(&p->predict_x0, 4); put(&p->n_hard, 4);
+    put(&p->philox_sample0, 8); put(&p->philox_total, 8);
     const int has_apf = p->apf.cloud != nullptr; put(&has_apf, 4);
     put(&p->apf.n_points, 4); put(&p->apf.window, 4); put(&p->apf.threshold, 8); put(&p->apf.strength, 8); put(&p->apf.passes, 4);
     const int ch = chain; put(&ch, 4); put(&c->force_x6, 4); put(&p->noise_mode, 4);
@@ -1746,7 +1750,7 @@ static int replan_body(ramp_ctx* c, const ramp_replan_params* p, hipStream_t s, 
     CK(rc_score);
     CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = shared ? 1 : p->n_rp;
     m.w0 = (float)p->w; m.w1 = 0.f; m.w0p1 = (float)(1.0 + p->w);
-    m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised;
+    m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised; m.predict_x0 = p->predict_x0 != 0;
     m.mean = nullptr; m.x0 = c->s_x0;
     CK(launch_cfg_mean(m, s));
     if (last) {
@@ -1844,7 +1848,7 @@ int ramp_replan(ramp_ctx* c, const ramp_replan_params* p, const ramp_replan_stat
     put(&p->B, 4); put(&p->n_steps, 4); put(&p->w, 8); put(p->t, 4 * p->n_steps); put(p->sqrt_recip, 4 * p->n_steps);
     put(p->sqrt_recipm1, 4 * p->n_steps); put(p->sqrt_a_t, 4 * p->n_steps); put(p->sqrt_1m_a_t, 4 * p->n_steps);
     put(p->sqrt_a_prev, 4 * p->n_steps); put(p->dir_coef, 4 * p->n_steps); put(&p->q_sqrt_a, 4); put(&p->q_sqrt_1m_a, 4);
-    put(&p->clip_denoised, 4); put(&p->n_hard, 4); put(&p->sm_window_last, 4); put(&p->sm_window_final, 4); put(&p->sm_dt, 4);
+    put(&p->clip_denoised, 4); put(&p->predict_x0, 4); put(&p->n_hard, 4); put(&p->sm_window_last, 4); put(&p->sm_window_final, 4); put(&p->sm_dt, 4);
     put(&p->sm_max_vel, 4); put(&p->n_static, 4); put(&p->n_dyn, 4); put(&p->thr_static, 8); put(&p->thr_pred, 8);
     put(&p->strength_static, 8); put(&p->strength_pred, 8); put(&p->window_static, 4); put(&p->n_cost, 4); put(&p->n_extra, 4);
     put(&p->cost_thr, 4); put(&p->w_smooth, 4); put(&p->w_len, 4); put(&c->force_x6, 4);
@@ -2013,12 +2017,12 @@ int ramp_waypoint_variance(const float* traj, int32_t B, int32_t H, int32_t S, d
 }
 
 int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32_t n_rp, double w0, double w1,
-                  float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip, float* x0_out,
+                  float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip, int32_t predict_x0, float* x0_out,
                   float* mean_out, float* ecomb_out, void* stream) {
   RAMP_REQUIRE(x && eps, "null argument");
   CfgMeanArgs m; m.x = x; m.eps = eps; m.B = B; m.HS = HS; m.n_rp = n_rp; m.w0 = (float)w0; m.w1 = (float)w1;
   m.w0p1 = (float)(1.0 + w0); m.sqrt_recip = sqrt_recip; m.sqrt_recipm1 = sqrt_recipm1; m.coef1 = coef1; m.coef2 = coef2;
-  m.clip = clip; m.x0 = x0_out; m.mean = mean_out; m.ecomb = ecomb_out;
+  m.clip = clip; m.predict_x0 = predict_x0 != 0; m.x0 = x0_out; m.mean = mean_out; m.ecomb = ecomb_out;
   return launch_cfg_mean(m, as_stream(stream));
 }
 
@@ -2039,7 +2043,7 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
                       int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step, int32_t L, int32_t mode,
                       float a_absmax_prev, float* a_absmax_out_host, int32_t* range_flag_out_host, void* stream) {
   RAMP_REQUIRE(A && W && C, "null argument");
-  RAMP_REQUIRE(mode >= 0 && mode <= 5, "mode: 0 fp32, 1 bf16x6, 2 bf16x6 (LDS-staged weights), 3 fp16x3, 4 fp16x3 through the LDS-DMA ring, 5 fp16x3 "
+  RAMP_REQUIRE(mode >= 0 && mode <= 5 && mode != 4, "mode: 0 fp32, 1 bf16x6, 2 bf16x6 (LDS-staged weights), 3 fp16x3, 5 fp16x3 "
                                        "sample-owning k = 5 convolution (tkc.hip)");
   hipStream_t s = as_stream(stream);
   if (mode == 5) {
@@ -2075,9 +2079,9 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
   a.M = M; a.N = N; a.K = K; a.taps = taps; a.shift0 = shift0; a.shift_step = shift_step; a.L = L;
   const long n = (long)taps * N * K;
   const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
-  unsigned short* planes = nullptr; float* slots = nullptr; unsigned short* aplanes = nullptr;
+  unsigned short* planes = nullptr; float* slots = nullptr;
   int rc = 0;
-  if ((mode == 3 || mode == 4) && frag_ok) {
+  if (mode == 3 && frag_ok) {
     // the product's static weight scale: max |w| -> [2^10, 2^11)  (ramp_finalize_weights)
     std::vector<float> hw(n);
     RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -2092,12 +2096,6 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
     a.Wx = planes; a.wx_packed = 2; a.w_scale_inv = 1.f / sc;
     a.a_absmax_in = a_absmax_prev > 0.f ? slots : nullptr; a.a_absmax_out = slots + 1;
     a.range_flag = reinterpret_cast<int*>(slots + 2);
-    if (mode == 4 && rc == 0) {
-      RAMP_HIP_CHECK(hipMalloc(&aplanes, (size_t)2 * M * K * sizeof(unsigned short)));
-      rc = launch_split_planes(A, K, aplanes, (long)M * K, M, K, a.a_absmax_in, slots + 1, reinterpret_cast<int*>(slots + 2), 0, s);
-      a.Ap = aplanes; a.ap_plane = (long)M * K;
-      if (!gemm_h3q_applicable(a)) { a.Ap = nullptr; }      // shapes it does not cover run the register-staged kernel
-    }
   } else if (mode == 1 && frag_ok) {
     RAMP_HIP_CHECK(hipMalloc(&planes, 3 * n * sizeof(unsigned short)));
     rc = launch_pack_x6(W, planes, (long)taps * N, K, s);
@@ -2107,7 +2105,7 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
     rc = launch_split3(W, planes, n, s);
     a.Wx = planes; a.wx_plane = n;
   }
-  if (rc == 0) rc = a.Ap ? launch_gemm_h3q(a, s) : launch_gemm(a, s);
+  if (rc == 0) rc = launch_gemm(a, s);
   hipError_t e = hipStreamSynchronize(s);
   if (rc == 0 && e == hipSuccess && slots) {
     float back[4] = {0, 0, 0, 0};
@@ -2120,7 +2118,6 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
     if (range_flag_out_host) *range_flag_out_host = 0;
   }
   if (planes) (void)hipFree(planes);
-  if (aplanes) (void)hipFree(aplanes);
   if (slots) (void)hipFree(slots);
   RAMP_HIP_CHECK(e);
   return rc;
@@ -2748,7 +2745,8 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
   const long n = (long)taps * N * K;
   const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
   unsigned short* planes = nullptr;
-  if ((mode == 3 || mode == 4) && frag_ok) {
+  RAMP_REQUIRE(mode != 4, "mode 4 (the experimental LDS-DMA tile GEMM) was removed from the library in round 5");
+  if (mode == 3 && frag_ok) {
     planes = reinterpret_cast<unsigned short*>(ar.alloc((size_t)n + 4));
     RAMP_REQUIRE(planes, "hipMalloc failed");
     const float sc = std::ldexp(1.f, 10) * std::sqrt((float)K * taps);      // max |w| ~ 1 / sqrt(K taps)
@@ -2756,13 +2754,6 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     CK(launch_pack_h3(W, planes, (long)taps * N, K, scp, s));
     a.Wx = planes; a.wx_packed = 2; a.w_scale_inv = 1.f / scp;
     a.a_absmax_in = slots; a.a_absmax_out = slots + 1; a.range_flag = reinterpret_cast<int*>(slots + 2);
-    if (mode == 4) {                                   // operands pre-split once; the timed launches are the LDS-DMA GEMM alone
-      unsigned short* ap = reinterpret_cast<unsigned short*>(ar.alloc((size_t)M * K + 4));
-      RAMP_REQUIRE(ap, "hipMalloc failed");
-      CK(launch_split_planes(A, Ka, ap, (long)M * K, M, K, slots, slots + 1, reinterpret_cast<int*>(slots + 2), 0, s));
-      a.Ap = ap; a.ap_plane = (long)M * K;
-      RAMP_REQUIRE(gemm_h3q_applicable(a), "shape not covered by the LDS-DMA GEMM");
-    }
   } else if (mode == 1 && frag_ok) {
     planes = reinterpret_cast<unsigned short*>(ar.alloc((3 * (size_t)n + 1) / 2 + 4));
     RAMP_REQUIRE(planes, "hipMalloc failed");
@@ -2774,7 +2765,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     CK(launch_split3(W, planes, n, s));
     a.Wx = planes; a.wx_plane = n;
   }
-  auto go = [&]() { return a.Ap ? launch_gemm_h3q(a, s) : launch_gemm(a, s); };
+  auto go = [&]() { return launch_gemm(a, s); };
   for (int i = 0; i < warmup; ++i) CK(go());
   hipEvent_t e0, e1;
   RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
@@ -2797,7 +2788,7 @@ int ramp_stress_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, i
   float us = 0.f;
   g_stress = &hook;
   int rc = 0;
-  if (rel_err_vs_fp32 && mode >= 1 && mode <= 4) {     // the same operands (seeded fills) on the exact-fp32 MFMA kernel first
+  if (rel_err_vs_fp32 && mode >= 1 && mode <= 3) {     // the same operands (seeded fills) on the exact-fp32 MFMA kernel first
     hook.capture_ref = true;
     rc = ramp_bench_gemm(M, N, K, taps, L, 0, flags & 0xff, 0, 1, &us, stream);
     hook.capture_ref = false;
@@ -2897,6 +2888,28 @@ int ramp_profile_read(ramp_ctx* c, double* ms, double* flops, int64_t* count) {
       fprintf(stderr, "[ramp profile] %8d %5d %5d %4d %6d %10.2f %9.1f %8.1f\n", sh[0], sh[1], sh[2], sh[3], kv.second.second,
               kv.second.first, kv.second.first * 1e3 / kv.second.second, fl * kv.second.second / (kv.second.first * 1e-3) / 1e12);
     }
+  }
+  return 0;
+}
+
+// per-kernel sums of the profiled launches (the shape codes the launch wrappers record): index 0 ffx forward, 1 ffx backward,
+// 2 tkl (LN1 -> QKV, d(o), out-projection), 3 tklb, 4 ato, 5 abl, 6 tkc, 7 tkw (wide k = 5 convolutions, GroupNorm fused),
+// 8 every other launch of the GEMM class (tile kernels, exact-fp32 layers, the round-2 fused forward)
+int ramp_profile_read_kernels(ramp_ctx* c, int32_t n, double* ms, double* flops, int64_t* count) {
+  RAMP_REQUIRE(c && ms && flops && count && n >= 1 && n <= 16, "bad arguments");
+  RAMP_HIP_CHECK(hipDeviceSynchronize());
+  for (int i = 0; i < n; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
+  for (size_t i = 0; i < c->prof_cat.size(); ++i) {
+    if (c->prof_cat[i] != CAT_GEMM) continue;
+    const auto& sh = c->prof_shape[i];
+    int k = 8;
+    if (sh[1] == -2) k = 0; else if (sh[1] == -3) k = 1;
+    else if (sh[3] == -10 || sh[3] == -11) k = 2; else if (sh[3] == -12) k = 3; else if (sh[3] == -4) k = 4; else if (sh[3] == -6) k = 5;
+    else if (sh[3] == -5) k = 6; else if (sh[3] == -7) k = 7;
+    if (k >= n) continue;
+    float t = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    ms[k] += t; flops[k] += c->prof_flops[i]; count[k]++;
   }
   return 0;
 }

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void cfg_mean_kernel(CfgMeanArgs a) {
       ec = ep[0];
     }
     const float xv = a.x[idx];
-    float x0 = sub(mul(a.sqrt_recip, xv), mul(a.sqrt_recipm1, ec));
+    // predict_start_from_noise (diffusion_model_static.py:109-118): predict_epsilon=False returns the network output itself
+    float x0 = a.predict_x0 ? ec : sub(mul(a.sqrt_recip, xv), mul(a.sqrt_recipm1, ec));
     if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
     if (a.ecomb) a.ecomb[idx] = ec;
     if (a.x0) a.x0[idx] = x0;
@@ -548,11 +549,20 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
 }
-__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, long n, const unsigned long long* __restrict__ rec) {
+// grp_row = groups of four per (sample, block) = HS / 4; a shard's local group g = (j B + b) grp_row + q is the stream's group
+// (j B_total + sample0 + b) grp_row + q.  grp_row == 0: the flat stream (local group = stream group).
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, long n, const unsigned long long* __restrict__ rec,
+                                                             long grp_row, long B, long sample0, long B_total) {
   const unsigned long long seed = rec[0], offset = rec[1];
   const long n_grp = (n + 3) >> 2;
   for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n_grp; g += (long)gridDim.x * 256) {
-    const unsigned long long ctr = (unsigned long long)g + offset;
+    long gg = g;
+    if (grp_row > 0) {
+      const long sb = g / grp_row, q = g - sb * grp_row;      // sb = j B + b
+      const long j = sb / B, b = sb - j * B;
+      gg = (j * B_total + sample0 + b) * grp_row + q;
+    }
+    const unsigned long long ctr = (unsigned long long)gg + offset;
     unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
     philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
     float z[4];
@@ -574,7 +584,17 @@ int launch_philox_normal(float* out, long n, const unsigned long long* rec, hipS
   RAMP_REQUIRE(out && rec && n > 0, "philox: null operand");
   RAMP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "philox: output must be 16-byte aligned");
   const long n_grp = (n + 3) >> 2;
-  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)std::min<long>((n_grp + 255) / 256, 8192)), dim3(256), 0, s, out, n, rec);
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)std::min<long>((n_grp + 255) / 256, 8192)), dim3(256), 0, s, out, n, rec, 0l, 1l, 0l, 1l);
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_philox_normal_sharded(float* out, int n_blocks, int B, int HS, long sample0, long B_total, const unsigned long long* rec, hipStream_t s) {
+  RAMP_REQUIRE(out && rec && n_blocks > 0 && B > 0 && HS > 0 && HS % 4 == 0, "philox: bad shard dims (H S must be a multiple of 4)");
+  RAMP_REQUIRE(sample0 >= 0 && B_total >= sample0 + B, "philox: the shard [sample0, sample0 + B) must lie inside the job's B_total samples");
+  RAMP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "philox: output must be 16-byte aligned");
+  const long n = (long)n_blocks * B * HS, n_grp = n >> 2;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)std::min<long>((n_grp + 255) / 256, 8192)), dim3(256), 0, s, out, n, rec,
+                     (long)(HS / 4), (long)B, sample0, B_total);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }

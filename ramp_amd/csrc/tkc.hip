@@ -70,8 +70,12 @@ void tkc_kernel(TkcArgs a, int n_tiles) {
   const int c = lane & 15, g = lane >> 4;
   const int n_my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
-  const float s_in = scale_of(a.amax_in);
-  const float os = a.wsi / s_in;
+  // amax_in == nullptr (a job's calibration evaluation, ramp_op_* without a previous maximum): no delayed scale exists, so every
+  // wave tile is scaled EXACTLY from its own maximum (max -> [2^5, 2^6), as the attention-internal operands of atk.hip): range-free,
+  // whatever the operand's magnitude -- an unscaled split would lose the low plane below ~1e-4 and overflow above 65504
+  const bool exact = a.amax_in == nullptr;
+  float s_in = scale_of(a.amax_in);
+  float os = a.wsi / s_in;
   float amax = 0.f;
 
   // ---- prologue: the weight planes -> LDS (once), the wave's tile zeroed (its padding rows stay zero for the block's lifetime)
@@ -108,6 +112,19 @@ void tkc_kernel(TkcArgs a, int n_tiles) {
     const int tok0 = tile * (4 * T) + wave * T;
     const bool full = tok0 + T <= a.M;
 
+    if (exact) {
+      float tm = 0.f;
+#pragma unroll
+      for (int t = 0; t < NG; ++t) {
+        const float lm = (full || tok0 + 16 * t + c < a.M) ? 1.f : 0.f;
+#pragma unroll
+        for (int fb = 0; fb < K / 16; ++fb) tm = amax4(xr[fb][t] * lm, tm);
+      }
+      tm = fmaxf(tm, __shfl_xor(tm, 32)); tm = fmaxf(tm, __shfl_xor(tm, 16)); tm = fmaxf(tm, __shfl_xor(tm, 8));
+      tm = fmaxf(tm, __shfl_xor(tm, 4)); tm = fmaxf(tm, __shfl_xor(tm, 2)); tm = fmaxf(tm, __shfl_xor(tm, 1));
+      s_in = scale_from(tm);
+      os = a.wsi / s_in;
+    }
     // ---- rows -> recorded maximum, two scaled fp16 planes -> the wave's LDS tile
 #pragma unroll
     for (int t = 0; t < NG; ++t) {
@@ -210,10 +227,7 @@ void tkc_kernel(TkcArgs a, int n_tiles) {
   amax = fmaxf(amax, __shfl_xor(amax, 4)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 1));
   // ONE atomic per block, behind a plain read of the slot (2048 same-address atomics at the tail of a 20-40 us launch cost 20 us: common.h)
   __syncthreads();
-  record_amax_block<true>(a.amax_out, amax, reinterpret_cast<float*>(smem + WBYTES));
-  if (lane == 0) {
-    if (a.range_flag && (!(amax * s_in < 60000.f) || (amax > 0.f && amax * s_in < 0.125f))) atomicMax(a.range_flag, a.site + 1);
-  }
+  record_amax_block_guarded<true>(a.amax_out, amax, reinterpret_cast<float*>(smem + WBYTES), a.range_flag, s_in, a.site);
 }
 
 bool tkc_applicable(int M, int L, int N, int K, int* ng) {

@@ -21,7 +21,17 @@ __device__ __forceinline__ void glds16(const void* src, char* dst) {
   __builtin_amdgcn_global_load_lds((glb_ptr_t)(uintptr_t)src, (lds_ptr_t)(unsigned)(uintptr_t)dst, 16, 0, 0);
 }
 
-__device__ __forceinline__ float scale_of(const float* p) {      // 2^(5 - floor(log2 max)): the operand lands in [2^5, 2^6)
+__device__ __forceinline__ float scale_from(float mx) {           // 2^(5 - floor(log2 max)): the operand lands in [2^5, 2^6)
+  float s = 1.f;
+  if (mx > 0.f) {
+    int eb = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu);
+    int sb = 259 - eb;
+    sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+    s = __builtin_bit_cast(float, (unsigned)sb << 23);
+  }
+  return s;
+}
+__device__ __forceinline__ float scale_of(const float* p) {      // the same from a recorded maximum (null / zero: 1)
   float s = 1.f;
   const float mx = p ? *p : 0.f;
   if (mx > 0.f) {

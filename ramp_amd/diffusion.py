@@ -83,6 +83,9 @@ class _GaussianDiffusionBase(nn.Module):
         self.noise_source = noise_source
         self.noise_seed = int(noise_seed)
         self._philox_offset = 0                 # groups of four elements consumed so far
+        # several GPUs: this wrapper's batch is samples [sample0, sample0 + B) of a job of `total` trajectories; a philox job then
+        # draws exactly the elements the unsharded job draws for those samples (set_noise_shard; ramp_sample_params.philox_sample0)
+        self._philox_shard = None
         self.context_model = context_model
         self.n_diffusion_steps = n_diffusion_steps
         self.ddim_num_inference_steps = 8 if (compose and use_apf) else 5      # diffusion_model_static.py:40
@@ -95,9 +98,8 @@ class _GaussianDiffusionBase(nn.Module):
         self.cfg_weight = self._default_cfg_weight if cfg_weight is None else float(cfg_weight)
         self.compose_weights = tuple(compose_weights) if compose_weights is not None else self._default_compose
         self.ddim = self._default_ddim if sampler is None else (sampler == 'ddim')
-        if not predict_epsilon:
-            raise NotImplementedError("predict_epsilon=False: the reference inference configs all use True "
-                                      "(base_config.py:26) and the energy gradient is an epsilon prediction")
+        # predict_epsilon=False is the reference constructor's default (diffusion_model_static.py:28): the guidance-combined
+        # network output is then x0 itself (predict_start_from_noise, :109-118); the inference configs pass True (base_config.py:26)
         if variance_schedule == 'cosine':
             betas = cosine_beta_schedule(n_diffusion_steps, s=0.008, a_min=0, a_max=0.999)
         elif variance_schedule == 'exponential':
@@ -131,9 +133,44 @@ class _GaussianDiffusionBase(nn.Module):
     apf_ddpm = dict(threshold=0.07, strength=0.1, window=5, after=20)          # diffusion_model_static.py:176-184
     apf_ddim = dict(threshold=0.07, strength=0.1, window=7, start=2, passes=3)  # diffusion_model_static.py:298-319
 
+    def set_noise_shard(self, sample0: Optional[int], total: Optional[int] = None):
+        """noise_source='philox' on one shard of a larger job: this wrapper's n_samples trajectories are the global samples
+        [sample0, sample0 + n_samples) of ``total``; every rank then draws what ONE GPU running all ``total`` samples with the
+        same ``noise_seed`` would have drawn for them.  ``set_noise_shard(None)`` makes every call a whole job again."""
+        self._philox_shard = None if sample0 is None else (int(sample0), int(total))
+
     # ------------------------------------------------------------------ helpers
     def _device(self):
         return self.betas.device
+
+    # ------------------------------------------------------------------ the reference's public arithmetic helpers
+    def predict_noise_from_start(self, x_t, t, x0):
+        """diffusion_model_static.py:96-106."""
+        if self.predict_epsilon:
+            return x0
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / \
+            extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        """diffusion_model_static.py:108-118."""
+        if self.predict_epsilon:
+            return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                    - extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+        return noise
+
+    def q_posterior(self, x_start, x_t, t):
+        """diffusion_model_static.py:120-127."""
+        posterior_mean = (extract(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                          + extract(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        return (posterior_mean, extract(self.posterior_variance, t, x_t.shape),
+                extract(self.posterior_log_variance_clipped, t, x_t.shape))
+
+    def deep_repeat_tensor(self, x, t, traj_normalized, obstacle_pts, n_rp):
+        """The reference's CFG batch doubling as tensors (diffusion_model_static.py:129-147: ``repeat_interleave``; the 3-D and
+        dynamic classes override it with their blocked ``repeat``).  The HIP path never materialises these copies -- row r of
+        the network reads trajectory r // n_rp (DESIGN.md section 3) -- the method exists for callers that hold it."""
+        return (x.repeat_interleave(n_rp, dim=0), t.repeat_interleave(n_rp, dim=0),
+                traj_normalized.repeat_interleave(n_rp, dim=0), obstacle_pts.repeat_interleave(x.shape[0] * n_rp, dim=0))
 
     def _n_rp(self) -> int:
         return 3 if self.compose else 2
@@ -254,6 +291,7 @@ class _GaussianDiffusionBase(nn.Module):
             p.sqrt_a_t, p.sqrt_1m_a_t, p.sqrt_a_prev, p.dir_coef = arr_f(sa), arr_f(s1), arr_f(sp), arr_f(dc)
         p.apply_apf = arr_i(apply_apf)
         p.clip_denoised = int(bool(self.clip_denoised))
+        p.predict_x0 = int(not self.predict_epsilon)
         idx, val = self._hard_arrays(hard_conds, B)
         p.n_hard = len(idx)
         p.hard_idx_host = arr_i(idx) if idx else None
@@ -278,8 +316,12 @@ class _GaussianDiffusionBase(nn.Module):
         chain = torch.empty((n_steps + 1, B, H, S), device=dev, dtype=torch.float32) if return_chain else None
         x_out = torch.empty((B, H, S), device=dev, dtype=torch.float32)
         if noise is None:          # the job draws its own: the next (n_steps + 1 | 1) * B * H * S elements of the Philox stream
-            n_el = (1 if ddim else n_steps + 1) * B * H * S
+            s0, tot = self._philox_shard if self._philox_shard is not None else (0, B)
+            if not (0 <= s0 and s0 + B <= tot):
+                raise ValueError(f"set_noise_shard: samples [{s0}, {s0 + B}) lie outside the job's {tot}")
+            n_el = (1 if ddim else n_steps + 1) * tot * H * S                     # the WHOLE job's block: every shard advances alike
             p.noise_mode, p.philox_seed, p.philox_offset = 1, self.noise_seed, self._philox_offset
+            p.philox_sample0, p.philox_total = s0, tot
             self.last_philox = (self.noise_seed, self._philox_offset, n_el)
             self._philox_offset += (n_el + 3) // 4
         else:
@@ -428,7 +470,8 @@ class _GaussianDiffusionBase(nn.Module):
                                          float(self.sqrt_recip_alphas_cumprod[ti]),
                                          float(self.sqrt_recipm1_alphas_cumprod[ti]),
                                          float(self.posterior_mean_coef1[ti]), float(self.posterior_mean_coef2[ti]),
-                                         int(bool(self.clip_denoised)), _lib.ptr(x0), _lib.ptr(mean), _lib.ptr(ec),
+                                         int(bool(self.clip_denoised)), int(not self.predict_epsilon),
+                                         _lib.ptr(x0), _lib.ptr(mean), _lib.ptr(ec),
                                          _lib.current_stream()), "ramp_cfg_mean")
         pv = extract(self.posterior_variance, t, x.shape)
         plv = extract(self.posterior_log_variance_clipped, t, x.shape)
@@ -444,6 +487,59 @@ class _GaussianDiffusionBase(nn.Module):
 
     _supports_apf = True
 
+    @torch.no_grad()
+    def p_mean_variance_compose(self, x, hard_conds, context, t, traj_normalized=None, obstacle_pts=None, forward_t=None,
+                                compose=True):
+        """diffusion_model_static.py:188-229 / diffusion_model_3d.py:163-182: the three-row (scene A, scene B, unconditional)
+        evaluation; the reference's own ``ddpm_sample_fn`` calls it by this name (sample_functions.py:28).  Same kernels as
+        ``p_mean_variance`` on a wrapper built with ``compose=True`` (no APF hook on this path in the reference)."""
+        if not self.compose:
+            raise ValueError("p_mean_variance_compose needs a wrapper constructed with compose=True (three rows per trajectory)")
+        return self.p_mean_variance(x, hard_conds, context, t, traj_normalized=traj_normalized, obstacle_pts=obstacle_pts,
+                                    forward_t=None, compose=True)
+
+    @torch.no_grad()
+    def ddim_p_sample(self, x, hard_conds, context, t, obstacle_pts, traj_normalized=None, forward_t=None, eta=0.0,
+                      use_clipped_model_output=False):
+        """One DDIM step of the static sampler (diffusion_model_static.py:259-333, eta = 0): x0 from the CFG / compose
+        evaluation, the APF hook (three passes of window 7 with hard conditioning after each) when ``use_apf`` and
+        ``forward_t >= 2``, then the deterministic update -- the step ``ramp_sample`` runs inside its captured loop, here one
+        at a time through the kernel-level entry points."""
+        assert use_clipped_model_output and eta == 0.0
+        dev = self._device()
+        B, H, S = x.shape
+        ti = int(t.reshape(-1)[0])
+        prev = ti - self.n_diffusion_steps // self.ddim_num_inference_steps
+        ac = self.alphas_cumprod.detach().cpu()
+        a_t = ac[ti]
+        a_prev = ac[prev] if prev >= 0 else self.final_alpha_cumprod[0]
+        was = self.ddim
+        self.ddim = True
+        try:
+            _, _, _, x0, _ = self.p_mean_variance(x, hard_conds, context, t, traj_normalized=traj_normalized,
+                                                  obstacle_pts=obstacle_pts, compose=self.compose)
+        finally:
+            self.ddim = was
+        xx = x.detach().to(dev, torch.float32).contiguous()
+        c = self.apf_ddim
+        if self.APF and self._supports_apf and forward_t is not None and forward_t >= c['start']:
+            from .apf import ObstacleField, avoidance
+            if self.compose:      # first six obstacles of scene A + first four of scene B (static.py:306-310)
+                cloud = torch.cat([obstacle_pts[0], obstacle_pts[1][:4]], dim=0).reshape(-1, 2)
+            else:       # the loop hands over obstacle_pts.unsqueeze(0) (static.py:366); one copy of the cloud is the field
+                cloud = (obstacle_pts[0] if obstacle_pts.dim() == 4 else obstacle_pts).reshape(-1, 2)
+            field = ObstacleField(cloud, distance_threshold=c['threshold'])
+            for _ in range(c['passes']):
+                x0 = avoidance(x0, field, avoidance_window=c['window'], avoidance_strength=c['strength'])
+                x0 = apply_hard_conditioning(x0, hard_conds)
+        out = torch.empty_like(xx)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().ramp_ddim_finish(_lib.ptr(xx), _lib.ptr(x0.contiguous()), float(a_t ** 0.5),
+                                                    float((1 - a_t) ** 0.5), float(a_prev ** 0.5),
+                                                    float((1 - a_prev) ** 0.5), _lib.ptr(out), B, H, S,
+                                                    _lib.current_stream()), "ramp_ddim_finish")
+        return out
+
 
 class StaticGaussianDiffusionModel(_GaussianDiffusionBase):
     """2-D sampler: CFG w = 2, compose w1 = w2 = 2, DDIM-5 by default, APF hook."""
@@ -458,6 +554,11 @@ class GaussianDiffusionModel3d(_GaussianDiffusionBase):
     _default_compose = (5.0, 5.0)      # diffusion_model_3d.py:170-171
     _default_ddim = False
     _supports_apf = False
+
+    def deep_repeat_tensor(self, x, t, traj_normalized, obstacle_pts, n_rp):
+        """diffusion_model_3d.py:124-142: blocked ``repeat`` (rows [x_0..x_{B-1}] n_rp times), unlike the static class."""
+        rep = lambda v: v.repeat((n_rp,) + (1,) * (v.dim() - 1))
+        return rep(x), t.repeat((n_rp,)), rep(traj_normalized), rep(obstacle_pts)
 
 
 class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
@@ -492,6 +593,11 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
     # dynamic APF constants hard-coded in the reference (diffusion_model_dynamic.py:380-389)
     apf_dynamic = dict(obs_radius=0.1, points_per_obstacle=64, threshold_static=0.2, threshold_pred=0.5,
                        strength_static=0.15, strength_pred=0.15, window_static=8, window_pred=5)
+
+    def deep_repeat_tensor(self, x, t, traj_normalized, obstacle_pts, n_rp):
+        """diffusion_model_dynamic.py:129-147: blocked ``repeat`` (the layout behind quirk Q1, see ``cfg_mode``)."""
+        rep = lambda v: v.repeat((n_rp,) + (1,) * (v.dim() - 1))
+        return rep(x), t.repeat((n_rp,)), rep(traj_normalized), rep(obstacle_pts)
 
     def _row_pattern(self, B):
         if self.cfg_mode == 'intended' or B is None:
@@ -704,6 +810,7 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
         c = self.apf_dynamic
         p = _lib.RampReplanParams()
         p.B, p.n_rp, p.n_steps, p.clip_denoised, p.w = B, 2, len(low), int(bool(self.clip_denoised)), float(self.cfg_weight)
+        p.predict_x0 = int(not self.predict_epsilon)
         p.t = arr_i(low)
         p.sqrt_recip, p.sqrt_recipm1 = arr_f(sr), arr_f(srm)
         p.sqrt_a_t, p.sqrt_1m_a_t, p.sqrt_a_prev, p.dir_coef = arr_f(sa), arr_f(s1), arr_f(sp), arr_f(dc)
@@ -767,8 +874,8 @@ class DynamicGaussianDiffusionModel(_GaussianDiffusionBase):
                 # Sharded: the ranks re-plan round by round in LOCK-STEP (every rank draws the same number of torch / numpy random
                 # numbers, so their pursuer clouds stay identical afterwards, and nobody waits in a collective while another rank
                 # is still looping); after each round the lowest rank that found a collision-free plan broadcasts it.
+                nb = min(30, rdist.min_over_ranks(B, device) if sharded else B)      # the SAME count on every rank: equal RNG consumption
                 while True:
-                    nb = min(30, B)
                     new_hc = {kk: v[:nb].clone() for kk, v in hard_conds.items()}
                     xs = self.ddim_replan_scratch((nb, H, S), new_hc, context, traj_normalized, forward_t=k,
                                                   obstacle_pts=cloud, use_apf=False, executed_history=executed_history)

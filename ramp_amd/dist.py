@@ -178,6 +178,16 @@ def lowest_rank_with(flag: bool, device) -> int:
     return v if v < world else -1
 
 
+def min_over_ranks(value: int, device) -> int:
+    """The minimum of `value` over the ranks (one MIN all-reduce); `value` itself without a process group.  The sharded
+    planner sizes its scratch re-plan with it, so that every rank draws the same number of random values per round."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def _select_hip(mask, plen, smooth, w_smooth, w_len):
     from . import _lib
     res = torch.zeros(4, dtype=torch.int32, device=mask.device)

@@ -59,6 +59,19 @@ def make_unet_state_dict(sp: UNetSpec, seed: int = 0, with_scene_encoder: bool =
     return sd
 
 
+def add_outlier_channels(sd, seed: int = 0, n_channels: int = 8, factor: float = 512.0):
+    """A copy of ``sd`` with trained-transformer statistics: in every transformer block, ``n_channels`` seeded OUTPUT channels
+    (rows) of ``attn1.to_out.0.weight`` and of ``ff.net.2.weight`` are scaled by ``factor`` (2^9) -- a few residual-stream
+    channels two to three orders of magnitude above the rest, which is where one power-of-two scale per tensor with a
+    2^8 full-precision window is most exposed.  Biases and every other tensor are untouched."""
+    out = OrderedDict((k, np.array(v, copy=True)) for k, v in sd.items())
+    for key in out:
+        if key.endswith("attn1.to_out.0.weight") or key.endswith("ff.net.2.weight"):
+            rows = _rng(seed, "outlier/" + key).choice(out[key].shape[0], size=n_channels, replace=False)
+            out[key][np.sort(rows)] *= np.float32(factor)
+    return out
+
+
 def make_boxes(n_boxes: int, dim: int = 2, seed: int = 42, box_size: float = 0.26,
                start=None, goal=None, extent: float = 0.7) -> np.ndarray:
     """Box centres uniform in [-extent, extent]^dim, rejecting overlap with start/goal."""

@@ -15,6 +15,7 @@ import pytest
 import torch
 
 from ramp_amd import _lib, synth
+import util
 from util import GOLDEN, NoiseInjector, build_unet, dev
 
 pytestmark = pytest.mark.gpu
@@ -116,7 +117,9 @@ def test_config3_full_size_against_embedded_reference_trajectories():
     # w = 5.75 amplifies rounding ~12x per step: the free-running chain is comparable at 5e-4 (the float64 truth is 1e-4
     # from the reference's own fp32 chain, tests/test_gpu_sampler.py::test_chain3d_...), every step teacher-forced at 1e-4
     err = np.abs(a[:, :2] - g["chain"]).reshape(26, -1).max(1)
-    print(f"config 3 full size: embedded golden rows free-running max {err.max():.2e}")
+    truth = util.oracle64_chain("chain_c3", 6, 48, 25, 5.75)
+    e_ref = np.abs(g["chain"] - truth).max(); e_gpu = np.abs(a[:, :2] - truth).max()
+    print(f"config 3 full size: embedded golden rows free-running max {err.max():.2e}; vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e} (ratio {e_gpu / e_ref:.2f})")
     assert err.max() < 5e-4
     hcb = {k: torch.from_numpy(v).cuda().unsqueeze(0).expand(B, -1) for k, v in synth.default_hard_conds(6, 48).items()}
     tf = []                                                      # EVERY step from the reference's own previous state
@@ -146,7 +149,9 @@ def test_config5_per_gpu_shard_full_size():
     assert _range_flag(u) == 0
     assert a.shape == (51, B, 64, 6) and np.isfinite(a).all() and np.abs(a[-1]).max() <= 1.0
     err = np.abs(a[:, :2] - g["chain"]).reshape(51, -1).max(1)
-    print(f"config 5 shard: embedded golden rows free-running max {err.max():.2e} (final {err[-1]:.2e})")
+    truth = util.oracle64_chain("chain3d_h64_t50", 6, 64, 50, 5.75)
+    e_ref = np.abs(g["chain"] - truth).max(); e_gpu = np.abs(a[:, :2] - truth).max()
+    print(f"config 5 shard: embedded golden rows free-running max {err.max():.2e} (final {err[-1]:.2e}); vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e} (ratio {e_gpu / e_ref:.2f})")
     assert err.max() < 2e-3                # same bar as the B = 2 test: T = 50 steps of 12x amplification (the float64 truth is
                                            # 4.3e-4 from the reference's own fp32 chain, tests/test_gpu_sampler.py)
     hcb = {k: torch.from_numpy(v).cuda().unsqueeze(0).expand(B, -1) for k, v in synth.default_hard_conds(6, 64).items()}

@@ -81,35 +81,6 @@ def test_gemm_fp16x3_launch_rules_at_scale(M, N, K, resid):
     assert worst < 3e-6, worst
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 256, 256), (384, 768, 256), (1024, 256, 1024), (256, 512, 2048), (2048, 2048, 256),
-                                   (128 * 37, 1024, 512)])
-@pytest.mark.parametrize("extras", [False, True])
-def test_gemm_lds_dma_kernel(M, N, K, extras):
-    """The fp16x3 GEMM whose operands both arrive through the LDS-DMA ring (gemm_q.hip: pre-split activation planes,
-    128 x 256 tiles, eight waves) against float64, with and without bias + residual, scaled from a recorded maximum;
-    tile streams of 1 .. 37 x 4 tiles per launch exercise the cross-tile prefetch and its vmcnt bookkeeping."""
-    g = rng(M + N + K)
-    A = (g.standard_normal((M, K)) * 1.7).astype(np.float32)
-    W = (g.standard_normal((1, N, K)) / np.sqrt(K)).astype(np.float32)
-    bias = g.standard_normal(N).astype(np.float32) if extras else None
-    resid = g.standard_normal((M, N)).astype(np.float32) if extras else None
-    ref = A.astype(np.float64) @ W[0].astype(np.float64).T
-    if extras:
-        ref = ref + bias + resid
-    out = torch.full((M, N), float("nan"), device="cuda")
-    amax = float(np.abs(A).max())
-    rec, flag = _lib.op_gemm(dev(A), dev(W), None if bias is None else dev(bias), None if resid is None else dev(resid), out,
-                             M, N, K, 1, 0, 0, 1, mode="fp16x3-dma", a_absmax_prev=amax * 0.7)
-    assert flag == 0 and rec == amax
-    got = out.cpu().numpy()
-    assert np.isfinite(got).all()
-    assert rel(got, ref) < 3e-6
-    out2 = torch.empty((M, N), device="cuda")                       # repeatable bit for bit (no race in the ring)
-    _lib.op_gemm(dev(A), dev(W), None if bias is None else dev(bias), None if resid is None else dev(resid), out2,
-                 M, N, K, 1, 0, 0, 1, mode="fp16x3-dma", a_absmax_prev=amax * 0.7)
-    assert torch.equal(out, out2)
-
-
 @pytest.mark.parametrize("R,L,C", [(3, 48, 32), (5, 24, 64), (2, 12, 128), (7, 6, 256), (2, 64, 32), (3, 8, 256), (2, 24, 32)])
 @pytest.mark.parametrize("mish", [0, 1])
 def test_groupnorm_fwd_bwd(R, L, C, mish):
@@ -276,7 +247,7 @@ def test_hard_conditioning_and_cfg_mean():
     mean = c1 * x0 + c2 * x
     o0 = torch.empty((5, 48, 4), device="cuda"); om = torch.empty_like(o0); oe = torch.empty_like(o0)
     de, dx = dev(eps), dev(x)
-    _lib.check(_lib.load().ramp_cfg_mean(_lib.ptr(dx), _lib.ptr(de), 5, 192, 2, w, 0.0, A, Bc, c1, c2, 1,
+    _lib.check(_lib.load().ramp_cfg_mean(_lib.ptr(dx), _lib.ptr(de), 5, 192, 2, w, 0.0, A, Bc, c1, c2, 1, 0,
                                          _lib.ptr(o0), _lib.ptr(om), _lib.ptr(oe), S()))
     assert np.array_equal(oe.cpu().numpy(), e) and np.array_equal(o0.cpu().numpy(), x0)
     assert np.array_equal(om.cpu().numpy(), mean)
@@ -735,3 +706,23 @@ def test_gemm_variants_are_bitwise_stable_under_stress(name, M, N, K, taps, L, m
     assert mism.value == 0, name
     if vs_fp32:
         assert 0.0 <= err.value < 5e-6, (name, err.value)
+
+
+SOAK_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags
+    ("abl L=48", 393216, 256, 768, 1, 48, 15, 0), ("abl L=6", 49152, 256, 768, 1, 6, 15, 0), ("ato L=48", 393216, 256, 256, 1, 48, 10, 1),
+    ("atb L=24", 196608, 256, 256, 1, 24, 13, 0), ("ffx forward", 393216, 2048, 256, 1, 1, 6, 0), ("ffx backward", 393216, 2048, 256, 1, 1, 7, 0),
+    ("tkl LN1->QKV", 393216, 768, 256, 1, 1, 8, 1), ("tklb", 196608, 256, 768, 1, 1, 9, 0),
+]
+
+
+@pytest.mark.parametrize("name,M,N,K,taps,L,mode,flags", SOAK_CASES, ids=[c[0].replace(" ", "-") for c in SOAK_CASES])
+def test_soak_2000_launches_bitwise(name, M, N, K, taps, L, mode, flags):
+    """The kernels whose correctness rests on inline-asm LDS-DMA rings with hand-counted ``s_waitcnt vmcnt(N)`` (ffx, tkl / tklb,
+    ato / atb, abl): 2000 back-to-back launches per kernel on the same operands, every output compared bit for bit with the first
+    launch's on the device (ramp_stress_gemm).  ramp_amd/tools/soak.py as a test, so that the schedules are exercised on every box
+    the suite runs on, not only the builder's (engineering 12)."""
+    import ctypes as C
+    mism = C.c_int64(-1)
+    _lib.check(_lib.load().ramp_stress_gemm(M, N, K, taps, L, mode, flags, 2000, C.byref(mism), None, None), "ramp_stress_gemm")
+    print(f"{name}: 2000 launches, {mism.value} differing words")
+    assert mism.value == 0, name

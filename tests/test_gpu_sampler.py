@@ -191,11 +191,9 @@ def test_chain3d_batched_equals_independent_reference_runs():
     chain, used = run(dm, g, 2)
     assert used == 26 and chain.shape == g["chain"].shape
     err = np.abs(chain - g["chain"]).reshape(26, -1).max(1)
-    uo = O.UNetOracle(weights(6, 48, True), 6, 48, obstacle_3d=True, dtype=np.float64)
-    sm = O.SamplerOracle(uo, 25, 5.75, dtype=np.float64, sched=dict(np.load(f"{GOLDEN}/schedule_T25.npz")))
-    truth = sm.ddpm(g["noise"], synth.default_hard_conds(6, 48), g["latent"])
+    truth = util.oracle64_chain("chain3d_ddpm", 6, 48, 25, 5.75)
     e_ref = np.abs(g["chain"] - truth).max(); e_gpu = np.abs(chain - truth).max()
-    print(f"3d ddpm free-running: vs reference {err.max():.2e}; vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e}")
+    print(f"3d ddpm free-running: vs reference {err.max():.2e}; vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e} (ratio {e_gpu / e_ref:.2f})")
     assert err.max() < 5e-4
     assert e_gpu < 3 * e_ref
 
@@ -299,11 +297,14 @@ def test_config5_shape_chain_against_reference_fixture():
     chain, used = run(dm, g, 2)
     assert used == 51 and chain.shape == g["chain"].shape == (51, 2, 64, 6)
     err = np.abs(chain - g["chain"]).max()
-    uo = O.UNetOracle(weights(6, 64, True), 6, 64, obstacle_3d=True, dtype=np.float64)
-    sm = O.SamplerOracle(uo, 50, 5.75, dtype=np.float64, sched=dict(np.load(f"{GOLDEN}/schedule_T50.npz")))
-    truth = sm.ddpm(g["noise"], synth.default_hard_conds(6, 64), g["latent"])
+    truth = util.oracle64_chain("chain3d_h64_t50", 6, 64, 50, 5.75)
     e_ref = np.abs(g["chain"] - truth).max(); e_gpu = np.abs(chain - truth).max()
-    print(f"config-5 shape free-running: vs reference {err:.2e}; vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e}")
+    print(f"config-5 shape free-running: vs reference {err:.2e}; vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e} (ratio {e_gpu / e_ref:.2f})")
+    for mode in ("bf16x6", "fp32"):       # the same chain on the other two arithmetic modes: is the distance a property of the mode or of the realisation?
+        um = build_unet(6, 64, True, max_rows=16, gemm_mode=mode)
+        dmm = GaussianDiffusionModel3d(model=um, variance_schedule="exponential", n_diffusion_steps=50, predict_epsilon=True, use_graph=True).eval().to("cuda")
+        cm, _ = run(dmm, g, 2)
+        print(f"   {mode}: vs reference {np.abs(cm - g['chain']).max():.2e}, vs float64 truth {np.abs(cm - truth).max():.2e}")
     assert e_gpu < 3 * e_ref              # as close to the truth as the reference itself (measured 6.7e-4 vs 4.3e-4)
     assert err < 2e-3                     # hence at most e_ref + e_gpu from the reference (measured 1.1e-3)
     flag = C.c_int32(-1)
@@ -644,3 +645,94 @@ def test_philox_noise_is_host_replicable_and_jobs_draw_it_inside_the_graph():
             b = dt.run_inference(None, hc, **kw).cpu().numpy()
         assert np.array_equal(a, b), (job, np.abs(a - b).max())
         assert np.isfinite(a).all() and np.abs(a).max() < 10.0
+
+
+def test_sharded_philox_jobs_reproduce_the_unsharded_job():
+    """the sample batch is sharded over GPUs.  With noise_source='philox' the counter is keyed on the GLOBAL
+    sample index (ramp_sample_params.philox_sample0 / philox_total; ``set_noise_shard``), so N shards draw exactly what ONE
+    job of the same total draws: (1) the x_T states (noise + hard conditioning, no network in between) of two shards equal
+    the unsharded job's rows BIT FOR BIT, for consecutive jobs on the same stream; (2) a ragged three-way split likewise;
+    (3) the final trajectories agree to rounding (different batch composition changes the delayed power-of-two operand
+    scales and a sample's position inside a wave tile, i.e. summation order -- not the arithmetic contract)."""
+    from ramp_amd.models import StaticGaussianDiffusionModel
+    g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
+    H, S, T, B = 48, 4, 25, 48
+    hc = {k: torch.from_numpy(v) for k, v in synth.default_hard_conds(S, H).items()}
+    cloud = dev(g["cloud"])
+
+    def make(rows):
+        u = build_unet(S, H, False, max_rows=rows)
+        return StaticGaussianDiffusionModel(model=u, n_diffusion_steps=T, predict_epsilon=True, sampler="ddpm", use_graph=True,
+                                            noise_source="philox", noise_seed=4242).eval().to("cuda")
+    kw = dict(horizon=H, return_chain=True, obstacle_pts=cloud, noise_std_extra_schedule_fn=lambda x: 0.5)
+    whole = make(2 * B)
+    parts = [make(2 * 24), make(2 * 24)]
+    rag = [make(2 * 20), make(2 * 20), make(2 * 20)]
+    for job in range(2):
+        ref = whole.run_inference(None, hc, n_samples=B, **kw)
+        got = []
+        for r, dm in enumerate(parts):
+            dm.set_noise_shard(24 * r, B)
+            got.append(dm.run_inference(None, hc, n_samples=24, **kw))
+        got = torch.cat(got, dim=1)
+        assert torch.equal(got[0], ref[0]), job                  # x_T: the same elements of the same stream
+        d = float((got - ref).abs().max())
+        print(f"job {job}: 2 shards vs 1 job, all {T + 1} states: max {d:.2e}")
+        assert d < 2e-5
+        cuts = [(0, 20), (20, 36), (36, 48)]
+        got = []
+        for (a, b), dm in zip(cuts, rag):
+            dm.set_noise_shard(a, B)
+            got.append(dm.run_inference(None, hc, n_samples=b - a, **kw))
+        got = torch.cat(got, dim=1)
+        assert torch.equal(got[0], ref[0]), job
+        assert float((got - ref).abs().max()) < 2e-5
+        assert whole.last_philox == parts[0].last_philox == rag[2].last_philox      # every shard advanced the stream alike
+    with pytest.raises(ValueError):
+        parts[0].set_noise_shard(40, B)
+        parts[0].run_inference(None, hc, n_samples=24, **kw)
+
+
+def test_predict_epsilon_false_and_the_public_helpers():
+    """The reference constructor's default predict_epsilon=False (the combined network output IS x0,
+    diffusion_model_static.py:28, 109-118) and the sampler class's public helpers, against outputs of the imported reference
+    (tests/golden/boundary_cases.npz): one p_mean_variance, a free-running T = 25 DDPM chain, one static ddim_p_sample step
+    with and without the APF hook, p_mean_variance_compose through its own name."""
+    from ramp_amd.models import StaticGaussianDiffusionModel
+    g = np.load(f"{GOLDEN}/boundary_cases.npz")
+    H, S = 48, 4
+    cloud = dev(g["cloud"])
+    t = torch.full((3,), int(g["t"]), dtype=torch.long, device="cuda")
+    for pe, tag in ((True, "eps"), (False, "x0")):
+        u = build_unet(S, H, False, max_rows=16)
+        dm = StaticGaussianDiffusionModel(model=u, n_diffusion_steps=25, predict_epsilon=pe, sampler="ddim").eval().to("cuda")
+        mean, _, _, x0, ec = dm.p_mean_variance(dev(g["x"]), None, None, t, obstacle_pts=cloud.unsqueeze(0))
+        assert rel(ec.cpu().numpy(), g[f"pmv_ecomb_{tag}"]) < 5e-5
+        assert np.abs(x0.cpu().numpy() - g[f"pmv_x0_{tag}"]).max() < 1e-4, tag
+        assert np.abs(mean.cpu().numpy() - g[f"pmv_mean_{tag}"]).max() < 1e-4, tag
+    # the chain: x0-prediction, DDPM, free-running, graph
+    u = build_unet(S, H, False, max_rows=16)
+    dm = StaticGaussianDiffusionModel(model=u, n_diffusion_steps=25, sampler="ddpm", use_graph=True).eval().to("cuda")   # predict_epsilon omitted: False
+    assert dm.predict_epsilon is False
+    chain, used = run(dm, {"noise": g["x0_noise"], "cloud": g["cloud"]}, 2)
+    err = np.abs(chain - g["x0_chain"]).max()
+    print(f"predict_epsilon=False DDPM chain free-running: max {err:.2e}")
+    assert used == 26 and err < 1e-4
+    # one static DDIM step, T = 100 / K = 5, t = 40, forward_t = 2
+    hc = {k: torch.from_numpy(v).cuda()[None].repeat(3, 1) for k, v in synth.default_hard_conds(S, H).items()}
+    for apf, key in ((False, "ddim_out"), (True, "ddim_out_apf")):
+        u = build_unet(S, H, False, max_rows=16)
+        dm = StaticGaussianDiffusionModel(model=u, n_diffusion_steps=100, predict_epsilon=True, use_apf=apf).eval().to("cuda")
+        out = dm.ddim_p_sample(dev(g["ddim_x"]), hc, None, torch.full((3,), 40, dtype=torch.long, device="cuda"), cloud.unsqueeze(0),
+                               forward_t=2, eta=0.0, use_clipped_model_output=True)
+        e = np.abs(out.cpu().numpy() - g[key]).max()
+        print(f"static ddim_p_sample (apf={apf}): {e:.2e}")
+        assert e < 1e-4, key
+    # compose through the reference's method name
+    gc_ = np.load(f"{GOLDEN}/compose_static.npz")
+    dmc = make_compose(25, False, sampler="ddim")
+    tt = torch.full((3,), int(gc_["pmv_t"]), dtype=torch.long, device="cuda")
+    mean, _, _, x0, ec = dmc.p_mean_variance_compose(dev(gc_["pmv_x"]), None, None, tt, obstacle_pts=dev(gc_["clouds"]), compose=True)
+    assert rel(ec.cpu().numpy(), gc_["pmv_ecomb"]) < 5e-5 and np.abs(mean.cpu().numpy() - gc_["pmv_mean"]).max() < 1e-4
+    with pytest.raises(ValueError):
+        dm.p_mean_variance_compose(dev(g["x"]), None, None, t, obstacle_pts=cloud)

@@ -193,3 +193,35 @@ def test_two_contexts_with_different_launch_plans_in_one_process():
     assert a.score_mode() == "fp16x3" and np.array_equal(got, out["ffx"])
     # 8 transformers x 2 blocks: LN + FF1 + FF2 (3 launches) -> 1 forward, d(hg) + FF1-dX + LN-backward (3) -> 1 backward
     assert per_eval_tiles - per_eval_ffx == 16 * 4, (per_eval_tiles, per_eval_ffx)
+
+
+@pytest.mark.parametrize("gemm_mode", ["fp16x3-tkc", "bf16x6", "fp32"])
+def test_score_with_outlier_channel_weights(gemm_mode):
+    """Trained-transformer statistics: 8 output channels of every attn1.to_out and ff.net.2 scaled by 2^9
+    (synth.add_outlier_channels), so the residual stream of every transformer carries a few channels two to three orders of
+    magnitude above the rest -- where one power-of-two scale per operand tensor with a 2^8 full-precision window is most
+    exposed.  Fixture: the imported reference with the same weights (unet2d_h48_outlier.npz).  The fp16x3 plan the bench runs
+    must either stay inside the bar without tripping its range guard, or trip it and return the bf16x6 answer (ramp_score
+    repeats a flagged evaluation at once); it may never return a silently degraded result."""
+    g = np.load(f"{GOLDEN}/unet2d_h48_outlier.npz")
+    gemm_mode, plan = util.split_mode(gemm_mode) if "-" in gemm_mode else (gemm_mode, None)
+    from ramp_amd.models import TemporalUnetInference
+    from ramp_amd.unet import load_numpy_state_dict
+    sd = synth.add_outlier_channels(weights(4, 48, False))
+    m = TemporalUnetInference(n_support_points=48, state_dim=4, max_rows=8, debug_taps=True, gemm_mode=gemm_mode, launch_plan=plan)
+    m = load_numpy_state_dict(m, sd).eval().to("cuda")
+    N = g["x"].shape[0]
+    x = dev(g["x"]); t = torch.from_numpy(g["t"]).cuda()
+    pts = dev(g["cloud"])[None].repeat(N, 1, 1, 1)
+    modes = []
+    for _ in range(3):
+        eps = m(x, t, None, obstacle_pts=pts).cpu().numpy()
+        modes.append(m.score_mode())
+    f = m.forward_no_energy(x, t, obstacle_pts=pts).cpu().numpy()
+    worst = 0.0
+    for k in g.files:
+        if k.startswith("out/") or k.startswith("gout/"):
+            kind, name = k.split("/")
+            worst = max(worst, rel(m.debug_read(kind, name, g[k].shape).cpu().numpy(), g[k]))
+    print(f"outlier weights {gemm_mode}: evaluations ran as {modes}; f {rel(f, g['f']):.2e} eps {rel(eps, g['eps']):.2e} worst tap {worst:.2e}")
+    assert rel(f, g["f"]) < 2e-5 and rel(eps, g["eps"]) < 5e-5 and worst < 5e-5

@@ -105,7 +105,10 @@ def test_schedule_buffers_bitwise(T):
 
 
 def test_scene_encoders_match_golden():
-    """The torch scene encoders (run once per scene above the C ABI) against the reference's latents."""
+    """The scene encoders' parameter containers mean what the reference's modules mean: a torch restatement over them
+    (tests/torch_scene_encoders.py; the product computes the latents in HIP) reproduces the reference's latents, and the
+    containers themselves refuse to compute."""
+    import torch_scene_encoders as tse
     from ramp_amd.models import TemporalUnetInference
     from ramp_amd.unet import load_numpy_state_dict
     g = np.load(f"{GOLDEN}/scene_latents.npz")
@@ -114,11 +117,13 @@ def test_scene_encoders_match_golden():
                                weights(6, 48, True)).eval()
     with torch.no_grad():
         for k in ("2d_6x64", "2d_16x64"):
-            lat = u2.scene_encoder(torch.from_numpy(g["cloud" + k])[None])[0].numpy()
+            lat = tse.encode_2d(u2.scene_encoder, torch.from_numpy(g["cloud" + k])[None])[0].numpy()
             assert rel(lat, g["lat" + k]) < 2e-6
         for k in ("3d_5x50", "3d_20x200"):
-            lat = u3.scene_encoder(torch.from_numpy(g["cloud" + k])[None])[0].numpy()
+            lat = tse.encode_3d(u3.scene_encoder, torch.from_numpy(g["cloud" + k])[None])[0].numpy()
             assert rel(lat, g["lat" + k]) < 2e-6
+        with pytest.raises(RuntimeError):
+            u2.scene_encoder(torch.from_numpy(g["cloud2d_6x64"])[None])
 
 
 def test_synthetic_inputs_are_deterministic():
@@ -313,3 +318,32 @@ def test_philox_replica_known_answer():
     assert abs(float(z.mean())) < 4e-3 and abs(float(z.std()) - 1.0) < 4e-3 and np.isfinite(z).all()
     a, _ = util.philox_normal(5, 3, 8)           # offset = groups of four elements
     assert np.array_equal(a, z[12:20])
+
+
+def test_sampler_helper_methods_against_reference_fixture():
+    """predict_start_from_noise / predict_noise_from_start / q_posterior / deep_repeat_tensor of the sampler classes
+    (diffusion_model_static.py:96-147; the blocked ``repeat`` of the 3-D and dynamic classes, diffusion_model_3d.py:124-142)
+    against outputs of the imported reference, for predict_epsilon True and False (the constructor default)."""
+    from ramp_amd.models import (DynamicGaussianDiffusionModel, GaussianDiffusionModel3d, StaticGaussianDiffusionModel,
+                                 TemporalUnetInference)
+    g = np.load(f"{GOLDEN}/boundary_cases.npz")
+    x, z = torch.from_numpy(g["x"]), torch.from_numpy(g["z"])
+    t = torch.full((3,), int(g["t"]), dtype=torch.long)
+    net = TemporalUnetInference(n_support_points=48, state_dim=4)
+    for pe, tag in ((True, "eps"), (False, "x0")):
+        dm = StaticGaussianDiffusionModel(model=net, n_diffusion_steps=25, predict_epsilon=pe)
+        assert np.array_equal(dm.predict_start_from_noise(x, t, z).numpy(), g[f"psn_{tag}"])
+        assert np.array_equal(dm.predict_noise_from_start(x, t, z).numpy(), g[f"pns_{tag}"])
+        qm, qv, qlv = dm.q_posterior(x_start=z, x_t=x, t=t)
+        assert np.array_equal(qm.numpy(), g[f"q_mean_{tag}"]) and np.array_equal(qv.numpy(), g[f"q_var_{tag}"])
+        assert np.array_equal(qlv.numpy(), g[f"q_logvar_{tag}"])
+    assert StaticGaussianDiffusionModel(model=net, n_diffusion_steps=25).predict_epsilon is False      # the reference's default
+    dm = StaticGaussianDiffusionModel(model=net, n_diffusion_steps=25, predict_epsilon=True)
+    pts = torch.from_numpy(g["cloud"]).unsqueeze(0)
+    xr, tr, trj, obr = dm.deep_repeat_tensor(x, torch.arange(3), z, pts, 2)
+    assert np.array_equal(xr.numpy(), g["rep_x"]) and np.array_equal(tr.numpy(), g["rep_t"])
+    assert np.array_equal(trj.numpy(), g["rep_traj"]) and list(obr.shape) == list(g["rep_obst_shape"])
+    for cls, kw in ((GaussianDiffusionModel3d, {}), (DynamicGaussianDiffusionModel, {})):
+        d3 = cls(model=net, n_diffusion_steps=25, predict_epsilon=True, **kw)
+        xr, tr, _, obr = d3.deep_repeat_tensor(x, torch.arange(3), z, pts, 2)
+        assert torch.equal(xr, torch.cat([x, x])) and tr.tolist() == [0, 1, 2, 0, 1, 2] and obr.shape[0] == 2

@@ -119,6 +119,23 @@ def make_fake_pursuit_env(stop_at=None, log=None):
     return NS(env=env), sphere
 
 
+_TRUTH = {}
+
+
+def oracle64_chain(fixture, S, H, T, w, o3=True):
+    """The float64 oracle's free-running DDPM chain on a chain fixture's inputs (its noise, its scene latent): the truth that both
+    the reference's fp32 chain and the HIP chain are measured against where CFG (w = 5.75) amplifies rounding ~12x per step.
+    Cached per process (H = 64 / T = 50 takes ~20 s of numpy)."""
+    key = (fixture, S, H, T, w)
+    if key not in _TRUTH:
+        from oracle import ramp_oracle as O
+        g = np.load(f"{GOLDEN}/{fixture}.npz")
+        uo = O.UNetOracle(weights(S, H, o3), S, H, obstacle_3d=o3, dtype=np.float64)
+        sm = O.SamplerOracle(uo, T, w, dtype=np.float64, sched=dict(np.load(f"{GOLDEN}/schedule_T{T}.npz")))
+        _TRUTH[key] = sm.ddpm(g["noise"], synth.default_hard_conds(S, H), g["latent"])
+    return _TRUTH[key]
+
+
 def philox_normal(seed, offset, n):
     """Host replica of ramp_philox_normal (include/ramp_hip.h; sampler.hip philox_normal_kernel): returns (z float32 [n],
     r uint32 [4 * ceil(n / 4)]) -- Philox4x32-10 words (exact) and their Box-Muller normals (float32 numpy math, so within a
