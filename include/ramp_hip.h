@@ -65,6 +65,10 @@ typedef struct ramp_launch_plan {
   int32_t tkc_rows;       /* the k = 5 convolutions with C_in, C_out in {32, 64} (the two finest levels' residual blocks, the final block) and
                            * their input gradients on sample-owning waves (tkc.hip) from this many tokens, on levels whose token count
                            * (>= 8) divides 48 or 32: 0 never, 1 always */
+  int32_t tkw_rows;       /* the k = 5 convolutions with C_out in {128, 256, 512} (the residual blocks of the coarse levels) with their
+                           * GroupNorm + Mish fused -- forward: behind the convolution; input gradient: GroupNorm backward folded into the
+                           * operand -- on sample-owning blocks (tkw.hip) from this many tokens, on levels whose token count (>= 3)
+                           * divides 96: 0 never, 1 always */
 } ramp_launch_plan;
 int ramp_get_launch_plan(ramp_ctx* ctx, ramp_launch_plan* out);
 int ramp_set_launch_plan(ramp_ctx* ctx, const ramp_launch_plan* plan);
@@ -349,6 +353,17 @@ int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const floa
  * differentiated): dqkv (M, 768) = d[q | k | v] given dout (M, 256) = d(o) and qkv (M, 768); 4 heads x 64, samples of L tokens; fp16x3 products
  * with exact per-wave operand scales (no call site, no range guard needed). */
 int ramp_op_atb(const float* qkv, const float* dout, float* dqkv, int32_t M, int32_t L, void* stream);
+/* One wide k = 5 convolution on the sample-owning block kernel (tkw.hip) from raw weights W [5][N][K] (tap, c_out, c_in; for the input
+ * gradient the transposed weight, same tap order, dir = -1): Conv1dBlock / ResidualTemporalBlock of the coarse levels (layers.py:280-297, 327-361).
+ *   operand: X (M, K) -- channels [0, K1) from X and [K1, K) from X2 when X2 is given -- or, when gn_c is given, the GroupNorm + Mish input
+ *            gradient GNbwd(X (.) mish'(gn_gamma x^ + gn_beta) gn_gamma) with x^ from gn_c (M, K) and gn_stats (M / L, 8, 2) [mean, rstd];
+ *   result:  Y = conv + bias + resid + resid2 (channels [0, N1) to Y, the rest to Y2 when Y2 is given), or, when Cst is given,
+ *            Cst = conv + bias, stats = its GroupNorm(8) statistics, Y = mish(GN(Cst) gamma + beta) + tbias + resid.
+ * absmax_prev > 0: the operand is scaled from that maximum (delayed scaling); the maximum of this call is returned. */
+int ramp_op_tkw(const float* X, const float* X2, int32_t K1, const float* W, const float* bias, const float* resid, const float* resid2,
+                const float* gn_c, const float* gn_stats, const float* gn_gamma, const float* gn_beta, const float* gamma, const float* beta,
+                const float* tbias, int32_t M, int32_t L, int32_t N, int32_t K, int32_t dir, int32_t N1, float absmax_prev, float* Y, float* Y2,
+                float* Cst, float* stats, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
 /* d(ln1) = d(qkv) Wqkv^T with the LayerNorm-1 backward in its epilogue (tkl.hip, tklb_kernel; the product path's replacement of
  * the d(ln1) GEMM + ln_bwd pair, reference layers_attention_mini.py:132 differentiated): out = add + LNbwd(dqkv W^T; z, ln_g).
  * dqkv (M, 768), W (256, 768) = [Wq | Wk | Wv]^T rows, z / add / out (M, 256), device fp32.  Scaling arguments as ramp_op_tkl. */

@@ -208,6 +208,8 @@ struct ramp_ctx {
                                      // from this many tokens where the level's token count divides 48 or 32 (RAMP_ATK: 0 never, n that threshold)
   int tkc_min_rows = 16384;          // fp16x3 evaluations: the k = 5 convolutions with C_in, C_out in {32, 64} as sample-owning waves (tkc.hip) from this
                                      // many tokens, on levels whose token count (>= 8) divides 48 or 32 (RAMP_TKC: 0 never, n that threshold)
+  int tkw_min_rows = 16384;          // fp16x3 evaluations: the k = 5 convolutions with C_out in {128, 256, 512} with GroupNorm + Mish fused around them as
+                                     // sample-owning blocks (tkw.hip) from this many tokens, on levels whose token count (>= 3) divides 96 (RAMP_TKW)
   struct TkcW { unsigned short* planes; float wsi; };
   std::map<const float*, TkcW> tkc_w;                       // fp32 conv weight [5][N][K] -> its tkc planes
   int share_prefix = 1;              // sampling jobs: rows of one trajectory share the network prefix (RAMP_SHARE_PREFIX=0: off)
@@ -429,6 +431,33 @@ struct Run {
     c->launches++;
     return rc;
   }
+  // a wide k = 5 convolution (C_out in {128, 256, 512}) with its GroupNorm fused (tkw.hip): forward = GroupNorm + Mish behind it (epi),
+  // input gradient = GroupNorm backward folded into the operand (pro); consumes the call site of the tile launch it replaces
+  struct GnPro { const float* c; const float* stats; const float* gamma; const float* beta; };
+  struct GnEpi { float* cst; float* stats; const float* gamma; const float* beta; const float* tbias; float eps; };
+  bool use_tkw(const GemmArgs& a, bool pro, bool epi) const {
+    return c->tkw_min_rows > 0 && a.M >= c->tkw_min_rows && c->gemm_mode == 2 && c->phase == 2 && !c->force_x6 && c->x6_pipe && a.taps == 5 && !a.Amul &&
+           !a.rowbias && a.epi == EPI_LINEAR && a.a_stride == 1 && a.c_rstride == 1 && a.c_roff == 0 &&
+           ((a.shift0 == -2 && a.shift_step == 1) || (a.shift0 == 2 && a.shift_step == -1)) && tkw_applicable(a.M, a.L, a.N, a.K, pro, epi) &&
+           (!a.A2 || !pro) && (!a.C2 || !epi) && has_h3(a.W, a.N, a.K);
+  }
+  int tkw(const GemmArgs& a, const GnPro* pro, const GnEpi* epi) {
+    GemmArgs b = a;
+    const int kind = prep(b);
+    if (kind < 0) return kind;
+    RAMP_REQUIRE(kind == 2, "tkw: weight without fp16 fragment planes (use_tkw must have been checked)");
+    prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * 5, {a.M, a.N, a.K, -7});
+    TkwArgs t; t.M = a.M; t.L = a.L; t.N = a.N; t.K = a.K; t.dir = a.shift_step; t.X = a.A; t.ldx = a.lda; t.X2 = a.A2; t.ldx2 = a.lda2;
+    t.K1 = a.A2 ? a.K1 : a.K; t.W = b.Wx; t.wsi = b.w_scale_inv; t.bias = a.bias; t.resid = a.resid; t.ldr = a.ldr; t.resid2 = a.resid2; t.ldr2 = a.ldr2;
+    t.Y = a.C; t.ldy = a.ldc; t.Y2 = a.C2; t.ldy2 = a.ldc2; t.N1 = a.C2 ? a.N1 : a.N;
+    if (pro) { t.gn_c = pro->c; t.gn_stats = pro->stats; t.gn_gamma = pro->gamma; t.gn_beta = pro->beta; }
+    if (epi) { t.Cst = epi->cst; t.stats = epi->stats; t.gamma = epi->gamma; t.beta = epi->beta; t.tbias = epi->tbias; t.eps = epi->eps; }
+    t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.site = b.site_id; t.range_flag = b.range_flag;
+    int rc = launch_tkw(t, s);
+    prof_post(c, s);
+    c->launches++;
+    return rc;
+  }
   int gemm(const GemmArgs& a) {
     if (const ramp_ctx::TkcW* w = tkc_planes(a)) return tkc(a, *w);
     prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, a.taps});
@@ -603,12 +632,19 @@ int rtb_forward(Run& r, RTB& m, const float* xa, int ca, const float* xb, int cb
   ramp_ctx* c = r.c; const int R = r.R, M = R * m.L;
   const float* tbias = c->time_table + (size_t)t * c->tt_stride + m.tb_off;
   const float* resid;
+  bool fused1 = false;
   if (m.first) {
     LAUNCH(c, r.s, CAT_SMALLCONV, 0, launch_conv_in_fwd(x_first, m.w5in, m.c1.bias, m.w1in, m.res_bias, m.a_c1, c->t_res, R, n_rp, m.L, m.cin, r.s));
     resid = c->t_res;
   } else {
     GemmArgs a = conv5(xa, ca, m.c1.fwd, m.c1.bias, m.a_c1, m.cout, M, m.cout, m.cin, m.L, false);
     if (xb) { a.A2 = xb; a.lda2 = cb; a.K1 = ca; }
+    fused1 = r.use_tkw(a, false, true);
+    if (fused1) {      // conv -> (stash c1, statistics) -> GroupNorm -> Mish -> + time bias = h, one launch (tkw.hip)
+      Run::GnEpi e{m.a_c1, m.a_st1, m.g1, m.b1, tbias, 1e-5f};
+      a.C = m.a_h;
+      CK(r.tkw(a, nullptr, &e));
+    } else
     CK(r.gemm(a));
     if (m.has_res) {
       GemmArgs b = lin(xa, ca, m.res_f, m.res_bias, c->t_res, m.cout, M, m.cout, m.cin);
@@ -621,10 +657,17 @@ int rtb_forward(Run& r, RTB& m, const float* xa, int ca, const float* xb, int cb
   }
   GnArgs g; g.x = m.a_c1; g.gamma = m.g1; g.beta = m.b1; g.tbias = tbias; g.resid = nullptr; g.y = m.a_h;
   g.stats = m.a_st1; g.R = R; g.L = m.L; g.C = m.cout; g.eps = 1e-5f; g.mish = 1;
-  LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_fwd(g, r.s));
-  CK(r.gemm(conv5(m.a_h, m.cout, m.c2.fwd, m.c2.bias, m.a_c2, m.cout, M, m.cout, m.cout, m.L, false)));
+  if (!fused1) LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_fwd(g, r.s));
+  GemmArgs c2a = conv5(m.a_h, m.cout, m.c2.fwd, m.c2.bias, m.a_c2, m.cout, M, m.cout, m.cout, m.L, false);
+  if (r.use_tkw(c2a, false, true)) {      // conv -> (stash c2, statistics) -> GroupNorm -> Mish -> + residual = the block's output
+    Run::GnEpi e{m.a_c2, m.a_st2, m.g2, m.b2, nullptr, 1e-5f};
+    c2a.C = m.a_out; c2a.resid = resid; c2a.ldr = m.cout;
+    CK(r.tkw(c2a, nullptr, &e));
+  } else {
+  CK(r.gemm(c2a));
   g.x = m.a_c2; g.gamma = m.g2; g.beta = m.b2; g.tbias = nullptr; g.resid = resid; g.y = m.a_out; g.stats = m.a_st2;
   LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_fwd(g, r.s));
+  }
   CK(dbg_store(c, "out/" + m.name, m.a_out, (size_t)M * m.cout, r.s));
   return 0;
 }
@@ -636,11 +679,18 @@ int rtb_backward(Run& r, RTB& m, const float* dy, float* dxa, int ca, float* dxb
   CK(dbg_store(c, "gout/" + m.name, dy, (size_t)M * m.cout, r.s));
   GnBwdArgs g; g.dy = dy; g.x = m.a_c2; g.stats = m.a_st2; g.gamma = m.g2; g.beta = m.b2; g.add = nullptr;
   g.dx = c->g_t1; g.R = R; g.L = m.L; g.C = m.cout; g.mish = 1;
+  GemmArgs c2b = conv5(c->g_t1, m.cout, m.c2.bwd, nullptr, c->g_t2, m.cout, M, m.cout, m.cout, m.L, true);
+  if (r.use_tkw(c2b, true, false)) {      // dh = conv2^T(GNbwd(dy mish'; c2)): the GroupNorm backward is the operand staging of the convolution (tkw.hip)
+    Run::GnPro p{m.a_c2, m.a_st2, m.g2, m.b2};
+    c2b.A = dy; c2b.lda = m.cout;
+    CK(r.tkw(c2b, &p, nullptr));
+  } else {
   LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));                                                     // dc2
-  CK(r.gemm(conv5(c->g_t1, m.cout, m.c2.bwd, nullptr, c->g_t2, m.cout, M, m.cout, m.cout, m.L, true)));   // dh
+  CK(r.gemm(c2b));                                                                                       // dh
+  }
   g.dy = c->g_t2; g.x = m.a_c1; g.stats = m.a_st1; g.gamma = m.g1; g.beta = m.b1; g.dx = c->g_t1;
-  LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));                                                     // dc1
   if (m.first) {
+    LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));                                                   // dc1
     LAUNCH(c, r.s, CAT_SMALLCONV, 0, launch_conv_in_bwd(c->g_t1, dy, m.w5in, m.w1in, eps_out, R, m.L, m.cin, r.s));
     return 0;
   }
@@ -655,6 +705,13 @@ int rtb_backward(Run& r, RTB& m, const float* dy, float* dxa, int ca, float* dxb
   a.resid = resid; a.ldr = ldr;
   if (dxb) { a.C2 = dxb; a.ldc2 = cb; a.N1 = ca; }
   if (add2) { RAMP_REQUIRE(dxb == nullptr, "add2 with split output"); a.resid2 = add2; a.ldr2 = ca; }
+  if (r.use_tkw(a, true, false)) {        // dx = conv1^T(GNbwd(dh mish'; c1)) + residual path (+ skip gradient), one launch
+    Run::GnPro p{m.a_c1, m.a_st1, m.g1, m.b1};
+    a.A = c->g_t2; a.lda = m.cout;
+    CK(r.tkw(a, &p, nullptr));
+    return 0;
+  }
+  LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));                                                     // dc1
   CK(r.gemm(a));
   return 0;
 }
@@ -1112,6 +1169,8 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
     if (ke) c->tkl_min_rows = atoi(ke);
     const char* tce = getenv("RAMP_TKC");
     if (tce) c->tkc_min_rows = atoi(tce);
+    const char* twe = getenv("RAMP_TKW");
+    if (twe) c->tkw_min_rows = atoi(twe);
     const char* ate = getenv("RAMP_ATK");
     if (ate) c->atk_min_rows = atoi(ate);
     const char* se = getenv("RAMP_SHARE_PREFIX");
@@ -1138,18 +1197,18 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
 
 int ramp_get_launch_plan(ramp_ctx* c, ramp_launch_plan* out) {
   RAMP_REQUIRE(c && out, "null argument");
-  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, c->tkl_min_rows, c->atk_min_rows, c->tkc_min_rows};
+  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, c->tkl_min_rows, c->atk_min_rows, c->tkc_min_rows, c->tkw_min_rows};
   return 0;
 }
 int ramp_set_launch_plan(ramp_ctx* c, const ramp_launch_plan* p) {
   RAMP_REQUIRE(c && p, "null argument");
-  RAMP_REQUIRE(p->ff_fused_rows >= 0 && p->ffx_rows >= 0 && p->tkl_rows >= 0 && p->atk_rows >= 0 && p->tkc_rows >= 0, "row thresholds must be >= 0");
+  RAMP_REQUIRE(p->ff_fused_rows >= 0 && p->ffx_rows >= 0 && p->tkl_rows >= 0 && p->atk_rows >= 0 && p->tkc_rows >= 0 && p->tkw_rows >= 0, "row thresholds must be >= 0");
   RAMP_REQUIRE(!c->finalized || (p->x6_pipe != 0) == (c->x6_pipe != 0), "x6_pipe is fixed once the weights are packed (ramp_finalize_weights)");
   const bool changed = p->ff_fused_rows != c->ff_fused || p->ffx_rows != c->ffx_min_rows || (p->share_prefix != 0) != (c->share_prefix != 0) ||
                        (p->three_blocks != 0) != (c->three_blocks != 0) || p->tkl_rows != c->tkl_min_rows || p->atk_rows != c->atk_min_rows ||
-                       p->tkc_rows != c->tkc_min_rows;
+                       p->tkc_rows != c->tkc_min_rows || p->tkw_rows != c->tkw_min_rows;
   c->ff_fused = p->ff_fused_rows; c->ffx_min_rows = p->ffx_rows; c->tkl_min_rows = p->tkl_rows; c->share_prefix = p->share_prefix != 0;
-  c->atk_min_rows = p->atk_rows; c->tkc_min_rows = p->tkc_rows;
+  c->atk_min_rows = p->atk_rows; c->tkc_min_rows = p->tkc_rows; c->tkw_min_rows = p->tkw_rows;
   c->three_blocks = p->three_blocks != 0; c->x6_pipe = p->x6_pipe != 0;
   if (changed && c->finalized) {   // other kernels from here on: captured graphs and kept calibrations belong to the old plan
     c->graph_key.clear(); c->r_key.clear();
@@ -1396,6 +1455,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
   CK(init_atk_attributes());
   CK(init_atl_attributes());
   CK(init_tkc_attributes());
+  CK(init_tkw_attributes());
   c->finalized = true;
   return 0;
 }
@@ -2305,6 +2365,44 @@ int ramp_op_abl(const float* qkv, const float* dout, const float* W, const float
   return rc;
 }
 
+int ramp_op_tkw(const float* X, const float* X2, int32_t K1, const float* W, const float* bias, const float* resid, const float* resid2,
+                const float* gn_c, const float* gn_stats, const float* gn_gamma, const float* gn_beta, const float* gamma, const float* beta,
+                const float* tbias, int32_t M, int32_t L, int32_t N, int32_t K, int32_t dir, int32_t N1, float absmax_prev, float* Y, float* Y2,
+                float* Cst, float* stats, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  RAMP_REQUIRE(X && W && Y && M > 0 && L > 0 && N % 32 == 0 && K % 16 == 0, "bad arguments");
+  hipStream_t s = as_stream(stream);
+  DevArena ar;
+  const size_t n = (size_t)5 * N * K;
+  std::vector<float> hw(n);
+  RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, n * 4, hipMemcpyDeviceToHost));
+  float mx = 0.f;
+  for (float v : hw) mx = std::max(mx, std::fabs(v));
+  float sc = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
+  unsigned short* planes = reinterpret_cast<unsigned short*>(ar.alloc(n + 4));
+  float* slots = ar.alloc(4);
+  RAMP_REQUIRE(planes && slots, "hipMalloc failed");
+  CK(init_tkw_attributes());
+  CK(launch_pack_h3(W, planes, (long)5 * N, K, sc, s));
+  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
+  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
+  TkwArgs a; a.M = M; a.L = L; a.N = N; a.K = K; a.dir = dir; a.X = X; a.ldx = X2 ? K1 : K; a.X2 = X2; a.ldx2 = X2 ? K - K1 : 0; a.K1 = X2 ? K1 : K;
+  a.gn_c = gn_c; a.gn_stats = gn_stats; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta; a.W = planes; a.wsi = 1.f / sc; a.bias = bias;
+  a.resid = resid; a.ldr = N; a.resid2 = resid2; a.ldr2 = N; a.Y = Y; a.ldy = Y2 ? N1 : N; a.Y2 = Y2; a.ldy2 = Y2 ? N - N1 : 0; a.N1 = Y2 ? N1 : N;
+  a.Cst = Cst; a.stats = stats; a.gamma = gamma; a.beta = beta; a.tbias = tbias; a.eps = 1e-5f;
+  a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.site = 0; a.range_flag = reinterpret_cast<int*>(slots + 2);
+  int rc = launch_tkw(a, s);
+  hipError_t e = hipStreamSynchronize(s);
+  float back[4] = {0, 0, 0, 0};
+  if (rc == 0 && e == hipSuccess) {
+    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
+    if (absmax_out_host) *absmax_out_host = back[1];
+    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
+  }
+  RAMP_HIP_CHECK(e);
+  return rc;
+}
+
 int ramp_op_tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, int32_t M,
                  float absmax_prev, float* out, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
   RAMP_REQUIRE(dqkv && W && z && ln_g && add && out && M > 0, "bad arguments");
@@ -2392,7 +2490,50 @@ thread_local StressHook* g_stress = nullptr;
 
 int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
                     int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 16, "bad arguments");
+  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 17, "bad arguments");
+  if (mode == 17) {                                    // tkw.hip: wide k = 5 convolution on sample-owning blocks; flags 1: GroupNorm + Mish epilogue (forward),
+                                                       // 2: GroupNorm-backward operand (input gradient), 4: dir = -1, 8: residual, 16: bias
+    hipStream_t sw = as_stream(stream);
+    DevArena arw;
+    const bool epi = flags & 1, pro = flags & 2;
+    RAMP_REQUIRE(taps == 5 && tkw_applicable(M, L, N, K, pro, epi), "mode 17: k = 5, C_out in {128, 256, 512}, L >= 3 dividing 96");
+    float* X = arw.alloc((size_t)M * K); float* Y = arw.alloc((size_t)M * N); float* R = arw.alloc((size_t)M * N); float* Cs = arw.alloc((size_t)M * std::max(N, K));
+    float* W = arw.alloc((size_t)5 * N * K); float* b = arw.alloc(N); float* gm = arw.alloc(std::max(N, K)); float* bt = arw.alloc(std::max(N, K));
+    float* st = arw.alloc((size_t)(M / L) * 16); float* sl = arw.alloc(4); float* tmp = arw.alloc((size_t)M * K);
+    unsigned short* pl = reinterpret_cast<unsigned short*>(arw.alloc((size_t)5 * N * K + 4));
+    RAMP_REQUIRE(X && Y && R && Cs && W && b && gm && bt && st && sl && tmp && pl, "hipMalloc failed");
+    auto fill = [&](float* p, size_t n, unsigned seed, float scv) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sw, p, (long)n, seed, scv); };
+    fill(X, (size_t)M * K, 1u, 1.f); fill(R, (size_t)M * N, 4u, 1.f); fill(W, (size_t)5 * N * K, 2u, 1.f / std::sqrt(5.f * K)); fill(b, N, 5u, 1.f);
+    fill(gm, std::max(N, K), 6u, 1.f); fill(bt, std::max(N, K), 7u, 0.5f); fill(Cs, (size_t)M * std::max(N, K), 8u, 1.f);
+    CK(init_tkw_attributes());
+    float scp = 1.f; { int e; std::frexp(std::ldexp(1.f, 10) * std::sqrt(5.f * K), &e); scp = std::ldexp(1.f, e - 1); }
+    CK(launch_pack_h3(W, pl, (long)5 * N, K, scp, sw));
+    if (pro) {      // statistics of the tensor the backward normalises again (any consistent mean / rstd do)
+      GnArgs g; g.x = Cs; g.gamma = gm; g.beta = bt; g.y = tmp; g.stats = st; g.R = M / L; g.L = L; g.C = K; g.eps = 1e-5f; g.mish = 1;
+      CK(launch_gn_fwd(g, sw));
+    }
+    const float one[4] = {pro ? 8.f : 1.f, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, sw));
+    TkwArgs t; t.M = M; t.L = L; t.N = N; t.K = K; t.dir = (flags & 4) ? -1 : 1; t.X = X; t.ldx = K; t.K1 = K; t.W = pl; t.wsi = 1.f / scp; t.Y = Y; t.ldy = N; t.N1 = N;
+    if ((flags & 16) || epi) t.bias = b;
+    if (flags & 8) { t.resid = R; t.ldr = N; }
+    if (pro) { t.gn_c = Cs; t.gn_stats = st; t.gn_gamma = gm; t.gn_beta = bt; }
+    if (epi) { t.Cst = Cs; t.stats = st; t.gamma = gm; t.beta = bt; t.tbias = b; }
+    t.amax_in = sl; t.amax_out = sl + 1; t.range_flag = reinterpret_cast<int*>(sl + 2);
+    for (int i = 0; i < warmup; ++i) CK(launch_tkw(t, sw));
+    hipEvent_t e0, e1;
+    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
+    RAMP_HIP_CHECK(hipEventRecord(e0, sw));
+    int rcw = 0;
+    for (int i = 0; i < iters && rcw == 0; ++i) { rcw = launch_tkw(t, sw); if (rcw == 0) STRESS(Y, (size_t)M * N, sw); }
+    RAMP_HIP_CHECK(hipEventRecord(e1, sw));
+    RAMP_HIP_CHECK(hipEventSynchronize(e1));
+    float msw = 0.f;
+    RAMP_HIP_CHECK(hipEventElapsedTime(&msw, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = msw * 1e3f / iters;
+    return rcw;
+  }
   if (mode == 15 || mode == 16) {                      // attention backward + d(ln1) + LN1 backward: abl_kernel (15, atl.hip) / atb_kernel + tklb_kernel (16)
     hipStream_t sb = as_stream(stream);
     DevArena arb;

@@ -120,7 +120,8 @@ def test_config3_full_size_against_embedded_reference_trajectories():
     truth = util.oracle64_chain("chain_c3", 6, 48, 25, 5.75)
     e_ref = np.abs(g["chain"] - truth).max(); e_gpu = np.abs(a[:, :2] - truth).max()
     print(f"config 3 full size: embedded golden rows free-running max {err.max():.2e}; vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e} (ratio {e_gpu / e_ref:.2f})")
-    assert err.max() < 5e-4
+    assert err.max() < 1.9e-4 and e_gpu < 1.9e-4 and e_gpu < 3 * e_ref      # measured 1.25e-4 / 1.26e-4 (x 1.5); free-running chains are chaotic:
+                                                                              # the per-step accuracy statement is test_chain3d_... (tests/test_gpu_sampler.py)
     hcb = {k: torch.from_numpy(v).cuda().unsqueeze(0).expand(B, -1) for k, v in synth.default_hard_conds(6, 48).items()}
     tf = []                                                      # EVERY step from the reference's own previous state
     for j in range(25):
@@ -152,8 +153,8 @@ def test_config5_per_gpu_shard_full_size():
     truth = util.oracle64_chain("chain3d_h64_t50", 6, 64, 50, 5.75)
     e_ref = np.abs(g["chain"] - truth).max(); e_gpu = np.abs(a[:, :2] - truth).max()
     print(f"config 5 shard: embedded golden rows free-running max {err.max():.2e} (final {err[-1]:.2e}); vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e} (ratio {e_gpu / e_ref:.2f})")
-    assert err.max() < 2e-3                # same bar as the B = 2 test: T = 50 steps of 12x amplification (the float64 truth is
-                                           # 4.3e-4 from the reference's own fp32 chain, tests/test_gpu_sampler.py)
+    assert err.max() < 9.9e-4 and e_gpu < 8.5e-4 and e_gpu < 3 * e_ref      # measured 6.6e-4 from the reference, 5.6e-4 from the truth (x 1.5); T = 50
+                                                                              # steps of 12x amplification, the reference itself: 4.3e-4 from the truth
     hcb = {k: torch.from_numpy(v).cuda().unsqueeze(0).expand(B, -1) for k, v in synth.default_hard_conds(6, 64).items()}
     tf = []                                                      # EVERY step from the reference's own previous state
     for j in range(50):

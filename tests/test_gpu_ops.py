@@ -688,6 +688,9 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("attention backward on sample-owning waves, L = 24 (atb)", 196608, 256, 256, 1, 24, 13, 0, False),
     ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 48 (abl)", 393216, 256, 768, 1, 48, 15, 0, False),
     ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 12 (abl)", 98304, 256, 768, 1, 12, 15, 0, False),
+    ("wide 5-tap convolution 256x256 + GroupNorm + Mish + residual, L = 6 (tkw)", 49152, 256, 256, 5, 6, 17, 1 | 8, False),
+    ("wide 5-tap convolution 128x128 input gradient with GroupNorm backward, L = 12 (tkw)", 98304, 128, 128, 5, 12, 17, 2 | 4 | 8, False),
+    ("wide 5-tap convolution 256x256 input gradient with GroupNorm backward, L = 6 (tkw)", 49152, 256, 256, 5, 6, 17, 2 | 4, False),
 ]
 
 
@@ -726,3 +729,123 @@ def test_soak_2000_launches_bitwise(name, M, N, K, taps, L, mode, flags):
     _lib.check(_lib.load().ramp_stress_gemm(M, N, K, taps, L, mode, flags, 2000, C.byref(mism), None, None), "ramp_stress_gemm")
     print(f"{name}: 2000 launches, {mism.value} differing words")
     assert mism.value == 0, name
+
+
+def _conv5_f64(A, W, L, direction):
+    """sum_tap shift(A, direction * (tap - 2)) W[tap]^T with zero padding per sample of L tokens; A (M, K), W (5, N, K) float64."""
+    M, K = A.shape
+    A3 = A.reshape(M // L, L, K)
+    out = np.zeros((M, W.shape[1]))
+    for j in range(5):
+        sh = direction * (j - 2)
+        Ash = np.zeros_like(A3)
+        if sh >= 0:
+            Ash[:, :L - sh] = A3[:, sh:]
+        else:
+            Ash[:, -sh:] = A3[:, :L + sh]
+        out += Ash.reshape(M, K) @ W[j].T
+    return out
+
+
+def _mish64(x):
+    return x * np.tanh(np.logaddexp(0.0, x))
+
+
+def _mish_grad64(x):
+    sp = np.logaddexp(0.0, x); th = np.tanh(sp)
+    return th + x * (1.0 / (1.0 + np.exp(-x))) * (1.0 - th * th)
+
+
+TKW_FWD = [   # L, K, N, samples, K1 (operand split) -- Conv1dBlock of the coarse levels: conv k5 -> GroupNorm(8) -> Mish (+ time bias / residual)
+    (6, 256, 256, 37, 0), (12, 128, 128, 19, 0), (6, 128, 256, 16, 0), (12, 64, 128, 8, 0), (6, 512, 128, 21, 256), (8, 256, 256, 13, 0),
+    (16, 128, 128, 7, 0), (3, 256, 256, 33, 0), (24, 64, 128, 5, 0), (48, 32, 128, 3, 0), (6, 256, 128, 16, 128),
+]
+
+
+@pytest.mark.parametrize("L,K,N,R,K1", TKW_FWD)
+@pytest.mark.parametrize("extras", [0, 1, 2])
+def test_tkw_conv_groupnorm_mish_forward(L, K, N, R, K1, extras):
+    """tkw.hip, forward: C = conv5(X) + bias (the stash), its GroupNorm(8) statistics, Y = mish(GN(C) gamma + beta) [+ time bias]
+    [+ residual] in ONE launch of sample-owning blocks, against float64 (layers.py:280-297, 327-361): every coarse-level shape, the
+    concatenated two-source operand of the up blocks, sample counts that leave the last tile partly empty; operand scaled from a
+    recorded maximum, the recorded maximum exact; extras 0: GroupNorm + Mish only, 1: + time bias (first Conv1dBlock), 2: + residual
+    (second)."""
+    g = rng(L * 1000 + K + N + extras)
+    M = L * R
+    X = (g.standard_normal((M, K)) * 1.3).astype(np.float32)
+    W = (g.standard_normal((5, N, K)) / np.sqrt(5 * K)).astype(np.float32)
+    bias = g.standard_normal(N).astype(np.float32) * 0.3
+    gam = (1 + 0.2 * g.standard_normal(N)).astype(np.float32); bet = (0.2 * g.standard_normal(N)).astype(np.float32)
+    tb = g.standard_normal(N).astype(np.float32) if extras == 1 else None
+    res = g.standard_normal((M, N)).astype(np.float32) if extras == 2 else None
+    c = _conv5_f64(X.astype(np.float64), W.astype(np.float64), L, 1) + bias
+    cg = c.reshape(R, L, 8, N // 8)
+    mean = cg.mean(axis=(1, 3)); var = cg.var(axis=(1, 3)); rstd = 1.0 / np.sqrt(var + 1e-5)
+    nrm = ((cg - mean[:, None, :, None]) * rstd[:, None, :, None]).reshape(M, N) * gam + bet
+    y = _mish64(nrm) + (tb if tb is not None else 0.0) + (res if res is not None else 0.0)
+    if K1:
+        xa, xb = dev(np.ascontiguousarray(X[:, :K1])), dev(np.ascontiguousarray(X[:, K1:]))
+    else:
+        xa, xb = dev(X), None
+    Y = torch.full((M, N), float("nan"), device="cuda"); Cs = torch.full((M, N), float("nan"), device="cuda")
+    st = torch.full((R, 8, 2), float("nan"), device="cuda")
+    amax, flag = C.c_float(0.0), C.c_int32(0)
+    prev = float(np.abs(X).max()) * 0.8
+    _lib.check(_lib.load().ramp_op_tkw(_lib.ptr(xa), _lib.ptr(xb), K1, _lib.ptr(dev(W)), _lib.ptr(dev(bias)), _lib.ptr(dev(res)) if res is not None else None,
+                                       None, None, None, None, None, _lib.ptr(dev(gam)), _lib.ptr(dev(bet)), _lib.ptr(dev(tb)) if tb is not None else None,
+                                       M, L, N, K, 1, N, prev, _lib.ptr(Y), None, _lib.ptr(Cs), _lib.ptr(st), C.byref(amax), C.byref(flag), S()), "ramp_op_tkw")
+    assert flag.value == 0 and amax.value == float(np.abs(X).max())
+    ec, ey = rel(Cs.cpu().numpy(), c), rel(Y.cpu().numpy(), y)
+    es = max(rel(st[:, :, 0].cpu().numpy(), mean), rel(st[:, :, 1].cpu().numpy(), rstd))
+    print(f"tkw fwd L={L} {K}->{N} rows={R} extras={extras}: stash {ec:.2e} stats {es:.2e} y {ey:.2e}")
+    assert ec < 3e-6 and es < 3e-6 and ey < 5e-6
+
+
+TKW_BWD = [   # L, K (= C_out of the forward layer), N (= C_in), samples, N1 (output split)
+    (6, 256, 256, 37, 0), (12, 128, 128, 19, 0), (6, 256, 128, 16, 0), (6, 128, 512, 21, 256), (12, 64, 256, 9, 128), (8, 256, 256, 13, 0),
+    (16, 128, 128, 7, 0), (3, 256, 256, 33, 0), (24, 64, 128, 5, 0), (12, 256, 256, 9, 0), (48, 32, 128, 3, 0),
+]
+
+
+@pytest.mark.parametrize("L,K,N,R,N1", TKW_BWD)
+@pytest.mark.parametrize("extras", [0, 3])
+def test_tkw_groupnorm_backward_conv_input_gradient(L, K, N, R, N1, extras):
+    """tkw.hip, input gradient: Y = conv5^T( GNbwd( dY (.) mish'(gamma x^ + beta) gamma ; x^ ) ) [+ resid + resid2] in ONE launch -- the
+    GroupNorm + Mish backward is the operand staging of the convolution -- against float64, incl. the split output of the up blocks'
+    first convolution (the skip gradient) and the recorded maximum of the operand the kernel never materialises."""
+    g = rng(L * 1000 + K + N + extras + 7)
+    M = L * R
+    dy = g.standard_normal((M, K)).astype(np.float32)
+    cst = (g.standard_normal((M, K)) * 1.5 + 0.3).astype(np.float32)
+    gam = (1 + 0.2 * g.standard_normal(K)).astype(np.float32); bet = (0.2 * g.standard_normal(K)).astype(np.float32)
+    W = (g.standard_normal((5, N, K)) / np.sqrt(5 * K)).astype(np.float32)
+    r1 = g.standard_normal((M, N)).astype(np.float32) if extras & 1 else None
+    r2 = g.standard_normal((M, N)).astype(np.float32) if (extras & 2 and not N1) else None
+    cg = cst.astype(np.float64).reshape(R, L, 8, K // 8)
+    mean = cg.mean(axis=(1, 3)); rstd = 1.0 / np.sqrt(cg.var(axis=(1, 3)) + 1e-5)
+    stats = np.stack([mean, rstd], axis=-1).astype(np.float32)
+    m32, r32 = stats[..., 0].astype(np.float64), stats[..., 1].astype(np.float64)          # what the kernel reads
+    h = (cg - m32[:, None, :, None]) * r32[:, None, :, None]
+    gg = gam.astype(np.float64).reshape(8, K // 8); bb = bet.astype(np.float64).reshape(8, K // 8)
+    d = dy.astype(np.float64).reshape(R, L, 8, K // 8) * _mish_grad64(h * gg + bb) * gg
+    m1 = d.mean(axis=(1, 3), keepdims=True); m2 = (d * h).mean(axis=(1, 3), keepdims=True)
+    dc = ((d - m1 - h * m2) * r32[:, None, :, None]).reshape(M, K)
+    y = _conv5_f64(dc, W.astype(np.float64), L, -1) + (r1 if r1 is not None else 0.0) + (r2 if r2 is not None else 0.0)
+    Ya = torch.full((M, N1 or N), float("nan"), device="cuda")
+    Yb = torch.full((M, N - N1), float("nan"), device="cuda") if N1 else None
+    amax, flag = C.c_float(0.0), C.c_int32(0)
+    prev = float(np.abs(dc).max()) * 1.3
+    _lib.check(_lib.load().ramp_op_tkw(_lib.ptr(dev(dy)), None, 0, _lib.ptr(dev(W)), None, _lib.ptr(dev(r1)) if r1 is not None else None,
+                                       _lib.ptr(dev(r2)) if r2 is not None else None, _lib.ptr(dev(cst)), _lib.ptr(dev(stats)), _lib.ptr(dev(gam)), _lib.ptr(dev(bet)),
+                                       None, None, None, M, L, N, K, -1, N1 or N, prev, _lib.ptr(Ya), _lib.ptr(Yb) if N1 else None, None, None,
+                                       C.byref(amax), C.byref(flag), S()), "ramp_op_tkw")
+    got = Ya.cpu().numpy() if not N1 else np.concatenate([Ya.cpu().numpy(), Yb.cpu().numpy()], axis=1)
+    e = rel(got, y)
+    print(f"tkw bwd L={L} {K}->{N} rows={R} extras={extras}: {e:.2e}; recorded max {amax.value:.4f} (float64 {np.abs(dc).max():.4f})")
+    assert flag.value == 0 and abs(amax.value - np.abs(dc).max()) < 2e-5 * np.abs(dc).max()
+    assert e < 5e-6
+    # a stale maximum (the operand grew 2^12-fold since it was recorded) raises the range flag instead of overflowing silently
+    _lib.check(_lib.load().ramp_op_tkw(_lib.ptr(dev(dy)), None, 0, _lib.ptr(dev(W)), None, None, None, _lib.ptr(dev(cst)), _lib.ptr(dev(stats)), _lib.ptr(dev(gam)),
+                                       _lib.ptr(dev(bet)), None, None, None, M, L, N, K, -1, N1 or N, prev / 4096.0, _lib.ptr(Ya), _lib.ptr(Yb) if N1 else None, None, None,
+                                       C.byref(amax), C.byref(flag), S()), "ramp_op_tkw")
+    assert flag.value == 1

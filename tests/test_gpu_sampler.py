@@ -51,7 +51,7 @@ def test_ddpm_chain_free_running(tag, nwn, graph):
     assert np.array_equal(chain[:, :, 47], np.broadcast_to(synth.default_hard_conds(4, 48)[47], chain[:, :, 47].shape))
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "fp16x3-atk", "fp16x3-tkc"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "fp16x3-atk", "fp16x3-tkc", "fp16x3-tkw"])
 def test_ddpm_chain_every_gemm_mode(mode):
     """The same reference chain in each GEMM mode: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bf16x6 (three bf16 planes,
     six products) and fp16x3 (two scaled fp16 planes, three products; its first evaluation calibrates in bf16x6),
@@ -114,7 +114,7 @@ def test_graph_replay_is_bitwise_eager_and_repeatable():
     assert np.array_equal(c1, b1) and np.array_equal(c2, b1)
 
 
-def step_teacher_forced(dm, g, ddim, noise_scale=0.5):
+def step_teacher_forced(dm, g, ddim, noise_scale=0.5, keep=None):
     """Run every loop iteration from the reference's own previous state (teacher forcing): the APF hook is
     discontinuous and stiff, so free-running chains amplify 1e-5 drift (see tests/test_oracle_vs_golden.py)."""
     ref = g["chain"]; n_steps = ref.shape[0] - 1; B = ref.shape[1]
@@ -139,7 +139,22 @@ def step_teacher_forced(dm, g, ddim, noise_scale=0.5):
             noise = torch.stack([dev(ref[j]), dev(g["noise"][j + 1])])
             x, _ = dm._launch(B, noise, hc, cloud, False, [t], apf, [noise_scale], cfg, False)
         worst = max(worst, float(np.abs(x.cpu().numpy() - ref[j + 1]).max()))
+        if keep is not None:
+            keep.append(x.cpu().numpy())
     return worst
+
+
+def assert_as_accurate_as_the_reference(steps, fixture, S, H, T, w, tag):
+    """Per step, from the reference's own previous state: the HIP step may be at most 1.5 x as far from the float64 step as the
+    reference's own fp32 step is (worst step against worst step, and on average).  Unlike a free-running w = 5.75 chain -- where ANY
+    fp32 evaluation lands 0.5 .. 3 x the reference's distance from the truth depending on the rounding realisation (measured: the
+    exact-fp32 MFMA mode 1.9 x, bf16x6 3.1 x, fp16x3 0.9 x on the same H = 64 / T = 50 chain) -- this is not chaotic: one step
+    amplifies rounding once."""
+    e_hip, e_ref = util.step_errors_vs_float64(steps, fixture, S, H, T, w)
+    print(f"{tag}: one step vs float64, worst / mean over steps: HIP {e_hip.max():.2e} / {e_hip.mean():.2e}, reference {e_ref.max():.2e} / {e_ref.mean():.2e}"
+          f" (ratios {e_hip.max() / e_ref.max():.2f} / {e_hip.mean() / e_ref.mean():.2f})")
+    assert e_hip.max() <= 1.5 * e_ref.max(), (tag, e_hip.max(), e_ref.max())
+    assert e_hip.mean() <= 1.5 * e_ref.mean(), (tag, e_hip.mean(), e_ref.mean())
 
 
 def test_ddpm_apf_chain_teacher_forced():
@@ -184,9 +199,11 @@ def test_chain3d_batched_equals_independent_reference_runs():
     u = build_unet(6, 48, True, max_rows=16)
     dm = GaussianDiffusionModel3d(model=u, variance_schedule="exponential", n_diffusion_steps=25,
                                   predict_epsilon=True, use_graph=False).eval().to("cuda")
-    worst = step_teacher_forced(dm, g, ddim=False)
+    steps = []
+    worst = step_teacher_forced(dm, g, ddim=False, keep=steps)
     print(f"3d ddpm teacher-forced worst {worst:.2e}")
     assert worst < 1e-4
+    assert_as_accurate_as_the_reference(steps, "chain3d_ddpm", 6, 48, 25, 5.75, "3d ddpm")
     dm.use_graph = True
     chain, used = run(dm, g, 2)
     assert used == 26 and chain.shape == g["chain"].shape
@@ -194,8 +211,9 @@ def test_chain3d_batched_equals_independent_reference_runs():
     truth = util.oracle64_chain("chain3d_ddpm", 6, 48, 25, 5.75)
     e_ref = np.abs(g["chain"] - truth).max(); e_gpu = np.abs(chain - truth).max()
     print(f"3d ddpm free-running: vs reference {err.max():.2e}; vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e} (ratio {e_gpu / e_ref:.2f})")
-    assert err.max() < 5e-4
-    assert e_gpu < 3 * e_ref
+    # free-running: chaotic (see assert_as_accurate_as_the_reference); measured 2.3e-4 from the truth, 2.8e-4 from the reference
+    assert e_gpu < 3 * e_ref and e_gpu < 3.5e-4
+    assert err.max() < 4.2e-4
 
 
 def make_compose(T, use_apf, sampler=None, use_graph=True, gemm_mode="default"):
@@ -290,9 +308,11 @@ def test_config5_shape_chain_against_reference_fixture():
     u = build_unet(6, 64, True, max_rows=16)
     dm = GaussianDiffusionModel3d(model=u, variance_schedule="exponential", n_diffusion_steps=50,
                                   predict_epsilon=True, use_graph=False).eval().to("cuda")
-    worst = step_teacher_forced(dm, g, ddim=False)
+    steps = []
+    worst = step_teacher_forced(dm, g, ddim=False, keep=steps)
     print(f"config-5 shape teacher-forced worst {worst:.2e}")
     assert worst < 1e-4
+    assert_as_accurate_as_the_reference(steps, "chain3d_h64_t50", 6, 64, 50, 5.75, "config-5 shape")
     dm.use_graph = True
     chain, used = run(dm, g, 2)
     assert used == 51 and chain.shape == g["chain"].shape == (51, 2, 64, 6)
@@ -305,8 +325,10 @@ def test_config5_shape_chain_against_reference_fixture():
         dmm = GaussianDiffusionModel3d(model=um, variance_schedule="exponential", n_diffusion_steps=50, predict_epsilon=True, use_graph=True).eval().to("cuda")
         cm, _ = run(dmm, g, 2)
         print(f"   {mode}: vs reference {np.abs(cm - g['chain']).max():.2e}, vs float64 truth {np.abs(cm - truth).max():.2e}")
-    assert e_gpu < 3 * e_ref              # as close to the truth as the reference itself (measured 6.7e-4 vs 4.3e-4)
-    assert err < 2e-3                     # hence at most e_ref + e_gpu from the reference (measured 1.1e-3)
+    # free-running: chaotic -- the three arithmetic modes land 0.9 x (fp16x3), 1.9 x (exact fp32 MFMA) and 3.1 x (bf16x6) the
+    # reference's own distance from the truth on this chain; bars = measured x 1.5 (3.8e-4 from the truth, 5.8e-4 from the reference)
+    assert e_gpu < 3 * e_ref and e_gpu < 5.7e-4
+    assert err < 8.7e-4
     flag = C.c_int32(-1)
     from ramp_amd import _lib as L
     L.check(L.load().ramp_range_status(u.ctx(), C.byref(flag), L.current_stream()))
@@ -652,8 +674,11 @@ def test_sharded_philox_jobs_reproduce_the_unsharded_job():
     sample index (ramp_sample_params.philox_sample0 / philox_total; ``set_noise_shard``), so N shards draw exactly what ONE
     job of the same total draws: (1) the x_T states (noise + hard conditioning, no network in between) of two shards equal
     the unsharded job's rows BIT FOR BIT, for consecutive jobs on the same stream; (2) a ragged three-way split likewise;
-    (3) the final trajectories agree to rounding (different batch composition changes the delayed power-of-two operand
-    scales and a sample's position inside a wave tile, i.e. summation order -- not the arithmetic contract)."""
+    (3) ONE score evaluation of a shard equals the unsharded job's rows to 5e-6 -- what differs is the batch the delayed
+    power-of-two operand scales were recorded on and a sample's position inside a wave tile, i.e. summation order, not the
+    arithmetic contract; (4) over the 25-step chain that rounding-level difference is amplified like any other (x0 = A x - B e
+    with B up to 4.6e3 at the first steps): the chains agree to 2e-4, as any two fp32-faithful evaluations of this chain do
+    (each sits ~4e-5 from the reference's).  Bitwise sharded == unsharded is NOT claimed."""
     from ramp_amd.models import StaticGaussianDiffusionModel
     g = np.load(f"{GOLDEN}/chain_ddpm_plain.npz")
     H, S, T, B = 48, 4, 25, 48
@@ -678,7 +703,7 @@ def test_sharded_philox_jobs_reproduce_the_unsharded_job():
         assert torch.equal(got[0], ref[0]), job                  # x_T: the same elements of the same stream
         d = float((got - ref).abs().max())
         print(f"job {job}: 2 shards vs 1 job, all {T + 1} states: max {d:.2e}")
-        assert d < 2e-5
+        assert d < 2e-4                                          # two fp32-faithful evaluations of a 25-step chain (each is ~4e-5 from the reference)
         cuts = [(0, 20), (20, 36), (36, 48)]
         got = []
         for (a, b), dm in zip(cuts, rag):
@@ -686,11 +711,25 @@ def test_sharded_philox_jobs_reproduce_the_unsharded_job():
             got.append(dm.run_inference(None, hc, n_samples=b - a, **kw))
         got = torch.cat(got, dim=1)
         assert torch.equal(got[0], ref[0]), job
-        assert float((got - ref).abs().max()) < 2e-5
+        assert float((got - ref).abs().max()) < 2e-4
         assert whole.last_philox == parts[0].last_philox == rag[2].last_philox      # every shard advanced the stream alike
     with pytest.raises(ValueError):
         parts[0].set_noise_shard(40, B)
         parts[0].run_inference(None, hc, n_samples=24, **kw)
+    # one evaluation: the shard's rows against the same rows inside the whole batch
+    x = ref[7]
+    tt = lambda n: torch.full((n,), 17, dtype=torch.long, device="cuda")
+    was = whole.ddim
+    outs = []
+    for dm, xs in ((whole, x), (parts[1], x[24:].contiguous())):
+        dm.ddim = True
+        for _ in range(2):        # (the first p_mean_variance after a job recalibrates: compare steady fp16x3 evaluations)
+            _, _, _, _, ec = dm.p_mean_variance(xs, None, None, tt(xs.shape[0]), obstacle_pts=cloud)
+        dm.ddim = was
+        outs.append(ec)
+    e1 = rel(outs[1].cpu().numpy(), outs[0][24:].cpu().numpy())
+    print(f"one evaluation, shard rows vs the same rows of the whole batch: {e1:.2e}")
+    assert e1 < 5e-6
 
 
 def test_predict_epsilon_false_and_the_public_helpers():

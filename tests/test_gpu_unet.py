@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 CASES = [("2d_h48", 4, 48, False), ("3d_h48", 6, 48, True), ("3d_h64", 6, 64, True), ("2d_h40", 4, 40, False)]
 
 
-@pytest.mark.parametrize("gemm_mode", ["fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "fp16x3-tok", "fp16x3-atk", "fp16x3-tkc", "bf16x6", "fp32"])
+@pytest.mark.parametrize("gemm_mode", ["fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "fp16x3-tok", "fp16x3-atk", "fp16x3-tkc", "fp16x3-tkw", "bf16x6", "fp32"])
 @pytest.mark.parametrize("tag,S,H,o3", CASES)
 def test_score_against_reference_fixture(tag, S, H, o3, gemm_mode):
     """forward_no_energy, eps and every per-module output / output-gradient tap of the reference
@@ -26,7 +26,8 @@ def test_score_against_reference_fixture(tag, S, H, o3, gemm_mode):
     through the launch plan (ramp_set_launch_plan); by default they only take the large ones (the full-size tests);
     "fp16x3-tok" adds the token-owning LN1 -> QKV / out-projection / d(o) kernel (tkl.hip), "fp16x3-atk" the self-attention fused with
     its output projection (atk.hip: sample-owning waves; levels whose token count divides 48 or 32, the others keep the pair) =
-    "fp16x3-tkc" also the narrow k = 5 convolutions on sample-owning waves (tkc.hip) = the bench's plan."""
+    "fp16x3-tkc" also the narrow k = 5 convolutions on sample-owning waves (tkc.hip), "fp16x3-tkw" also the wide ones with their GroupNorm +
+    Mish (forward) / GroupNorm backward (input gradient) fused (tkw.hip: sample-owning blocks, level lengths dividing 96) = the bench's plan."""
     g = np.load(f"{GOLDEN}/unet{tag}.npz")
     gemm_mode, plan = util.split_mode(gemm_mode)
     m = build_unet(S, H, o3, max_rows=8, debug=True, gemm_mode=gemm_mode, launch_plan=plan)
@@ -195,7 +196,7 @@ def test_two_contexts_with_different_launch_plans_in_one_process():
     assert per_eval_tiles - per_eval_ffx == 16 * 4, (per_eval_tiles, per_eval_ffx)
 
 
-@pytest.mark.parametrize("gemm_mode", ["fp16x3-tkc", "bf16x6", "fp32"])
+@pytest.mark.parametrize("gemm_mode", ["fp16x3-tkw", "bf16x6", "fp32"])
 def test_score_with_outlier_channel_weights(gemm_mode):
     """Trained-transformer statistics: 8 output channels of every attn1.to_out and ff.net.2 scaled by 2^9
     (synth.add_outlier_channels), so the residual stream of every transformer carries a few channels two to three orders of

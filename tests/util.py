@@ -29,12 +29,13 @@ def dev(a):
 
 
 PLANS = {   # launch plans the parity tests force onto the small fixtures (ramp_launch_plan; row thresholds: 0 never, 1 always)
-    "": dict(ff_fused_rows=0, ffx_rows=0, tkl_rows=0, atk_rows=0, tkc_rows=0),
-    "fusedff": dict(ff_fused_rows=1, ffx_rows=0, tkl_rows=0, atk_rows=0, tkc_rows=0),   # FF1 -> GEGLU -> FF2 forward in one launch (gemm.hip, ff_fwd_kernel)
-    "ffx": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=0, atk_rows=0, tkc_rows=0),       # token-owning fused feed-forward, forward and backward (ffx.hip)
-    "tok": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=0, tkc_rows=0),       # + token-owning LN1 -> QKV, out-projection, d(o) (tkl.hip): round 3's bench plan
-    "atk": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=0),       # + self-attention fused with the out-projection (atk.hip)
-    "tkc": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=1),       # + the narrow k = 5 convolutions on sample-owning waves (tkc.hip): the bench's plan
+    "": dict(ff_fused_rows=0, ffx_rows=0, tkl_rows=0, atk_rows=0, tkc_rows=0, tkw_rows=0),
+    "fusedff": dict(ff_fused_rows=1, ffx_rows=0, tkl_rows=0, atk_rows=0, tkc_rows=0, tkw_rows=0),   # FF1 -> GEGLU -> FF2 forward in one launch (gemm.hip, ff_fwd_kernel)
+    "ffx": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=0, atk_rows=0, tkc_rows=0, tkw_rows=0),       # token-owning fused feed-forward, forward and backward (ffx.hip)
+    "tok": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=0, tkc_rows=0, tkw_rows=0),       # + token-owning LN1 -> QKV, out-projection, d(o) (tkl.hip): round 3's bench plan
+    "atk": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=0, tkw_rows=0),       # + self-attention fused with the out-projection (atk.hip)
+    "tkc": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=1, tkw_rows=0),       # + the narrow k = 5 convolutions on sample-owning waves (tkc.hip): round 4's bench plan
+    "tkw": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=1, tkw_rows=1),       # + the wide k = 5 convolutions with GroupNorm + Mish fused around them (tkw.hip): the bench's plan
 }
 
 
@@ -122,18 +123,31 @@ def make_fake_pursuit_env(stop_at=None, log=None):
 _TRUTH = {}
 
 
-def oracle64_chain(fixture, S, H, T, w, o3=True):
-    """The float64 oracle's free-running DDPM chain on a chain fixture's inputs (its noise, its scene latent): the truth that both
-    the reference's fp32 chain and the HIP chain are measured against where CFG (w = 5.75) amplifies rounding ~12x per step.
-    Cached per process (H = 64 / T = 50 takes ~20 s of numpy)."""
-    key = (fixture, S, H, T, w)
+def oracle64_chain(fixture, S, H, T, w, o3=True, teacher=False):
+    """The float64 oracle's DDPM chain on a chain fixture's inputs (its noise, its scene latent): the truth that both the
+    reference's fp32 chain and the HIP chain are measured against where CFG (w = 5.75) amplifies rounding ~12x per step.
+    teacher=False: free-running.  teacher=True: state j + 1 is the float64 step FROM THE REFERENCE'S OWN state j (teacher
+    forcing), so |reference[j + 1] - truth[j + 1]| is the reference's rounding error of ONE step -- the yardstick for "as
+    accurate as the reference" that a chaotic free-running chain cannot give.  Cached per process (H = 64 / T = 50: ~20 s)."""
+    key = (fixture, S, H, T, w, teacher)
     if key not in _TRUTH:
         from oracle import ramp_oracle as O
         g = np.load(f"{GOLDEN}/{fixture}.npz")
         uo = O.UNetOracle(weights(S, H, o3), S, H, obstacle_3d=o3, dtype=np.float64)
         sm = O.SamplerOracle(uo, T, w, dtype=np.float64, sched=dict(np.load(f"{GOLDEN}/schedule_T{T}.npz")))
-        _TRUTH[key] = sm.ddpm(g["noise"], synth.default_hard_conds(S, H), g["latent"])
+        _TRUTH[key] = sm.ddpm(g["noise"], synth.default_hard_conds(S, H), g["latent"], teacher=g["chain"] if teacher else None)
     return _TRUTH[key]
+
+
+def step_errors_vs_float64(steps_hip, fixture, S, H, T, w):
+    """(HIP, reference) per-step distances from the float64 step taken from the reference's own previous state.
+    steps_hip[j] = the HIP step from reference state j (what the teacher-forced tests compute)."""
+    g = np.load(f"{GOLDEN}/{fixture}.npz")
+    truth = oracle64_chain(fixture, S, H, T, w, teacher=True)
+    n = g["chain"].shape[0] - 1
+    e_hip = np.array([np.abs(steps_hip[j] - truth[j + 1]).max() for j in range(n)])
+    e_ref = np.array([np.abs(g["chain"][j + 1] - truth[j + 1]).max() for j in range(n)])
+    return e_hip, e_ref
 
 
 def philox_normal(seed, offset, n):
