@@ -289,6 +289,7 @@ struct TkwArgs {
   const float* gamma = nullptr; const float* beta = nullptr; const float* tbias = nullptr; float eps = 1e-5f;
   const float* amax_in = nullptr; float* amax_out = nullptr; int site = 0;
   int* range_flag = nullptr;
+  int ablate = 0;                      // diagnostic (ramp_bench_gemm only; wrong results): 1 no MFMA loop, 2 no operand loads, 4 no epilogue stores
 };
 bool tkw_applicable(int M, int L, int N, int K, int pro, int epi);
 int launch_tkw(const TkwArgs& a, hipStream_t s);

@@ -2519,7 +2519,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     if (flags & 8) { t.resid = R; t.ldr = N; }
     if (pro) { t.gn_c = Cs; t.gn_stats = st; t.gn_gamma = gm; t.gn_beta = bt; }
     if (epi) { t.Cst = Cs; t.stats = st; t.gamma = gm; t.beta = bt; t.tbias = b; }
-    t.amax_in = sl; t.amax_out = sl + 1; t.range_flag = reinterpret_cast<int*>(sl + 2);
+    t.amax_in = sl; t.amax_out = sl + 1; t.range_flag = reinterpret_cast<int*>(sl + 2); t.ablate = (flags >> 8) & 7;
     for (int i = 0; i < warmup; ++i) CK(launch_tkw(t, sw));
     hipEvent_t e0, e1;
     RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));

@@ -32,6 +32,7 @@ namespace {
 
 constexpr int TW_TB = 96;                                   // tokens of a block tile
 constexpr int TW_NT = 3;                                    // = 32-token groups (the B operand's columns)
+constexpr int TW_SCRATCH = 4096 + 4 * 1024;                 // behind the tile: 1 KB per wave + bias / gamma / beta / time bias of <= 256 channels
 
 __device__ __forceinline__ float tw_mish(float x) {         // rowops.hip mish_f: x n / (n + 2), n = e (e + 2), e = exp(x)
   const float e = __builtin_amdgcn_exp2f(fminf(x, 20.f) * 1.44269504088896340736f);
@@ -56,12 +57,12 @@ struct TwGeom { int KC, n_chunks, rows, xrow, n_pass; size_t lds; };
 // MB: 32-channel blocks of a wave per pass (1: N = 128, 2: N = 256 / 512); PRO 1: GroupNorm backward folded into the operand; EPI 1:
 // GroupNorm + Mish behind the convolution
 template <int MB, int PRO, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
-void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_pass, int mulL) {
+__device__ __forceinline__ void tkw_body(const TkwArgs& a, int n_tiles, int kc32, int n_chunks, int n_rows, int n_pass, int mulL) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tok = lane & 31, kh = lane >> 5;
+  const int KC = kc32 << 5;                                 // (a multiple of 32: the plane offset 2 KC keeps 16-byte LDS reads aligned)
   const int XROW = 4 * KC + 16;                             // hi plane (2 KC bytes) | lo plane (2 KC) | 16 bytes (bank spread)
   const int KS = KC >> 4;                                   // k16 steps of a chunk
   char* const scr = smem + (size_t)n_rows * XROW;           // small scratch behind the tile: 4 waves x 1 KB
@@ -77,6 +78,12 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
 
   // the tile's padding rows are zeroed once and never written again
   for (int i = tid; i < n_rows * XROW / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  float* const prm = reinterpret_cast<float*>(scr + 4096);  // EPI 1: [bias | gamma | beta | time bias] of the N <= 256 channels
+  if (EPI == 1) {
+    for (int i = tid; i < a.N; i += 256) {
+      prm[i] = a.bias[i]; prm[256 + i] = a.gamma[i]; prm[512 + i] = a.beta[i]; prm[768 + i] = a.tbias ? a.tbias[i] : 0.f;
+    }
+  }
   __syncthreads();
 
   // B-operand rows of this lane's tokens: token t = 32 tg + tok sits in row t + 2 (t / L) + 2
@@ -117,7 +124,7 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
                 const int t = 24 * wave + it0 + u * RP + sr;
                 const int tk = min(tok0 + t, m_last);
                 const float* src = ch < a.K1 ? a.X + (size_t)tk * a.ldx + ch : a.X2 + (size_t)tk * a.ldx2 + (ch - a.K1);
-                v[u] = (it0 + u * RP < 24) ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                v[u] = (it0 + u * RP < 24 && !(a.ablate & 2)) ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
               }
 #pragma unroll
               for (int u = 0; u < 8; ++u) {
@@ -147,7 +154,7 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
               const int s0 = sm * a.L;                      // the sample's first token in the tile
               const int srow = min(tok0 / a.L + sm, m_last / a.L);                       // the sample (a GroupNorm "row")
               const float mean = a.gn_stats[((size_t)srow * 8 + grp) * 2], rstd = a.gn_stats[((size_t)srow * 8 + grp) * 2 + 1];
-              f32x4 dq[12], xh[12];                         // L / RP <= 12 (L <= 12 at RP = 1; L = 24 needs RP >= 2)
+              f32x4 dq[12];                                 // L / RP <= 12 wave instructions per sample; x^ is recomputed from a second (L1-hot) read of c
               float s1 = 0.f, s2 = 0.f;
 #pragma unroll
               for (int u = 0; u < 12; ++u) {
@@ -160,7 +167,7 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
                   for (int j = 0; j < 4; ++j) {
                     const float h = (cv[j] - mean) * rstd;
                     const float d = dy[j] * tw_mish_grad(h * gam[j] + bet[j]) * gam[j];
-                    xh[u][j] = h; dq[u][j] = d;
+                    dq[u][j] = d;
                     s1 += d; s2 += d * h;
                   }
                 }
@@ -174,9 +181,10 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
               for (int u = 0; u < 12; ++u) {
                 if (u < n_it) {
                   const int t = s0 + u * RP + sr;
+                  const f32x4 cv = *reinterpret_cast<const f32x4*>(a.gn_c + (size_t)min(tok0 + t, m_last) * a.K + ch);
                   f32x4 x;
 #pragma unroll
-                  for (int j = 0; j < 4; ++j) x[j] = live ? (dq[u][j] - m1 - xh[u][j] * m2) * rstd : 0.f;
+                  for (int j = 0; j < 4; ++j) x[j] = live ? (dq[u][j] - m1 - ((cv[j] - mean) * rstd) * m2) * rstd : 0.f;
                   amax = amax4(x, amax);
                   unsigned h0, h1, l0, l1;
                   split4(x * s_in, h0, h1, l0, l1);
@@ -190,52 +198,74 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
         }
         __syncthreads();
 
-        // ---- D^T[c_out][token] += sum_tap W_tap X_shifted^T over this chunk's channels: step = (tap, k16 step); the weight fragments of
-        // step s + 1 are requested before the MFMAs of step s
+        // ---- D^T[c_out][token] += sum_tap W_tap X_shifted^T over this chunk's channels.  Step s = (tap, k16 step) = (s >> log2 KS, s & (KS - 1)).
+        // Software-pipelined by hand: the weight fragments (global / L2 -> registers) and the token fragments (LDS) of step s + 1 are requested
+        // before the MFMAs of step s (two register sets each, two steps unrolled so that every set has a static name); the second wave of the
+        // SIMD (the CU's other block) covers what that leaves exposed
         const int n_steps = 5 * KS;
+        const int lks = 31 - __builtin_clz(KS);
         const size_t wtap = (size_t)(a.N >> 5) * (a.K >> 4) * 2048;                         // bytes of one tap's planes
         const char* wbase = reinterpret_cast<const char*>(a.W) + ((size_t)(nb0 >> 5) * (a.K >> 4) + (size_t)kc * KS) * 2048 + lane * 16;
         const size_t wmb = (size_t)(a.K >> 4) * 2048;                                      // bytes between two 32-row blocks
-        u32x4 ah[MB], al[MB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          ah[mb] = *reinterpret_cast<const u32x4*>(wbase + mb * wmb);
-          al[mb] = *reinterpret_cast<const u32x4*>(wbase + mb * wmb + 1024);
-        }
-        int tap = 0, ks = 0;
-#pragma unroll 1
-        for (int st = 0; st < n_steps; ++st) {
-          int tap_n = tap, ks_n = ks + 1;
-          if (ks_n == KS) { ks_n = 0; tap_n = tap + 1; }
-          if (tap_n == 5) { tap_n = 4; ks_n = KS - 1; }      // (the last step re-requests its own fragments)
-          u32x4 nh[MB], nl[MB];
+        auto load_a = [&](u32x4 (&h)[MB], u32x4 (&l)[MB], int st) __attribute__((always_inline)) {
+          const char* p = wbase + (size_t)(st >> lks) * wtap + (size_t)(st & (KS - 1)) * 2048;
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) {
-            const char* p = wbase + (size_t)tap_n * wtap + (size_t)ks_n * 2048 + mb * wmb;
-            nh[mb] = *reinterpret_cast<const u32x4*>(p);
-            nl[mb] = *reinterpret_cast<const u32x4*>(p + 1024);
+            h[mb] = *reinterpret_cast<const u32x4*>(p + mb * wmb);
+            l[mb] = *reinterpret_cast<const u32x4*>(p + mb * wmb + 1024);
           }
-          const int sh = a.dir * (tap - 2) * XROW + 32 * ks;
-          u32x4 bh[TW_NT], bl[TW_NT];
+        };
+        auto load_b = [&](u32x4 (&h)[TW_NT], u32x4 (&l)[TW_NT], int st) __attribute__((always_inline)) {
+          const int sh = a.dir * ((st >> lks) - 2) * XROW + 32 * (st & (KS - 1));
 #pragma unroll
           for (int tg = 0; tg < TW_NT; ++tg) {
             const char* p = smem + boff[tg] + sh;
-            bh[tg] = *reinterpret_cast<const u32x4*>(p);
-            bl[tg] = *reinterpret_cast<const u32x4*>(p + 2 * KC);
+            h[tg] = *reinterpret_cast<const u32x4*>(p);
+            l[tg] = *reinterpret_cast<const u32x4*>(p + 2 * KC);
           }
+        };
+        // one step: the 9 MB MFMAs of (ua, ub), and between them -- one request after each MFMA, pinned with sched_barrier: left alone hipcc
+        // clusters every load of the loop body in front of its MFMAs, i.e. waits for them at once -- the fragments of step `nxt` into (na, nb)
+        auto step = [&](const u32x4 (&uah)[MB], const u32x4 (&ual)[MB], const u32x4 (&ubh)[TW_NT], const u32x4 (&ubl)[TW_NT],
+                        u32x4 (&nah)[MB], u32x4 (&nal)[MB], u32x4 (&nbh)[TW_NT], u32x4 (&nbl)[TW_NT], int nxt) __attribute__((always_inline)) {
+          const int sc = min(nxt, n_steps - 1);                                            // (the last step re-requests its own fragments)
+          const char* pa = wbase + (size_t)(sc >> lks) * wtap + (size_t)(sc & (KS - 1)) * 2048;
+          const int shn = a.dir * ((sc >> lks) - 2) * XROW + 32 * (sc & (KS - 1));
+          auto issue = [&](int q) __attribute__((always_inline)) {
+            if (q < 2 * MB) {
+              const u32x4 v = *reinterpret_cast<const u32x4*>(pa + (q >> 1) * wmb + (q & 1) * 1024);
+              if (q & 1) nal[q >> 1] = v; else nah[q >> 1] = v;
+            } else if (q < 2 * MB + 2 * TW_NT) {
+              const int r = q - 2 * MB;
+              const u32x4 v = *reinterpret_cast<const u32x4*>(smem + boff[r >> 1] + shn + (r & 1) * 2 * KC);
+              if (r & 1) nbl[r >> 1] = v; else nbh[r >> 1] = v;
+            }
+          };
+          int q = 0;
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int tg = 0; tg < TW_NT; ++tg) {
               f32x16 v = acc[mb][tg];
-              v = mfma16(ah[mb], bl[tg], v);
-              v = mfma16(al[mb], bh[tg], v);
-              v = mfma16(ah[mb], bh[tg], v);
+              v = mfma16(uah[mb], ubl[tg], v);
+              issue(q++);
+              __builtin_amdgcn_sched_barrier(0);
+              v = mfma16(ual[mb], ubh[tg], v);
+              issue(q++);
+              __builtin_amdgcn_sched_barrier(0);
+              v = mfma16(uah[mb], ubh[tg], v);
+              issue(q++);
+              __builtin_amdgcn_sched_barrier(0);
               acc[mb][tg] = v;
             }
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) { ah[mb] = nh[mb]; al[mb] = nl[mb]; }
-          tap = tap_n; ks = ks_n;
+        };
+        u32x4 a0h[MB], a0l[MB], a1h[MB], a1l[MB], b0h[TW_NT], b0l[TW_NT], b1h[TW_NT], b1l[TW_NT];
+        load_a(a0h, a0l, 0); load_b(b0h, b0l, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int st = (a.ablate & 1) ? n_steps : 0; st < n_steps; st += 2) {      // (n_steps = 5 KS is even)
+          step(a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l, st + 1);
+          step(a1h, a1l, b1h, b1l, a0h, a0l, b0h, b0l, st + 2);
         }
       }
 
@@ -256,7 +286,7 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
               if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)tk * a.ldr + n);
               if (a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + (size_t)tk * a.ldr2 + n);
               float* dst = n < a.N1 ? a.Y + (size_t)tk * a.ldy + n : a.Y2 + (size_t)tk * a.ldy2 + (n - a.N1);
-              if (t < a.M) *reinterpret_cast<f32x4*>(dst) = v;
+              if (t < a.M && !(a.ablate & 4)) *reinterpret_cast<f32x4*>(dst) = v;
             }
         }
       } else {
@@ -270,7 +300,7 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + nb0 + 32 * mb + 8 * q + 4 * kh);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(prm + nb0 + 32 * mb + 8 * q + 4 * kh);
 #pragma unroll
             for (int tg = 0; tg < TW_NT; ++tg)
 #pragma unroll
@@ -285,7 +315,7 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (t < a.M) *reinterpret_cast<f32x4*>(a.Cst + (size_t)tk * a.N + nb0 + 32 * mb + 8 * q + 4 * kh) = quad(acc[mb][tg], q);
+              if (t < a.M && !(a.ablate & 4)) *reinterpret_cast<f32x4*>(a.Cst + (size_t)tk * a.N + nb0 + 32 * mb + 8 * q + 4 * kh) = quad(acc[mb][tg], q);
         }
         // group gi of the wave: MB = 2 -> block gi, all 16 registers; MB = 1 -> block 0, registers 8 gi .. 8 gi + 7
         float mean_t[NGW][TW_NT], rstd_t[NGW][TW_NT];
@@ -344,13 +374,13 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
             for (int q = 0; q < 4; ++q) {
               const int n = nb0 + 32 * mb + 8 * q + 4 * kh;
               const int gi = MB == 2 ? mb : (q >> 1);
-              const f32x4 gam = *reinterpret_cast<const f32x4*>(a.gamma + n), bet = *reinterpret_cast<const f32x4*>(a.beta + n);
+              const f32x4 gam = *reinterpret_cast<const f32x4*>(prm + 256 + n), bet = *reinterpret_cast<const f32x4*>(prm + 512 + n);
               f32x4 v;
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = tw_mish((acc[mb][tg][4 * q + j] - mean_t[gi][tg]) * rstd_t[gi][tg] * gam[j] + bet[j]);
-              if (a.tbias) v += *reinterpret_cast<const f32x4*>(a.tbias + n);
+              v += *reinterpret_cast<const f32x4*>(prm + 768 + n);
               if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)tk * a.ldr + n);
-              if (t < a.M) *reinterpret_cast<f32x4*>(a.Y + (size_t)tk * a.ldy + n) = v;
+              if (t < a.M && !(a.ablate & 4)) *reinterpret_cast<f32x4*>(a.Y + (size_t)tk * a.ldy + n) = v;
             }
         }
       }
@@ -362,6 +392,14 @@ void tkw_kernel(TkwArgs a, int n_tiles, int KC, int n_chunks, int n_rows, int n_
   record_amax_block_guarded<true>(a.amax_out, amax, reinterpret_cast<float*>(scr), a.range_flag, s_in, a.site);
 }
 
+// 256 registers per lane everywhere: two blocks share a CU (tw_geometry)
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void tkw_kernel1(TkwArgs a, int n_tiles, int kc32, int n_chunks, int n_rows, int n_pass, int mulL) { tkw_body<1, PRO, EPI>(a, n_tiles, kc32, n_chunks, n_rows, n_pass, mulL); }
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void tkw_kernel2(TkwArgs a, int n_tiles, int kc32, int n_chunks, int n_rows, int n_pass, int mulL) { tkw_body<2, PRO, EPI>(a, n_tiles, kc32, n_chunks, n_rows, n_pass, mulL); }
+
 namespace {
 
 // chunk of operand channels that fits the LDS with the padded tile (at most 256), the tile's rows and bytes
@@ -370,20 +408,23 @@ bool tw_geometry(int L, int N, int K, TwGeom* g) {
   if (!(N == 128 || N == 256 || N == 512)) return false;
   if (K < 32 || K % 32 != 0 || K > 512) return false;
   const int rows = TW_TB + 2 * (TW_TB / L + 1);
-  int KC = std::min(K, 256);
-  while (KC >= 32 && (size_t)rows * (4 * KC + 16) + 4096 > 160 * 1024) KC >>= 1;
+  // chunks of at most 128 operand channels: the tile (rows x (4 KC + 16) bytes) then leaves room for TWO blocks per CU (2 x 78 KB), so that one
+  // block's staging / epilogue (memory latency, GroupNorm arithmetic) runs beside the other's MFMA phase -- with one wave per SIMD nothing overlaps
+  int KC = std::min(K, 128);
+  while (KC > 32 && (size_t)rows * (4 * KC + 16) + TW_SCRATCH > 80 * 1024) KC >>= 1;
   if (KC < 32 || K % KC != 0) return false;
   g->KC = KC; g->n_chunks = K / KC; g->rows = rows; g->xrow = 4 * KC + 16;
   g->n_pass = N == 512 ? 2 : 1;
-  g->lds = (size_t)rows * g->xrow + 4096;
+  g->lds = (size_t)rows * g->xrow + TW_SCRATCH;
   return true;
 }
 
 template <int MB, int PRO, int EPI> int tkw_go(const TkwArgs& a, const TwGeom& g, hipStream_t s) {
   const int n_tiles = (a.M + TW_TB - 1) / TW_TB;
-  const int per_cu = g.lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int per_cu = g.lds * 2 <= 160 * 1024 ? 2 : 1;        // (all variants compile to <= 256 registers: two waves per SIMD)
   const int nb = std::min(n_tiles, per_cu * device_cu_count());
-  hipLaunchKernelGGL((tkw_kernel<MB, PRO, EPI>), dim3(nb), dim3(256), g.lds, s, a, n_tiles, g.KC, g.n_chunks, g.rows, g.n_pass, (65536 + a.L - 1) / a.L);
+  if (MB == 1) hipLaunchKernelGGL((tkw_kernel1<PRO, EPI>), dim3(nb), dim3(256), g.lds, s, a, n_tiles, g.KC >> 5, g.n_chunks, g.rows, g.n_pass, (65536 + a.L - 1) / a.L);
+  else hipLaunchKernelGGL((tkw_kernel2<PRO, EPI>), dim3(nb), dim3(256), g.lds, s, a, n_tiles, g.KC >> 5, g.n_chunks, g.rows, g.n_pass, (65536 + a.L - 1) / a.L);
   RAMP_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -401,7 +442,7 @@ bool tkw_applicable(int M, int L, int N, int K, int pro, int epi) {
     if (K % 32 != 0 || (K / 8) % 4 != 0) return false;
     if (g.n_chunks > 1 && (K / 8) > g.KC) return false;
   }
-  if (epi && N == 512) return false;                                  // (no forward layer has 512 output channels)
+  if (epi && N > 256) return false;                                   // (no forward layer has 512 output channels; the epilogue's parameter table holds 256)
   return true;
 }
 
@@ -430,8 +471,8 @@ int launch_tkw(const TkwArgs& a, hipStream_t s) {
 }
 
 int init_tkw_attributes() {
-#define TW_ATTR(MBV, PROV, EPIV) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tkw_kernel<MBV, PROV, EPIV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-  TW_ATTR(1, 0, 0); TW_ATTR(1, 0, 1); TW_ATTR(1, 1, 0); TW_ATTR(2, 0, 0); TW_ATTR(2, 0, 1); TW_ATTR(2, 1, 0);
+#define TW_ATTR(KV, PROV, EPIV) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&KV<PROV, EPIV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  TW_ATTR(tkw_kernel1, 0, 0); TW_ATTR(tkw_kernel1, 0, 1); TW_ATTR(tkw_kernel1, 1, 0); TW_ATTR(tkw_kernel2, 0, 0); TW_ATTR(tkw_kernel2, 0, 1); TW_ATTR(tkw_kernel2, 1, 0);
 #undef TW_ATTR
   return 0;
 }
