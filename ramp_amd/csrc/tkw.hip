@@ -51,11 +51,13 @@ __device__ __forceinline__ void tw_wave_sync() {
 }
 
 struct TwGeom { int KC, n_chunks, rows, xrow, n_pass; size_t lds; };
+// the GroupNorm-backward scratch holds 8 groups x 8 instructions: groups of a chunk = (KC / 4) / (K / 32) <= 8
+#define LR_GROUPS_OK(KC_, K_) (((KC_) / 4) / ((K_) / 32) <= 8)
 
 }  // namespace
 
-// MB: 32-channel blocks of a wave per pass (1: N = 128, 2: N = 256 / 512); PRO 1: GroupNorm backward folded into the operand; EPI 1:
-// GroupNorm + Mish behind the convolution
+// MB: 32-channel blocks of a wave per pass (1: N = 128, 2: N = 256 / 512); PRO > 0: GroupNorm backward folded into the operand, PRO = the wave
+// instructions of RP rows of one staging pass (3, 4, 6, 8: whole samples); EPI 1: GroupNorm + Mish behind the convolution
 template <int MB, int PRO, int EPI>
 __device__ __forceinline__ void tkw_body(const TkwArgs& a, int n_tiles, int kc32, int n_chunks, int n_rows, int n_pass, int mulL) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -115,7 +117,7 @@ __device__ __forceinline__ void tkw_body(const TkwArgs& a, int n_tiles, int kc32
         if (n_chunks > 1 || pass == 0) {
           // ---- staging: the wave's 24 tokens x KC channels -> (optionally GroupNorm-backward) -> maximum, two scaled fp16 planes -> tile
           const int ch = kc * KC + 4 * sl;                  // this lane's four channels
-          if (PRO == 0) {
+          if constexpr (PRO == 0) {
 #pragma unroll 1
             for (int it0 = 0; it0 < 24; it0 += 8 * RP) {
               f32x4 v[8];
@@ -142,57 +144,88 @@ __device__ __forceinline__ void tkw_body(const TkwArgs& a, int n_tiles, int kc32
             }
           } else {
             // GroupNorm backward on whole samples: d = dy mish'(gamma x^ + beta) gamma; dc = (d - mean(d) - x^ mean(d x^)) rstd, the two
-            // means over the sample's L tokens x (K / 8) channels of the group: this lane's partial sums + shuffles inside the wave
+            // means over the sample's L tokens x (K / 8) channels of the group.  The wave's samples (dealt: wave w takes [w n / 4, (w + 1) n / 4)
+            // of the tile's n) are staged in passes of PRO wave instructions of RP rows = whole samples; a pass's rows are requested at once
+            // (one memory round trip per pass, not per sample).  Each instruction's partial sums are reduced over the group's lanes and
+            // the row slots by shuffles and meet in the wave's scratch, where one lane per (group, sample) adds the sample's instructions
+            constexpr int NW = PRO > 0 ? PRO : 1;           // wave instructions per pass held in registers (a multiple of those per sample)
             const int G4 = (a.K >> 5);                      // lanes of a group: (K / 8) / 4
-            const int grp = ch / (a.K >> 3);
+            const int grp = ch / (a.K >> 3), gl = sl / G4;  // the group among the 8, among this chunk's
+            const int n_gl = LR / G4;
             const f32x4 gam = *reinterpret_cast<const f32x4*>(a.gn_gamma + ch), bet = *reinterpret_cast<const f32x4*>(a.gn_beta + ch);
             const float inv_cnt = 1.f / (float)(a.L * (a.K >> 3));
             const int n_it = a.L / RP;                      // wave instructions per sample (RP | L is checked on the host)
-            const int n_smp = TW_TB / a.L;                  // the tile's samples are dealt to the waves: wave w takes [w n / 4, (w + 1) n / 4)
+            const int spp = NW / n_it;                      // samples per pass
+            const int n_smp = TW_TB / a.L;
+            const int sm_lo = (wave * n_smp) >> 2, sm_hi = ((wave + 1) * n_smp) >> 2;
 #pragma unroll 1
-            for (int sm = (wave * n_smp) >> 2; sm < ((wave + 1) * n_smp) >> 2; ++sm) {
-              const int s0 = sm * a.L;                      // the sample's first token in the tile
-              const int srow = min(tok0 / a.L + sm, m_last / a.L);                       // the sample (a GroupNorm "row")
-              const float mean = a.gn_stats[((size_t)srow * 8 + grp) * 2], rstd = a.gn_stats[((size_t)srow * 8 + grp) * 2 + 1];
-              f32x4 dq[12];                                 // L / RP <= 12 wave instructions per sample; x^ is recomputed from a second (L1-hot) read of c
-              float s1 = 0.f, s2 = 0.f;
+            for (int sm0 = sm_lo; sm0 < sm_hi; sm0 += spp) {
+              const int t_lo = sm0 * a.L;
+              f32x4 dv[NW], hv[NW];
+              float mu[NW], rs[NW];
+              int u_s = 0, u_i = 0;                          // sample of instruction u inside the pass, position inside the sample
 #pragma unroll
-              for (int u = 0; u < 12; ++u) {
-                if (u < n_it) {
-                  const int t = s0 + u * RP + sr;
-                  const int tk = min(tok0 + t, m_last);
-                  const f32x4 dy = *reinterpret_cast<const f32x4*>(a.X + (size_t)tk * a.ldx + ch);
-                  const f32x4 cv = *reinterpret_cast<const f32x4*>(a.gn_c + (size_t)tk * a.K + ch);
+              for (int u = 0; u < NW; ++u) {
+                const int tk = min(tok0 + t_lo + u * RP + sr, m_last);
+                dv[u] = *reinterpret_cast<const f32x4*>(a.X + (size_t)tk * a.ldx + ch);
+                hv[u] = *reinterpret_cast<const f32x4*>(a.gn_c + (size_t)tk * a.K + ch);
+                const int srow = min(tok0 / a.L + sm0 + u_s, m_last / a.L);                // the sample (a GroupNorm "row")
+                mu[u] = a.gn_stats[((size_t)srow * 8 + grp) * 2]; rs[u] = a.gn_stats[((size_t)srow * 8 + grp) * 2 + 1];
+                if (++u_i == n_it) { u_i = 0; ++u_s; }
+              }
+              float p1[NW], p2[NW];
 #pragma unroll
-                  for (int j = 0; j < 4; ++j) {
-                    const float h = (cv[j] - mean) * rstd;
-                    const float d = dy[j] * tw_mish_grad(h * gam[j] + bet[j]) * gam[j];
-                    dq[u][j] = d;
-                    s1 += d; s2 += d * h;
-                  }
+              for (int u = 0; u < NW; ++u) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float h = (hv[u][j] - mu[u]) * rs[u];
+                  const float d = dv[u][j] * tw_mish_grad(h * gam[j] + bet[j]) * gam[j];
+                  hv[u][j] = h; dv[u][j] = d;
+                  s1 += d; s2 += d * h;
                 }
+                p1[u] = s1; p2[u] = s2;
               }
               // over the group's lanes (the low bits of the lane index below G4) and the row slots (the bits from LR up)
-              for (int b = 1; b < G4; b <<= 1) { s1 += __shfl_xor(s1, b); s2 += __shfl_xor(s2, b); }
-              for (int b = LR; b < 64; b <<= 1) { s1 += __shfl_xor(s1, b); s2 += __shfl_xor(s2, b); }
-              const float m1 = s1 * inv_cnt, m2 = s2 * inv_cnt;
-              const bool live = tok0 + s0 < a.M;                                            // (whole samples: M % L == 0)
+              for (int b = 1; b < G4; b <<= 1) {
 #pragma unroll
-              for (int u = 0; u < 12; ++u) {
-                if (u < n_it) {
-                  const int t = s0 + u * RP + sr;
-                  const f32x4 cv = *reinterpret_cast<const f32x4*>(a.gn_c + (size_t)min(tok0 + t, m_last) * a.K + ch);
-                  f32x4 x;
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) x[j] = live ? (dq[u][j] - m1 - ((cv[j] - mean) * rstd) * m2) * rstd : 0.f;
-                  amax = amax4(x, amax);
-                  unsigned h0, h1, l0, l1;
-                  split4(x * s_in, h0, h1, l0, l1);
-                  char* dst = smem + (t + 2 * sm + 2) * XROW + 8 * sl;
-                  *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
-                  *reinterpret_cast<u32x2*>(dst + 2 * KC) = u32x2{l0, l1};
-                }
+                for (int u = 0; u < NW; ++u) { p1[u] += __shfl_xor(p1[u], b); p2[u] += __shfl_xor(p2[u], b); }
               }
+              for (int b = LR; b < 64; b <<= 1) {
+#pragma unroll
+                for (int u = 0; u < NW; ++u) { p1[u] += __shfl_xor(p1[u], b); p2[u] += __shfl_xor(p2[u], b); }
+              }
+              // wave scratch [group of the chunk (<= 8)][instruction (<= 8)][2]: per-instruction sums -> per-sample totals at the sample's first instruction
+              if (sr == 0 && sl == gl * G4) {
+#pragma unroll
+                for (int u = 0; u < NW; ++u) { wscr[(gl * 8 + u) * 2] = p1[u]; wscr[(gl * 8 + u) * 2 + 1] = p2[u]; }
+              }
+              tw_wave_sync();
+              if (lane < n_gl * spp) {
+                const int g2 = lane / spp, s2i = lane - g2 * spp;
+                float t1 = 0.f, t2 = 0.f;
+                for (int i2 = 0; i2 < n_it; ++i2) { t1 += wscr[(g2 * 8 + s2i * n_it + i2) * 2]; t2 += wscr[(g2 * 8 + s2i * n_it + i2) * 2 + 1]; }
+                wscr[(g2 * 8 + s2i * n_it) * 2] = t1 * inv_cnt; wscr[(g2 * 8 + s2i * n_it) * 2 + 1] = t2 * inv_cnt;
+              }
+              tw_wave_sync();
+              u_s = 0; u_i = 0;
+#pragma unroll
+              for (int u = 0; u < NW; ++u) {
+                const float m1 = wscr[(gl * 8 + u_s * n_it) * 2], m2 = wscr[(gl * 8 + u_s * n_it) * 2 + 1];
+                if (++u_i == n_it) { u_i = 0; ++u_s; }
+                const int t = t_lo + u * RP + sr;
+                const bool live = tok0 + t < a.M;                                            // (whole samples: M % L == 0)
+                f32x4 x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = live ? (dv[u][j] - m1 - hv[u][j] * m2) * rs[u] : 0.f;
+                amax = amax4(x, amax);
+                unsigned h0, h1, l0, l1;
+                split4(x * s_in, h0, h1, l0, l1);
+                char* dst = smem + trow(t) * XROW + 8 * sl;
+                *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(dst + 2 * KC) = u32x2{l0, l1};
+              }
+              tw_wave_sync();                               // (the scratch is reused by the next pass)
             }
           }
         }
@@ -419,6 +452,24 @@ bool tw_geometry(int L, int N, int K, TwGeom* g) {
   return true;
 }
 
+// the PRO template value of a GroupNorm-backward launch (0: not covered): the wave instructions of one staging pass = whole samples, at most 8
+int tw_pro_variant(int L, int N, int K) {
+  TwGeom g;
+  if (!tw_geometry(L, N, K, &g)) return 0;
+  const int RP = 64 / (g.KC / 4);
+  if (L % RP != 0 || (K / 8) % 4 != 0) return 0;
+  const int n_it = L / RP, n_smp = TW_TB / L;
+  // every wave's share of samples must be whole passes: shares are floor((w + 1) n / 4) - floor(w n / 4)
+  for (int nw : {6, 8, 4, 3}) {
+    if (nw % n_it != 0) continue;
+    const int spp = nw / n_it;
+    bool ok = true;
+    for (int w = 0; w < 4; ++w) ok &= ((((w + 1) * n_smp) >> 2) - ((w * n_smp) >> 2)) % spp == 0;
+    if (ok && (LR_GROUPS_OK(g.KC, K))) return nw;
+  }
+  return 0;
+}
+
 template <int MB, int PRO, int EPI> int tkw_go(const TkwArgs& a, const TwGeom& g, hipStream_t s) {
   const int n_tiles = (a.M + TW_TB - 1) / TW_TB;
   const int per_cu = g.lds * 2 <= 160 * 1024 ? 2 : 1;        // (all variants compile to <= 256 registers: two waves per SIMD)
@@ -431,15 +482,13 @@ template <int MB, int PRO, int EPI> int tkw_go(const TkwArgs& a, const TwGeom& g
 
 }  // namespace
 
+namespace { int tw_pro_variant(int L, int N, int K); }
 bool tkw_applicable(int M, int L, int N, int K, int pro, int epi) {
   TwGeom g;
   if (!(M > 0 && M % L == 0 && tw_geometry(L, N, K, &g))) return false;
   if ((long)M * std::max(N, K) * 4 >= (1l << 32)) return false;      // (int offsets inside the kernel are size_t; kept as a sanity bound)
-  if (pro) {      // GroupNorm backward: a wave stages whole samples, a sample's rows in whole wave instructions, at most 12 of them
-    const int RP = 64 / (g.KC / 4);
-    if (RP > 1 && L % RP != 0) return false;
-    if (L / std::max(RP, 1) > 12) return false;
-    if (K % 32 != 0 || (K / 8) % 4 != 0) return false;
+  if (pro) {      // GroupNorm backward: a wave stages whole samples, a sample's rows in whole wave instructions, all of them in registers at once
+    if (tw_pro_variant(L, N, K) == 0) return false;
     if (g.n_chunks > 1 && (K / 8) > g.KC) return false;
   }
   if (epi && N > 256) return false;                                   // (no forward layer has 512 output channels; the epilogue's parameter table holds 256)
@@ -464,15 +513,18 @@ int launch_tkw(const TkwArgs& a, hipStream_t s) {
   RAMP_REQUIRE(!ranges_overlap(a.Y, ybytes, a.X, xbytes), "tkw: the output must not overlap the operand");
   RAMP_REQUIRE(!epi || !ranges_overlap(a.Cst, (size_t)a.M * a.N * 4, a.X, xbytes), "tkw: the stash must not overlap the operand");
   const int mbv = a.N == 128 ? 1 : 2;
-#define TW_CASE(MBV, PROV, EPIV) if (mbv == MBV && pro == PROV && epi == EPIV) return tkw_go<MBV, PROV, EPIV>(a, g, s);
-  TW_CASE(1, 0, 0) TW_CASE(1, 0, 1) TW_CASE(1, 1, 0) TW_CASE(2, 0, 0) TW_CASE(2, 0, 1) TW_CASE(2, 1, 0)
+  const int prov = pro ? tw_pro_variant(a.L, a.N, a.K) : 0;
+#define TW_CASE(MBV, PROV, EPIV) if (mbv == MBV && prov == PROV && epi == EPIV) return tkw_go<MBV, PROV, EPIV>(a, g, s);
+  TW_CASE(1, 0, 0) TW_CASE(1, 0, 1) TW_CASE(1, 3, 0) TW_CASE(1, 4, 0) TW_CASE(1, 6, 0) TW_CASE(1, 8, 0)
+  TW_CASE(2, 0, 0) TW_CASE(2, 0, 1) TW_CASE(2, 3, 0) TW_CASE(2, 4, 0) TW_CASE(2, 6, 0) TW_CASE(2, 8, 0)
 #undef TW_CASE
   RAMP_REQUIRE(false, "tkw: variant not built");
 }
 
 int init_tkw_attributes() {
 #define TW_ATTR(KV, PROV, EPIV) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&KV<PROV, EPIV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-  TW_ATTR(tkw_kernel1, 0, 0); TW_ATTR(tkw_kernel1, 0, 1); TW_ATTR(tkw_kernel1, 1, 0); TW_ATTR(tkw_kernel2, 0, 0); TW_ATTR(tkw_kernel2, 0, 1); TW_ATTR(tkw_kernel2, 1, 0);
+  TW_ATTR(tkw_kernel1, 0, 0); TW_ATTR(tkw_kernel1, 0, 1); TW_ATTR(tkw_kernel1, 3, 0); TW_ATTR(tkw_kernel1, 4, 0); TW_ATTR(tkw_kernel1, 6, 0); TW_ATTR(tkw_kernel1, 8, 0);
+  TW_ATTR(tkw_kernel2, 0, 0); TW_ATTR(tkw_kernel2, 0, 1); TW_ATTR(tkw_kernel2, 3, 0); TW_ATTR(tkw_kernel2, 4, 0); TW_ATTR(tkw_kernel2, 6, 0); TW_ATTR(tkw_kernel2, 8, 0);
 #undef TW_ATTR
   return 0;
 }
