@@ -417,14 +417,13 @@ int ramp_range_status(ramp_ctx* ctx, int32_t* flag, void* stream);
 /* fp16x3 mode: bf16x6_only != 0 makes the following ramp_sample calls run every evaluation with the bf16x6 kernels
  * (what the Python wrapper does to repeat a job whose range flag was raised); 0 restores fp16x3. */
 int ramp_set_fallback(ramp_ctx* ctx, int32_t bf16x6_only);
-/* fp16x3 mode: keep the calibration from one ramp_sample to the next (default on).  The first score evaluation of a
- * ramp_sample normally runs the bf16x6 kernels and records every GEMM call site's operand maximum; with reuse on, a job
- * whose predecessor (a) had the same shape and schedule (everything the captured graph depends on), (b) was reported
- * clean by ramp_range_status and (c) was not followed by ramp_score / ramp_replan / ramp_set_scene / ramp_set_fallback
- * instead runs its first evaluation on the fp16x3 kernels too, scaled from the maxima the predecessor's FIRST evaluation
- * recorded (both see x_T ~ N(0, I) at the same timestep), under the same range guard.  Consequence: with identical
- * inputs, call 1 (calibrating) and call 2 (continuing) differ at fp32 rounding level; calls 2, 3, ... are repeatable.
- * on = 0: every job calibrates itself and never depends on an earlier call. */
+/* fp16x3 mode: where a sampling job's FIRST score evaluation takes its operand scales from (every later one: the evaluation before it).
+ * on = 1 (default, round 5): from the context's CANONICAL calibration -- one bf16x6 evaluation that only records the operand maxima, run once,
+ * outside any job, on x ~ N(0, I) drawn with a fixed Philox seed under the job's hard conditions at the job's first timestep (x_T of every job
+ * is a draw of the same distribution; the maxima only pick power-of-two scales with 2^9.9 of head room, and the range guard covers callers whose
+ * x_T is something else).  No job contains a bf16x6 evaluation, the first job on a context costs that one extra evaluation, and a job's result
+ * does not depend on which jobs ran before it (same inputs -> same bits, whatever happened in between).
+ * on = 0: every job calibrates itself in its first evaluation (bf16x6 kernels), ~3 % slower, equally independent of history. */
 int ramp_set_calibration_reuse(ramp_ctx* ctx, int32_t on);
 /* per-launch HIP-event timing (eager, non-graph calls only).  Categories: 0 = MFMA GEMM (linears + k5/k1
  * convs), 1 = attention, 2 = GroupNorm/LayerNorm/GEGLU rows, 3 = stride-2 / first / last convs, 4 = sampler

@@ -174,6 +174,10 @@ struct ramp_ctx {
   // job's first evaluation then reads the maxima the previous job's first evaluation recorded (table 2).  A job becomes
   // the next one's calibration only when ramp_range_status has reported it clean.
   int cal_reuse = 1; bool s_calibrated = false, s_pending = false; std::string s_cal_key, s_pending_key;
+  // Round 5: the calibration a job's first evaluation is scaled from is CANONICAL -- one bf16x6 evaluation, outside the job, on Philox noise of
+  // a fixed seed with the job's hard conditions, at the job's first timestep (table 2) -- instead of whatever the previous job left behind: no
+  // job contains a bf16x6 evaluation, and a job's result does not depend on what ran before it on the context (ramp_set_calibration_reuse)
+  bool c_cal_valid = false; std::string c_cal_key; unsigned long long* c_cal_rec = nullptr;
   // receding-horizon replanning (ramp_replan): fixed device buffers the captured graphs read, the graph of a replan whose
   // first evaluation calibrates ([0]) and of one that continues from the previous replan's operand maxima ([1])
   float *r_noise = nullptr, *r_hist = nullptr, *r_xclean = nullptr, *r_best = nullptr, *r_plen = nullptr, *r_smooth = nullptr,
@@ -195,7 +199,7 @@ struct ramp_ctx {
   // fp16x3 (gemm_mode 2): delayed operand scaling.  phase 0 = bf16x6; 1 = bf16x6 that records max|A| per GEMM call site
   // (the calibration evaluation: the first score evaluation of every ramp_sample); 2 = fp16x3 scaled from the
   // previous evaluation's maxima, recording its own.  obs[2][MAX_SITES] floats, ping-pong by evaluation.
-  static constexpr int MAX_SITES = 1024, N_OBS_TABLES = 3;
+  static constexpr int MAX_SITES = 1024, N_OBS_TABLES = 4;      // 0 / 1: ping-pong by evaluation, 2: the canonical calibration of the sampling jobs, 3: carried from replan to replan
   int phase = 0, site = 0;
   int ff_fused = 150000;             // fp16x3 evaluations: FF1 -> GEGLU -> FF2 as one launch for M >= this many rows
                                      // (RAMP_FF_FUSED: 0 never, 1 always, n > 1 that threshold)
@@ -1212,7 +1216,7 @@ int ramp_set_launch_plan(ramp_ctx* c, const ramp_launch_plan* p) {
   c->three_blocks = p->three_blocks != 0; c->x6_pipe = p->x6_pipe != 0;
   if (changed && c->finalized) {   // other kernels from here on: captured graphs and kept calibrations belong to the old plan
     c->graph_key.clear(); c->r_key.clear();
-    c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false;
+    c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false; c->c_cal_valid = false;
   }
   return 0;
 }
@@ -1538,7 +1542,7 @@ int ramp_set_scene(ramp_ctx* c, const float* latents, int32_t n_variants, const 
   RAMP_HIP_CHECK(hipFree(d));
   c->graph_key.clear();     // scene changed: cross_bias pointer may have moved
   c->r_key.clear();
-  c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false;
+  c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false; c->c_cal_valid = false;
   return rc;
 }
 
@@ -1618,8 +1622,8 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
   }
   for (int j = 0; j < p->n_steps; ++j) {
     if (c->gemm_mode == 2 && !c->force_x6) {
-      // evaluation 0 calibrates (bf16x6 + recorded operand maxima) or, in a job that continues from the previous one
-      // of the same shape, runs fp16x3 scaled from THAT job's evaluation 0 (table 2); evaluation j >= 1 runs fp16x3
+      // evaluation 0 runs fp16x3 scaled from the context's CANONICAL maxima (table 2: canonical_calibration below) -- or, with
+      // ramp_set_calibration_reuse(ctx, 0), calibrates itself (bf16x6 + recorded operand maxima); evaluation j >= 1 runs fp16x3
       // scaled from j - 1
       c->phase = (j == 0 && !steady) ? 1 : 2;
       c->obs_out = c->obs + (j & 1) * ramp_ctx::MAX_SITES;
@@ -1636,8 +1640,6 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
     const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s, shared ? comb : nullptr);
     c->phase = 0;
     CK(rc_score);
-    if (j == 0 && c->gemm_mode == 2 && !c->force_x6)      // what the next job's evaluation 0 is scaled from
-      RAMP_HIP_CHECK(hipMemcpyAsync(c->obs + 2 * ramp_ctx::MAX_SITES, c->obs, ramp_ctx::MAX_SITES * 4, hipMemcpyDeviceToDevice, s));
     CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = shared ? 1 : p->n_rp;
     m.w0 = (float)p->w0; m.w1 = (float)p->w1; m.w0p1 = (float)(1.0 + p->w0);
     m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised; m.predict_x0 = p->predict_x0 != 0;
@@ -1661,6 +1663,34 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
     }
   }
   return 0;
+}
+
+// The calibration every job's first evaluation is scaled from (fp16x3 mode): ONE score evaluation on the bf16x6 kernels that only records the
+// operand maxima of every GEMM call site (phase 1) into table 2, on a CANONICAL input -- x ~ N(0, I) from Philox4x32-10 with a fixed seed, the
+// job's hard conditions applied, at the job's first timestep -- not on anybody's data: x_T of every job is a draw of the same distribution, the
+// recorded maxima only pick power-of-two scales (the operand may then grow 2^9.9-fold before the range guard fires, elements down to 2^-8 of the
+// maximum keep all 22 bits), and the guard covers a caller whose x_T is something else.  Runs eagerly on the job's stream, outside its graph,
+// once per (batch, first timestep, hard-condition layout, scene).
+static int canonical_calibration(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s) {
+  const int B = p->B, H = c->cfg.horizon, S = c->cfg.state_dim;
+  if (!c->c_cal_rec) {
+    float* q; CK(dev_alloc(c, &q, 4)); c->c_cal_rec = reinterpret_cast<unsigned long long*>(q);
+    const unsigned long long rec[2] = {0x52414d5043414cull /* "RAMPCAL" */, 0ull};
+    RAMP_HIP_CHECK(hipMemcpyAsync(c->c_cal_rec, rec, 16, hipMemcpyHostToDevice, s));
+    RAMP_HIP_CHECK(hipStreamSynchronize(s));       // (rec is a stack array)
+  }
+  RAMP_REQUIRE((H * S) % 4 == 0, "H * S must be a multiple of 4");
+  CK(launch_philox_normal(c->s_x, (long)B * H * S, c->c_cal_rec, s));
+  HardConds hc; hc.idx = c->s_hard_idx; hc.val = c->s_hard_val; hc.n = p->n_hard;
+  CK(launch_hard_cond(c->s_x, hc, B, H, S, s));
+  c->phase = 1;
+  c->obs_out = c->obs + 2 * ramp_ctx::MAX_SITES; c->obs_in = c->obs;
+  hipLaunchKernelGGL(zero_words_kernel, dim3(ramp_ctx::MAX_SITES / 256), dim3(256), 0, s, reinterpret_cast<unsigned*>(c->obs_out), ramp_ctx::MAX_SITES);
+  const float comb[3] = {p->n_rp == 2 ? (float)(1.0 + p->w0) : (float)p->w0, p->n_rp == 2 ? -(float)p->w0 : (float)p->w1, (float)(1.0 - p->w0 - p->w1)};
+  const bool shared = p->n_rp > 1 && c->share_prefix;
+  const int rc = score_all(c, c->s_x, B, p->n_rp, p->t[0], nullptr, c->s_eps, s, shared ? comb : nullptr);
+  c->phase = 0;
+  return rc;
 }
 
 int ramp_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
@@ -1740,9 +1770,21 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
     const int ch = chain; put(&ch, 4); put(&c->force_x6, 4); put(&p->noise_mode, 4);
   }
   const bool h3 = c->gemm_mode == 2 && !c->force_x6;
-  steady = h3 && c->cal_reuse && c->s_calibrated && c->s_cal_key == key;
-  c->s_calibrated = false;
-  c->s_pending = h3; if (h3) c->s_pending_key = key;
+  steady = h3 && c->cal_reuse;
+  c->s_calibrated = false; c->s_pending = false;
+  if (steady) {
+    // what the canonical maxima depend on: batch, row variants, first timestep, hard conditions (their values are part of the canonical input)
+    std::string ck;
+    auto putc = [&](const void* q, size_t b) { ck.append(static_cast<const char*>(q), b); };
+    putc(&p->B, 4); putc(&p->n_rp, 4); putc(p->t, 4); putc(&p->n_hard, 4); putc(&p->w0, 8); putc(&p->w1, 8);
+    if (p->n_hard) putc(p->hard_idx_host, 4 * p->n_hard);
+    const int sp = c->share_prefix; putc(&sp, 4);
+    if (!c->c_cal_valid || c->c_cal_key != ck) {
+      CK(canonical_calibration(c, p, s));
+      c->c_cal_valid = true; c->c_cal_key = ck;
+      c->launches = 0;
+    }
+  }
   if (!p->use_graph) {
     CK(sample_body(c, p, s, chain, steady));
   } else {
@@ -1792,10 +1834,10 @@ static int replan_body(ramp_ctx* c, const ramp_replan_params* p, hipStream_t s, 
     const bool last = p->t[j] == 0;                       // the reference's `i == 0`: smoothing + APF on the final step
     if (last) CK(launch_replan_sm(c->s_x, c->r_state, p->sm_window_last, p->sm_dt, p->sm_max_vel, B, H, S, s));
     if (h3) {
-      // delayed-scaling tables: evaluation j writes table j & 1, the last one table 2, which the first evaluation of the
+      // delayed-scaling tables: evaluation j writes table j & 1, the last one table 3, which the first evaluation of the
       // NEXT replan reads: every steady-state replan sees the same pointers, so its graph is captured once
-      const int t_out = j + 1 == p->n_steps ? 2 : (j & 1);
-      const int t_in = j == 0 ? 2 : ((j - 1) & 1);
+      const int t_out = j + 1 == p->n_steps ? 3 : (j & 1);
+      const int t_in = j == 0 ? 3 : ((j - 1) & 1);
       c->phase = (calibrate && j == 0) ? 1 : 2;
       c->obs_out = c->obs + t_out * ramp_ctx::MAX_SITES;
       c->obs_in = c->obs + t_in * ramp_ctx::MAX_SITES;
@@ -1899,7 +1941,7 @@ int ramp_replan(ramp_ctx* c, const ramp_replan_params* p, const ramp_replan_stat
   ReplanState hs{}; hs.n_hist = st->n_hist; hs.stepp = st->stepp; hs.pursuer[0] = st->pursuer[0]; hs.pursuer[1] = st->pursuer[1];
   RAMP_HIP_CHECK(hipMemcpyAsync(c->r_state, &hs, sizeof(hs), hipMemcpyHostToDevice, s));
   c->launches = 0;
-  c->score_calibrated = false; c->s_calibrated = false; c->s_pending = false;
+  c->score_calibrated = false; c->s_calibrated = false; c->s_pending = false;      // (the replans carry their maxima in table 3: the sampling jobs' canonical table 2 survives)
   const bool h3 = c->gemm_mode == 2 && !c->force_x6;
   auto run = [&](bool calibrate) -> int {
     if (!p->use_graph) return replan_body(c, p, s, calibrate);
@@ -1934,7 +1976,7 @@ int ramp_replan(ramp_ctx* c, const ramp_replan_params* p, const ramp_replan_stat
     RAMP_HIP_CHECK(hipGraphLaunch(c->r_graph[which], s));
     return 0;
   };
-  // a one-step replan has no second table to carry its maxima in (its only evaluation reads and clears table 2): it always
+  // a one-step replan has no second table to carry its maxima in (its only evaluation reads and clears table 3): it always
   // calibrates, on the bf16x6 kernels, instead of running fp16x3 from an empty table
   CK(run(h3 && (!c->r_calibrated || p->n_steps == 1)));
   // ---- the one read-back of a replan: {n_free, rank, row} + the range flag
@@ -3058,7 +3100,7 @@ int ramp_profile_read_kernels(ramp_ctx* c, int32_t n, double* ms, double* flops,
 int ramp_set_fallback(ramp_ctx* c, int32_t bf16x6_only) {
   RAMP_REQUIRE(c, "null argument");
   c->force_x6 = bf16x6_only ? 1 : 0;
-  c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false;
+  c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false;      // (the canonical table 2 survives: nothing writes it in a bf16x6 job)
   return 0;
 }
 int ramp_score_mode(ramp_ctx* c, int32_t* mode) {
@@ -3073,17 +3115,12 @@ int ramp_range_status(ramp_ctx* c, int32_t* flag, void* stream) {
     RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
     RAMP_HIP_CHECK(hipMemcpy(flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost));
   }
-  if (c->s_pending) {                                  // a clean fp16x3 job is the next one's calibration
-    c->s_pending = false;
-    c->s_calibrated = *flag == 0;
-    if (c->s_calibrated) c->s_cal_key = c->s_pending_key;
-  }
   return 0;
 }
 int ramp_set_calibration_reuse(ramp_ctx* c, int32_t on) {
   RAMP_REQUIRE(c, "null argument");
   c->cal_reuse = on ? 1 : 0;
-  c->s_calibrated = false; c->s_pending = false;
+  c->s_calibrated = false; c->s_pending = false; c->c_cal_valid = false;
   return 0;
 }
 int ramp_workspace_bytes(ramp_ctx* c, int64_t* bytes) {
