@@ -65,7 +65,7 @@ __device__ __forceinline__ void tkw_body(const TkwArgs& a, int n_tiles, int kc32
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tok = lane & 31, kh = lane >> 5;
   const int KC = kc32 << 5;                                 // (a multiple of 32: the plane offset 2 KC keeps 16-byte LDS reads aligned)
-  const int XROW = 4 * KC + 16;                             // hi plane (2 KC bytes) | lo plane (2 KC) | 16 bytes (bank spread)
+  const int XROW = 4 * KC + 16;                             // hi plane (2 KC bytes) | lo plane (2 KC) | 16 bytes (bank spread; 32 .. 112 measured the same)
   const int KS = KC >> 4;                                   // k16 steps of a chunk
   char* const scr = smem + (size_t)n_rows * XROW;           // small scratch behind the tile: 4 waves x 1 KB
   float* const wscr = reinterpret_cast<float*>(scr + wave * 1024);
