@@ -688,6 +688,38 @@ def gen_replan(m2, sp2):
         arrs[f"env{j}/t"] = np.array(t); arrs[f"env{j}/state"] = st
     arrs["n_cost"] = np.array(len(log_cost)); arrs["n_env"] = np.array(len(log_env))
     arrs["pursuer_final"] = sphere.centers.numpy()
+    # the same run in float64 (model, noise, cloud, default dtype): how far the reference's OWN fp32 run is from exact arithmetic at every
+    # logged batch -- the yardstick for a free-running chain that passes through APF pushes and re-selection
+    n32 = len(log_cost)
+    log_cost64, log_env64 = [], []
+    dataset64, sphere64 = make_fake_pursuit_env(stop_at=K, log=log_env64)
+
+    def logged64(trajs, pts, **kw):
+        out = orig(trajs, pts, **kw)
+        log_cost64.append((trajs.detach().numpy().copy(), -1 if out[4] is None else int(out[4]), out[3].numpy().copy()))
+        return out
+
+    ref_dyn.compute_trajectory_costs = logged64
+    torch.set_default_dtype(torch.float64)
+    m2.double(); dm.double()
+    m2.reset_cache()
+    np.random.seed(23)
+    try:
+        with NoiseInjector([n.double() for n in noises]):
+            quiet(dm.ddim_p_sample_loop, (B, H, S), {k: v.double() for k, v in hard.items()}, context={'dataset': dataset64}, return_chain=True,
+                  traj_normalized=torch.zeros(B, H, S), obstacle_pts=torch.from_numpy(cloud).double())
+    except _StopReplan:
+        pass
+    finally:
+        ref_dyn.compute_trajectory_costs = orig
+        torch.set_default_dtype(torch.float32)
+        m2.float(); dm.float(); m2.reset_cache()
+    assert len(log_cost64) == n32
+    for j, (tr64, idx64, free64) in enumerate(log_cost64):
+        assert tr64.dtype == np.float64 and idx64 == log_cost[j][2] and np.array_equal(free64, log_cost[j][3]), j      # the same plan
+        arrs[f"cost{j}/trajs64"] = tr64
+    print("    replan: the reference's fp32 run vs its float64 twin, per ranked batch:",
+          [f"{np.abs(log_cost[j][0] - log_cost64[j][0]).max():.2e}" for j in range(n32)])
     print(f"    replan: {len(log_cost)} selections (idx {[c[2] for c in log_cost]}, free {[int(c[3].sum()) for c in log_cost]}), "
           f"{len(log_env)} pursuer updates, {used} noise draws")
     save("replan_chain.npz", **arrs)

@@ -260,6 +260,11 @@ struct TkcArgs {
   float* Y = nullptr; int ldy = 0;
   const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;
   int* range_flag = nullptr;
+  // round 5, the GroupNorm(8) + Mish around the convolution fused as in tkw.hip (TkwArgs): PRO -- gn_c (M, K) given: the operand is
+  // GNbwd(X (.) mish'(gn_gamma x^ + gn_beta) gn_gamma), statistics (M / L, 8, 2) in gn_stats; EPI -- Cst (M, N) given: Cst = conv + bias, its statistics
+  // to `stats`, Y = mish(GN(Cst) gamma + beta) + tbias + resid
+  const float* gn_c = nullptr; const float* gn_stats = nullptr; const float* gn_gamma = nullptr; const float* gn_beta = nullptr;
+  float* Cst = nullptr; float* stats = nullptr; const float* gamma = nullptr; const float* beta = nullptr; const float* tbias = nullptr; float eps = 1e-5f;
 };
 bool tkc_applicable(int M, int L, int N, int K, int* ng);
 int launch_tkc(const TkcArgs& a, hipStream_t s);

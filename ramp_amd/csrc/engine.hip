@@ -210,6 +210,8 @@ struct ramp_ctx {
                                      // tokens run the token-owning kernel of tkl.hip (RAMP_TKL: 0 never, n that threshold)
   int atk_min_rows = 40000;          // fp16x3 evaluations: self-attention + output projection as one launch of sample-owning waves (atk.hip)
                                      // from this many tokens where the level's token count divides 48 or 32 (RAMP_ATK: 0 never, n that threshold)
+  int tkc_gn = 3;                    // ... and the GroupNorm + Mish of their Conv1dBlock inside the same launch: bit 0 forward (epilogue), bit 1 input
+                                     // gradient (operand); RAMP_TKC_GN=0: separate gn kernels
   int tkc_min_rows = 16384;          // fp16x3 evaluations: the k = 5 convolutions with C_in, C_out in {32, 64} as sample-owning waves (tkc.hip) from this
                                      // many tokens, on levels whose token count (>= 8) divides 48 or 32 (RAMP_TKC: 0 never, n that threshold)
   int tkw_min_rows = 16384;          // fp16x3 evaluations: the k = 5 convolutions with C_out in {128, 256, 512} with GroupNorm + Mish fused around them as
@@ -422,13 +424,22 @@ struct Run {
     auto it = c->tkc_w.find(a.W);
     return it == c->tkc_w.end() ? nullptr : &it->second;
   }
-  int tkc(const GemmArgs& a, const ramp_ctx::TkcW& w) {
+  struct GnPro { const float* c; const float* stats; const float* gamma; const float* beta; };
+  struct GnEpi { float* cst; float* stats; const float* gamma; const float* beta; const float* tbias; float eps; };
+  // ... with the GroupNorm + Mish of its Conv1dBlock fused like tkw below (pro: the input gradient's operand; epi: behind the forward convolution)
+  const ramp_ctx::TkcW* tkc_gn_planes(const GemmArgs& a, bool epi) const {
+    if (!(c->tkc_gn & (epi ? 1 : 2)) || (epi && a.resid2)) return nullptr;
+    return tkc_planes(a);
+  }
+  int tkc(const GemmArgs& a, const ramp_ctx::TkcW& w, const GnPro* pro = nullptr, const GnEpi* epi = nullptr) {
     RAMP_REQUIRE(c->site < ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
     prof_pre(c, s, CAT_GEMM, 2.0 * a.M * a.N * a.K * a.taps, {a.M, a.N, a.K, -5});
     TkcArgs t; t.M = a.M; t.L = a.L; t.N = a.N; t.K = a.K; t.dir = a.shift_step; t.X = a.A; t.ldx = a.lda; t.W = w.planes; t.bias = a.bias;
     t.resid = a.resid; t.ldr = a.ldr; t.resid2 = a.resid2; t.ldr2 = a.ldr2; t.Y = a.C; t.ldy = a.ldc;
     t.amax_in = c->phase == 2 ? c->obs_in + c->site : nullptr; t.amax_out = c->obs_out + c->site; t.wsi = w.wsi; t.site = c->site;
     t.range_flag = c->phase == 2 ? c->range_flag : nullptr;      // (the guard judges the DELAYED scale; the calibration evaluation runs unscaled)
+    if (pro) { t.gn_c = pro->c; t.gn_stats = pro->stats; t.gn_gamma = pro->gamma; t.gn_beta = pro->beta; }
+    if (epi) { t.Cst = epi->cst; t.stats = epi->stats; t.gamma = epi->gamma; t.beta = epi->beta; t.tbias = epi->tbias; t.eps = epi->eps; }
     c->site++;
     int rc = launch_tkc(t, s);
     prof_post(c, s);
@@ -437,8 +448,6 @@ struct Run {
   }
   // a wide k = 5 convolution (C_out in {128, 256, 512}) with its GroupNorm fused (tkw.hip): forward = GroupNorm + Mish behind it (epi),
   // input gradient = GroupNorm backward folded into the operand (pro); consumes the call site of the tile launch it replaces
-  struct GnPro { const float* c; const float* stats; const float* gamma; const float* beta; };
-  struct GnEpi { float* cst; float* stats; const float* gamma; const float* beta; const float* tbias; float eps; };
   bool use_tkw(const GemmArgs& a, bool pro, bool epi) const {
     return c->tkw_min_rows > 0 && a.M >= c->tkw_min_rows && c->gemm_mode == 2 && c->phase == 2 && !c->force_x6 && c->x6_pipe && a.taps == 5 && !a.Amul &&
            !a.rowbias && a.epi == EPI_LINEAR && a.a_stride == 1 && a.c_rstride == 1 && a.c_roff == 0 &&
@@ -648,6 +657,11 @@ int rtb_forward(Run& r, RTB& m, const float* xa, int ca, const float* xb, int cb
       Run::GnEpi e{m.a_c1, m.a_st1, m.g1, m.b1, tbias, 1e-5f};
       a.C = m.a_h;
       CK(r.tkw(a, nullptr, &e));
+    } else if (const ramp_ctx::TkcW* w = r.tkc_gn_planes(a, true)) {      // the same on the narrow levels (tkc.hip)
+      Run::GnEpi e{m.a_c1, m.a_st1, m.g1, m.b1, tbias, 1e-5f};
+      a.C = m.a_h; a.ldc = m.cout;
+      CK(r.tkc(a, *w, nullptr, &e));
+      fused1 = true;
     } else
     CK(r.gemm(a));
     if (m.has_res) {
@@ -667,6 +681,10 @@ int rtb_forward(Run& r, RTB& m, const float* xa, int ca, const float* xb, int cb
     Run::GnEpi e{m.a_c2, m.a_st2, m.g2, m.b2, nullptr, 1e-5f};
     c2a.C = m.a_out; c2a.resid = resid; c2a.ldr = m.cout;
     CK(r.tkw(c2a, nullptr, &e));
+  } else if (const ramp_ctx::TkcW* w = r.tkc_gn_planes(c2a, true)) {
+    Run::GnEpi e{m.a_c2, m.a_st2, m.g2, m.b2, nullptr, 1e-5f};
+    c2a.C = m.a_out; c2a.resid = resid; c2a.ldr = m.cout;
+    CK(r.tkc(c2a, *w, nullptr, &e));
   } else {
   CK(r.gemm(c2a));
   g.x = m.a_c2; g.gamma = m.g2; g.beta = m.b2; g.tbias = nullptr; g.resid = resid; g.y = m.a_out; g.stats = m.a_st2;
@@ -688,6 +706,10 @@ int rtb_backward(Run& r, RTB& m, const float* dy, float* dxa, int ca, float* dxb
     Run::GnPro p{m.a_c2, m.a_st2, m.g2, m.b2};
     c2b.A = dy; c2b.lda = m.cout;
     CK(r.tkw(c2b, &p, nullptr));
+  } else if (const ramp_ctx::TkcW* w = r.tkc_gn_planes(c2b, false)) {
+    Run::GnPro p{m.a_c2, m.a_st2, m.g2, m.b2};
+    c2b.A = dy; c2b.lda = m.cout;
+    CK(r.tkc(c2b, *w, &p, nullptr));
   } else {
   LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));                                                     // dc2
   CK(r.gemm(c2b));                                                                                       // dh
@@ -714,6 +736,11 @@ int rtb_backward(Run& r, RTB& m, const float* dy, float* dxa, int ca, float* dxb
     a.A = c->g_t2; a.lda = m.cout;
     CK(r.tkw(a, &p, nullptr));
     return 0;
+  }
+  if (const ramp_ctx::TkcW* w = r.tkc_gn_planes(a, false)) {
+    Run::GnPro p{m.a_c1, m.a_st1, m.g1, m.b1};
+    a.A = c->g_t2; a.lda = m.cout;
+    return r.tkc(a, *w, &p, nullptr);
   }
   LAUNCH(c, r.s, CAT_ROW, 0, launch_gn_bwd(g, r.s));                                                     // dc1
   CK(r.gemm(a));
@@ -898,10 +925,17 @@ int net_forward(ramp_ctx* c, const float* x_chunk, int row0, int R, int n_rp, in
     cur = u.a_y; cc = u.C;
   }
   const int H = c->cfg.horizon, C0 = c->cfg.unet_input_dim, M = R * H;
-  CK(r.gemm(conv5(cur, cc, c->final_conv.fwd, c->final_conv.bias, c->a_fin_c, C0, M, C0, C0, H, false)));
+  GemmArgs fa = conv5(cur, cc, c->final_conv.fwd, c->final_conv.bias, c->a_fin_c, C0, M, C0, C0, H, false);
+  if (const ramp_ctx::TkcW* w = r.tkc_gn_planes(fa, true)) {
+    Run::GnEpi e{c->a_fin_c, c->a_fin_st, c->fin_g, c->fin_b, nullptr, 1e-5f};
+    fa.C = c->a_fin_a; fa.ldc = C0;
+    CK(r.tkc(fa, *w, nullptr, &e));
+  } else {
+  CK(r.gemm(fa));
   GnArgs g; g.x = c->a_fin_c; g.gamma = c->fin_g; g.beta = c->fin_b; g.y = c->a_fin_a; g.stats = c->a_fin_st;
   g.R = R; g.L = H; g.C = C0; g.eps = 1e-5f; g.mish = 1;
   LAUNCH(c, s, CAT_ROW, 0, launch_gn_fwd(g, s));
+  }
   LAUNCH(c, s, CAT_SMALLCONV, 0, launch_conv_out(c->a_fin_a, c->fin_w, c->fin_bias, f_out, want_grad ? c->a_fin_da : nullptr, M, c->cfg.state_dim, s));
   return 0;
 }
@@ -913,9 +947,16 @@ int net_backward(ramp_ctx* c, int row0, int R, float* eps_out, hipStream_t s, in
   const int nl = c->cfg.n_levels, H = c->cfg.horizon, C0 = c->cfg.unet_input_dim, M = R * H;
   GnBwdArgs g; g.dy = c->a_fin_da; g.x = c->a_fin_c; g.stats = c->a_fin_st; g.gamma = c->fin_g; g.beta = c->fin_b;
   g.dx = c->g_t1; g.R = R; g.L = H; g.C = C0; g.mish = 1;
-  LAUNCH(c, s, CAT_ROW, 0, launch_gn_bwd(g, s));
   float* d = c->g_a; float* e = c->g_b;
-  CK(r.gemm(conv5(c->g_t1, C0, c->final_conv.bwd, nullptr, d, C0, M, C0, C0, H, true)));
+  GemmArgs fb = conv5(c->g_t1, C0, c->final_conv.bwd, nullptr, d, C0, M, C0, C0, H, true);
+  if (const ramp_ctx::TkcW* w = r.tkc_gn_planes(fb, false)) {
+    Run::GnPro p{c->a_fin_c, c->a_fin_st, c->fin_g, c->fin_b};
+    fb.A = c->a_fin_da; fb.lda = C0;
+    CK(r.tkc(fb, *w, &p, nullptr));
+  } else {
+  LAUNCH(c, s, CAT_ROW, 0, launch_gn_bwd(g, s));
+  CK(r.gemm(fb));
+  }
   for (int k = nl - 2; k >= 0; --k) {
     RTB& a = c->rtbs[2 * nl + 2 + 2 * k]; RTB& b = c->rtbs[2 * nl + 3 + 2 * k]; ST& st = c->sts[nl + 1 + k];
     Resample& u = c->ups[k];
@@ -1173,6 +1214,7 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
     if (ke) c->tkl_min_rows = atoi(ke);
     const char* tce = getenv("RAMP_TKC");
     if (tce) c->tkc_min_rows = atoi(tce);
+    if (const char* tg = getenv("RAMP_TKC_GN")) c->tkc_gn = atoi(tg) & 3;
     const char* twe = getenv("RAMP_TKW");
     if (twe) c->tkw_min_rows = atoi(twe);
     const char* ate = getenv("RAMP_ATK");
@@ -2415,6 +2457,36 @@ int ramp_op_tkw(const float* X, const float* X2, int32_t K1, const float* W, con
   hipStream_t s = as_stream(stream);
   DevArena ar;
   const size_t n = (size_t)5 * N * K;
+  if (N <= 64 && K <= 64) {      // the narrow layers: the same fusion on sample-owning WAVES (tkc.hip)
+    RAMP_REQUIRE(!X2 && !Y2 && tkc_applicable(M, L, N, K, nullptr), "narrow fused convolution: C_in, C_out in {32, 64}, L >= 8 dividing 48 or 32, one operand, one output");
+    std::vector<float> hw(n);
+    RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, n * 4, hipMemcpyDeviceToHost));
+    float mx = 0.f; for (float v : hw) mx = std::max(mx, std::fabs(v));
+    float sc = 1.f;
+    if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
+    unsigned short* pl = reinterpret_cast<unsigned short*>(ar.alloc(tkc_packed_halves(N, K) / 2 + 4));
+    float* sl = ar.alloc(4);
+    RAMP_REQUIRE(pl && sl, "hipMalloc failed");
+    CK(init_tkc_attributes());
+    CK(tkc_pack(W, N, K, sc, pl, s));
+    const float v[4] = {absmax_prev, 0.f, 0.f, 0.f};
+    RAMP_HIP_CHECK(hipMemcpyAsync(sl, v, 16, hipMemcpyHostToDevice, s));
+    TkcArgs t; t.M = M; t.L = L; t.N = N; t.K = K; t.dir = dir; t.X = X; t.ldx = K; t.W = pl; t.bias = bias; t.resid = resid; t.ldr = N;
+    t.resid2 = resid2; t.ldr2 = N; t.Y = Y; t.ldy = N; t.amax_in = absmax_prev > 0.f ? sl : nullptr; t.amax_out = sl + 1; t.wsi = 1.f / sc;
+    t.range_flag = reinterpret_cast<int*>(sl + 2);
+    t.gn_c = gn_c; t.gn_stats = gn_stats; t.gn_gamma = gn_gamma; t.gn_beta = gn_beta;
+    t.Cst = Cst; t.stats = stats; t.gamma = gamma; t.beta = beta; t.tbias = tbias; t.eps = 1e-5f;
+    int rc5 = launch_tkc(t, s);
+    hipError_t e5 = hipStreamSynchronize(s);
+    float back[4] = {0, 0, 0, 0};
+    if (rc5 == 0 && e5 == hipSuccess) {
+      e5 = hipMemcpy(back, sl, sizeof(back), hipMemcpyDeviceToHost);
+      if (absmax_out_host) *absmax_out_host = back[1];
+      if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
+    }
+    RAMP_HIP_CHECK(e5);
+    return rc5;
+  }
   std::vector<float> hw(n);
   RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, n * 4, hipMemcpyDeviceToHost));
   float mx = 0.f;
@@ -2661,23 +2733,33 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     *avg_us = msb * 1e3f / iters;
     return rcb;
   }
-  if (mode == 12) {                                    // tkc.hip: k = 5 convolution with C_in, C_out in {32, 64} on sample-owning waves; flags 1 bias, 2 residual, 4 input gradient
+  if (mode == 12) {                                    // tkc.hip: k = 5 convolution with C_in, C_out in {32, 64} on sample-owning waves; flags 1 bias, 2 residual, 4 input gradient,
+                                                       // 8 GroupNorm + Mish epilogue, 16 GroupNorm-backward operand
     hipStream_t sc = as_stream(stream);
     DevArena arc;
     RAMP_REQUIRE(taps == 5 && tkc_applicable(M, L, N, K, nullptr), "mode 12: k = 5, C in {32, 64}, L >= 8 dividing 48 or 32");
     float* X = arc.alloc((size_t)M * K); float* Y = arc.alloc((size_t)M * N); float* R = arc.alloc((size_t)M * N); float* W = arc.alloc((size_t)5 * N * K);
     float* b = arc.alloc(N); float* sl = arc.alloc(4);
+    float* Cs = arc.alloc((size_t)M * 64); float* gm = arc.alloc(64); float* bt = arc.alloc(64); float* st = arc.alloc((size_t)(M / L) * 16);
     unsigned short* pl = reinterpret_cast<unsigned short*>(arc.alloc(tkc_packed_halves(N, K) / 2 + 4));
-    RAMP_REQUIRE(X && Y && R && W && b && sl && pl, "hipMalloc failed");
+    RAMP_REQUIRE(X && Y && R && W && b && sl && pl && Cs && gm && bt && st, "hipMalloc failed");
     auto fill = [&](float* p, size_t n, unsigned seed, float scv) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sc, p, (long)n, seed, scv); };
     fill(X, (size_t)M * K, 1u, 1.f); fill(R, (size_t)M * N, 4u, 1.f); fill(W, (size_t)5 * N * K, 2u, 1.f / 16.f); fill(b, N, 5u, 1.f);
     CK(init_tkc_attributes());
     CK(tkc_pack(W, N, K, 16384.f, pl, sc));
-    const float one[4] = {1.f, 0.f, 0.f, 0.f};
+    const float one[4] = {(flags & 16) ? 8.f : 1.f, 0.f, 0.f, 0.f};
     RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, sc));
     TkcArgs t; t.M = M; t.L = L; t.N = N; t.K = K; t.dir = (flags & 4) ? -1 : 1; t.X = X; t.ldx = K; t.W = pl; t.Y = Y; t.ldy = N;
     if (flags & 1) t.bias = b;
     if (flags & 2) { t.resid = R; t.ldr = N; }
+    if (flags & 24) { fill(gm, 64, 6u, 1.f); fill(bt, 64, 7u, 0.5f); fill(Cs, (size_t)M * 64, 8u, 1.f); }
+    if (flags & 16) {
+      GnArgs g; g.x = Cs; g.gamma = gm; g.beta = bt; g.y = Y; g.stats = st; g.R = M / L; g.L = L; g.C = K; g.eps = 1e-5f; g.mish = 1;
+      RAMP_REQUIRE(N >= K, "mode 12 with flag 16: the scratch of the statistics pass is the output");
+      CK(launch_gn_fwd(g, sc));
+      t.gn_c = Cs; t.gn_stats = st; t.gn_gamma = gm; t.gn_beta = bt;
+    }
+    if (flags & 8) { t.bias = b; t.Cst = Cs; t.stats = st; t.gamma = gm; t.beta = bt; t.tbias = b; }
     t.amax_in = sl; t.amax_out = sl + 1; t.wsi = 1.f / 16384.f; t.range_flag = reinterpret_cast<int*>(sl + 2);
     for (int i = 0; i < warmup; ++i) CK(launch_tkc(t, sc));
     hipEvent_t e0, e1;

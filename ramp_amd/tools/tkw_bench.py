@@ -27,3 +27,13 @@ for L, K, N in ((6, 256, 256), (6, 128, 256), (6, 512, 128), (6, 128, 128), (12,
     f = t(M, N, K, L, 17, 1 | 8) if N != 512 else float("nan")
     g = t(M, N, K, L, 17, 2 | 4 | 8) if K <= 256 else float("nan")
     print(f"L={L:2d} {K:3d}->{N:3d} M={M:7d}     {a:10.1f} {b:10.1f} {f:11.1f} {g:10.1f}   {fl / a / 1e6:6.1f} / {fl / f / 1e6:6.1f} / {fl / g / 1e6:6.1f}", flush=True)
+
+# the narrow levels: tkc.hip plain (bias + residual) / with the GroupNorm + Mish epilogue / input gradient with the GroupNorm-backward operand
+print(f"\n{'shape':28s} {'tkc plain':>10s} {'tkc+GN fwd':>11s} {'tkc bwd':>10s} {'tkc GNbwd':>10s}")
+for L, K, N in ((48, 32, 32), (24, 32, 64), (24, 64, 64)):
+    M = R * L
+    a = t(M, N, K, L, 12, 1 | 2)
+    f = t(M, N, K, L, 12, 2 | 8)
+    b = t(M, N, K, L, 12, 4 | 2)
+    g = t(M, N, K, L, 12, 4 | 16 | 2) if N >= K else float("nan")
+    print(f"L={L:2d} {K:3d}->{N:3d} M={M:7d}     {a:10.1f} {f:11.1f} {b:10.1f} {g:10.1f}", flush=True)

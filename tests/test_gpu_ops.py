@@ -685,6 +685,8 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("self-attention fused with the out-projection, L = 6 (atk)", 49152, 256, 256, 1, 6, 10, 1, False),
     ("sample-owning 5-tap convolution 64x64 with bias and residual, L = 24 (tkc)", 196608, 64, 64, 5, 24, 12, 3, False),
     ("sample-owning 5-tap convolution 32x32 input gradient, L = 48 (tkc)", 393216, 32, 32, 5, 48, 12, 4, False),
+    ("sample-owning 5-tap convolution 64x64 with GroupNorm + Mish and residual, L = 24 (tkc)", 196608, 64, 64, 5, 24, 12, 2 | 8, False),
+    ("sample-owning 5-tap convolution 32x32 input gradient with GroupNorm backward, L = 48 (tkc)", 393216, 32, 32, 5, 48, 12, 4 | 16 | 2, False),
     ("attention backward on sample-owning waves, L = 24 (atb)", 196608, 256, 256, 1, 24, 13, 0, False),
     ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 48 (abl)", 393216, 256, 768, 1, 48, 15, 0, False),
     ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 12 (abl)", 98304, 256, 768, 1, 12, 15, 0, False),
@@ -759,6 +761,9 @@ def _mish_grad64(x):
 TKW_FWD = [   # L, K, N, samples, K1 (operand split) -- Conv1dBlock of the coarse levels: conv k5 -> GroupNorm(8) -> Mish (+ time bias / residual)
     (6, 256, 256, 37, 0), (12, 128, 128, 19, 0), (6, 128, 256, 16, 0), (12, 64, 128, 8, 0), (6, 512, 128, 21, 256), (8, 256, 256, 13, 0),
     (16, 128, 128, 7, 0), (3, 256, 256, 33, 0), (24, 64, 128, 5, 0), (48, 32, 128, 3, 0), (6, 256, 128, 16, 128),
+    # the narrow levels: the same fusion on sample-owning waves (tkc.hip), wave tiles of 48 and of 32 tokens, partly empty last tiles
+    (48, 32, 32, 7, 0), (24, 32, 64, 9, 0), (24, 64, 64, 11, 0), (48, 64, 32, 3, 0), (16, 32, 32, 5, 0), (8, 64, 64, 13, 0), (12, 64, 64, 9, 0),
+    (32, 32, 64, 3, 0), (48, 64, 64, 300, 0),
 ]
 
 
@@ -806,6 +811,9 @@ def test_tkw_conv_groupnorm_mish_forward(L, K, N, R, K1, extras):
 TKW_BWD = [   # L, K (= C_out of the forward layer), N (= C_in), samples, N1 (output split)
     (6, 256, 256, 37, 0), (12, 128, 128, 19, 0), (6, 256, 128, 16, 0), (6, 128, 512, 21, 256), (12, 64, 256, 9, 128), (8, 256, 256, 13, 0),
     (16, 128, 128, 7, 0), (4, 256, 256, 33, 0), (24, 64, 128, 5, 0), (12, 256, 256, 9, 0), (48, 32, 128, 3, 0),
+    # the narrow levels (tkc.hip)
+    (48, 32, 32, 7, 0), (24, 64, 32, 9, 0), (24, 64, 64, 11, 0), (48, 32, 64, 3, 0), (16, 32, 32, 5, 0), (8, 64, 64, 13, 0), (12, 64, 64, 9, 0),
+    (32, 64, 32, 3, 0), (48, 64, 64, 300, 0),
 ]
 
 
