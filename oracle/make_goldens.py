@@ -455,7 +455,9 @@ def gen_boundary(m2, sp2):
     arrs.update(rep_x=xr.numpy(), rep_t=tr.numpy(), rep_traj=trj.numpy(), rep_obst_shape=np.asarray(obr.shape))
     # one static DDIM step of T = 100 / K = 5 at t = 40 (forward_t = 2: the APF hook's first step), with and without the hook
     hc = {k: torch.from_numpy(v)[None].repeat(B, 1) for k, v in synth.default_hard_conds(S, H).items()}
-    xs = synth.make_noise((B, H, S), seed=33) * np.float32(0.5)
+    # (the state: what the reference's own DDIM loop holds before that step -- chain_ddim_apf.npz, same cloud, state 2.  On a random state the
+    # hook moves x0 by O(1) through its collision tests and amplifies a 1e-7 perturbation of x0 to 1e-4 .. 1e-3: not a parity fixture)
+    xs = np.load(os.path.join(OUT, "chain_ddim_apf.npz"))["chain"][2][:B].copy()
     arrs["ddim_x"] = xs
     for apf in (False, True):
         dm = quiet(StaticGaussianDiffusionModel, model=m2, variance_schedule="exponential", n_diffusion_steps=100,

@@ -822,10 +822,15 @@ def test_predict_epsilon_false_and_the_public_helpers():
     u = build_unet(S, H, False, max_rows=16)
     dm = StaticGaussianDiffusionModel(model=u, n_diffusion_steps=25, sampler="ddpm", use_graph=True).eval().to("cuda")   # predict_epsilon omitted: False
     assert dm.predict_epsilon is False
+    # (with the network output taken as x0 the synthetic-weight chain doubles a perturbation every step -- 1.7e-6 after the first step, O(1) after
+    # 25, in every arithmetic mode alike -- so free-running it is compared over its first six states, and over all 25 steps from the reference's
+    # own previous state)
     chain, used = run(dm, {"noise": g["x0_noise"], "cloud": g["cloud"]}, 2)
-    err = np.abs(chain - g["x0_chain"]).max()
-    print(f"predict_epsilon=False DDPM chain free-running: max {err:.2e}")
-    assert used == 26 and err < 1e-4
+    err = np.abs(chain - g["x0_chain"]).reshape(chain.shape[0], -1).max(1)
+    worst = step_teacher_forced(dm, {"chain": g["x0_chain"], "noise": g["x0_noise"], "cloud": g["cloud"]}, ddim=False)
+    print(f"predict_epsilon=False DDPM chain: free-running {' '.join(f'{e:.1e}' for e in err[:8])} ...; per step from the reference's state {worst:.2e}")
+    assert used == 26 and chain.shape == g["x0_chain"].shape and np.isfinite(chain).all()
+    assert err[:6].max() < 5e-5 and worst < 5e-5
     # one static DDIM step, T = 100 / K = 5, t = 40, forward_t = 2
     hc = {k: torch.from_numpy(v).cuda()[None].repeat(3, 1) for k, v in synth.default_hard_conds(S, H).items()}
     for apf, key in ((False, "ddim_out"), (True, "ddim_out_apf")):
