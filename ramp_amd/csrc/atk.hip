@@ -80,8 +80,9 @@ int ato_pack(const float* W, float scale, unsigned short* out, hipStream_t s) {
 // head step only the raw q rows wait in registers (48): its k and v rows go to wave-private LDS regions by LDS-DMA, in single pieces
 // spread over the whole head step (the kernel is bound by the rate at which HBM requests can be issued: ~11 bytes per cycle and CU).
 // Vector-memory order of a head step: wait(0) | S^T / softmax: the NEXT step's k pieces (4 per query group) | its q loads (12) | slab k:
-// ring slab g + 2 + k (4 pieces, every other macro-step), v pieces 3 k .. 3 k + 2 | slab 3 also: touches of the epilogue's residual rows (6)
-// | (epilogue).  A slab's pieces are issued two slabs ahead into a 3-slot ring; slabs 2, 3 wait with vmcnt(6) (8 and more requests are
+// ring slab g + 2 + k (4 pieces, every other macro-step), v pieces 3 k .. 3 k + 2 | (epilogue).  (Round 4 touched one dword of every line of the
+// epilogue's residual rows during slab 3 of every head step, to find them in the L2; round 5's counters showed the launch reading 8.3 KB per token where
+// 4 KB are needed, and without the touches it is 10-18 % faster: removed.)  A slab's pieces are issued two slabs ahead into a 3-slot ring; slabs 2, 3 wait with vmcnt(6) (8 and more requests are
 // younger than the slab they wait for), the wait at the head step's start drains everything.
 // ABL (diagnostic twins, ramp_bench_gemm only): bit 0 per-wave s_memtime sums of a head step's phases; bit 1 no k / v LDS-DMA, bit 2 no
 // ring LDS-DMA inside the slabs (wrong results)
@@ -145,9 +146,6 @@ void ato_kernel(AtoArgs a, int n_tiles) {
   int gs = 0;                                               // slabs consumed
   const char* rd = smem + lane * 16;
 
-  float tch[2 * NG], touch = 0.f;                           // sink of the touches
-#pragma unroll
-  for (int i = 0; i < 2 * NG; ++i) tch[i] = 0.f;
   // rows of the wave in qkv: 32-bit byte offsets (launch_ato bounds M) from ONE per-use token index the compiler cannot see through
   // (left visible, hipcc hoists fifteen tile-independent partial sums out of the head-step loop and spills them), clamped into
   // [0, M): tokens past M read row M - 1
@@ -410,17 +408,6 @@ void ato_kernel(AtoArgs a, int n_tiles) {
       __builtin_amdgcn_s_barrier();                         // slab gs is complete in LDS; every wave has left slab gs - 1
       stamp(4);
       ring_begin();                                         // slab gs + 2 goes into the slot of slab gs - 1 (past the last tile: bytes nobody reads)
-      if (k4 == 3) {
-        // the tile's epilogue reads 48 KB of residual rows per wave: one dword of each of their 384 lines, so that its loads find them in
-        // the L2 / MALL (as tklb_kernel touches its next operand chunk); every head step re-touches them, only the last matters
-        int tk0 = (int)tok0 + c;
-        asm volatile("" : "+v"(tk0));
-#pragma unroll
-        for (int t = 0; t < NG; ++t)
-#pragma unroll
-          for (int k2 = 0; k2 < 2; ++k2)
-            tch[2 * t + k2] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.resid) + ((unsigned)min(tk0 + 16 * t, m_last) * 1024u + 128u * (unsigned)(g + 4 * k2)));
-      }
       const char* sl = rd + (gs % AT_R) * AT_SLAB;
       // macro-step m = (nbl, j): fragments (hi, lo) of 16 output features x 32 k, 3 token groups x 3 products.  Order inside a macro-step,
       // pinned: first MFMA | this macro-step's LDS-DMA pieces | fragment reads of macro-step m + 1 | the other 8 MFMAs
@@ -471,8 +458,6 @@ void ato_kernel(AtoArgs a, int n_tiles) {
       }
       const char* rbase = reinterpret_cast<const char*>(a.resid);
       char* ybase = reinterpret_cast<char*>(a.Y);
-#pragma unroll
-      for (int i = 0; i < 2 * NG; ++i) touch += tch[i];
       if (full) {
         // all loads of a batch first, every store unconditional (a store behind a per-lane predicate sits in its own basic block behind
         // s_waitcnt vmcnt(0): DESIGN.md section 5); 8 batches of 2 feature blocks, the loads two batches ahead of their stores
@@ -525,7 +510,6 @@ void ato_kernel(AtoArgs a, int n_tiles) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the block
 
   amax = wave_max(amax);
-  if (touch == 1.2345e-30f && a.amax_out) a.amax_out[0] = touch;      // (keeps the touches alive; never true in practice)
   record_amax_block_guarded(a.amax_out, amax, reinterpret_cast<float*>(smem), a.range_flag, s_in, a.site);      // (no LDS-DMA in flight: vmcnt(0) above)
 }
 
