@@ -359,7 +359,9 @@ int ramp_op_atb(const float* qkv, const float* dout, float* dqkv, int32_t M, int
  *            gradient GNbwd(X (.) mish'(gn_gamma x^ + gn_beta) gn_gamma) with x^ from gn_c (M, K) and gn_stats (M / L, 8, 2) [mean, rstd];
  *   result:  Y = conv + bias + resid + resid2 (channels [0, N1) to Y, the rest to Y2 when Y2 is given), or, when Cst is given,
  *            Cst = conv + bias, stats = its GroupNorm(8) statistics, Y = mish(GN(Cst) gamma + beta) + tbias + resid.
- * absmax_prev > 0: the operand is scaled from that maximum (delayed scaling); the maximum of this call is returned. */
+ * absmax_prev > 0: the operand is scaled from that maximum (delayed scaling); the maximum of this call is returned.
+ * Narrow layers (N, K in {32, 64}; one operand, one output; L >= 8 dividing 48 or 32) run the same fusion on sample-owning WAVES (tkc.hip), as
+ * ramp_sample does for the two finest levels and the final Conv1dBlock (UnetInference.py:142-145). */
 int ramp_op_tkw(const float* X, const float* X2, int32_t K1, const float* W, const float* bias, const float* resid, const float* resid2,
                 const float* gn_c, const float* gn_stats, const float* gn_gamma, const float* gn_beta, const float* gamma, const float* beta,
                 const float* tbias, int32_t M, int32_t L, int32_t N, int32_t K, int32_t dir, int32_t N1, float absmax_prev, float* Y, float* Y2,
