@@ -69,6 +69,10 @@ typedef struct ramp_launch_plan {
                            * GroupNorm + Mish fused -- forward: behind the convolution; input gradient: GroupNorm backward folded into the
                            * operand -- on sample-owning blocks (tkw.hip) from this many tokens, on levels whose token count (>= 3)
                            * divides 96: 0 never, 1 always */
+  int32_t mfma16;         /* the token-owning fused feed-forward issues v_mfma_f32_16x16x32_f16 (ffx16.hip, 1: the default) or
+                           * v_mfma_f32_32x32x16_f16 (ffx.hip, 0): same products and call sites, another summation tiling; the 16-wide
+                           * shape holds a higher clock under the socket power cap (profiles/r06_mfma_shape_probe.txt).  Default from
+                           * RAMP_MFMA16, read once in ramp_create */
 } ramp_launch_plan;
 int ramp_get_launch_plan(ramp_ctx* ctx, ramp_launch_plan* out);
 int ramp_set_launch_plan(ramp_ctx* ctx, const ramp_launch_plan* plan);
@@ -331,6 +335,10 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
 int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
                 const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
                 float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
+/* the same operation on the v_mfma_f32_16x16x32_f16 kernel pair (ffx16.hip; ramp_launch_plan.mfma16 = 1, what the product runs) */
+int ramp_op_ffx16(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
+                  const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
+                  float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
 /* Token-owning linear layer with K = 256 (tkl.hip; the product path uses it for LayerNorm-1 -> QKV, the attention output
  * projection and its input gradient -- reference layers_attention_mini.py:60-120, 130-149):
  *   Y[m][n] = sum_k pro(X)[m][k] W[n][k] + bias[n] + rowbias[rowvar[m / L]][n] + resid[m][n],  pro = LayerNorm(256) when ln_g

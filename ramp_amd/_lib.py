@@ -25,7 +25,7 @@ class RampConfig(C.Structure):
 class RampLaunchPlan(C.Structure):
     _fields_ = [("ff_fused_rows", C.c_int32), ("ffx_rows", C.c_int32), ("share_prefix", C.c_int32),
                 ("three_blocks", C.c_int32), ("x6_pipe", C.c_int32), ("tkl_rows", C.c_int32), ("atk_rows", C.c_int32),
-                ("tkc_rows", C.c_int32), ("tkw_rows", C.c_int32)]
+                ("tkc_rows", C.c_int32), ("tkw_rows", C.c_int32), ("mfma16", C.c_int32)]
 
 
 class RampApfParams(C.Structure):
@@ -115,6 +115,7 @@ PROTOTYPES = {
     "ramp_op_gemm": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]),
     "ramp_op_gemm_mode": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 8 + [C.c_float, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_ffx": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, c_f32p, C.c_void_p, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
+    "ramp_op_ffx16": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, c_f32p, C.c_void_p, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_tkl": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_ato": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_atb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libramp_hip.so")
-SOURCES = ["gemm.hip", "ffx.hip", "tkl.hip", "atk.hip", "atl.hip", "tkc.hip", "tkw.hip", "rowops.hip", "attention.hip", "sampler.hip", "scene.hip", "metrics.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "ffx.hip", "ffx16.hip", "tkl.hip", "atk.hip", "atl.hip", "tkc.hip", "tkw.hip", "rowops.hip", "attention.hip", "sampler.hip", "scene.hip", "metrics.hip", "engine.hip"]
 # default GEMM mode 2 = fp16x3 split with delayed operand scaling, 1 = bf16x6 split (both fp32-accurate, see gemm.hip);
 # 0 = exact fp32 MFMA
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DRAMP_DEFAULT_GEMM_MODE=2"]
@@ -18,7 +18,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # -ffp-contract=fast would fuse a*b - c*d into an FMA (HIP's __fmul_rn is a plain multiply), so it is off there.
 # ffx.hip: hipcc's SLP vectoriser pairs the GEGLU elements into v_pk_* instructions, which issue slower beside MFMAs and
 # bunch the elementwise work in front of a slab's first MFMA
-EXTRA_FLAGS = {"sampler.hip": ["-ffp-contract=off"], "ffx.hip": ["-fno-slp-vectorize"], "tkl.hip": ["-fno-slp-vectorize"], "atk.hip": ["-fno-slp-vectorize"], "atl.hip": ["-fno-slp-vectorize"], "tkc.hip": ["-fno-slp-vectorize"], "tkw.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"sampler.hip": ["-ffp-contract=off"], "ffx.hip": ["-fno-slp-vectorize"], "ffx16.hip": ["-fno-slp-vectorize"], "tkl.hip": ["-fno-slp-vectorize"], "atk.hip": ["-fno-slp-vectorize"], "atl.hip": ["-fno-slp-vectorize"], "tkc.hip": ["-fno-slp-vectorize"], "tkw.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(out: str, deps) -> bool:

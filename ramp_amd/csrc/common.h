@@ -160,6 +160,12 @@ int ffx_pack_second(const float* W, int rows, int cols, int mode, float scale, f
 // out: 96 * 32 KB
 int ffx_build_stream(const unsigned short* p1, const unsigned short* p2, unsigned short* out, bool bwd, hipStream_t s);
 int init_ffx_attributes();
+// the same kernel pair on v_mfma_f32_16x16x32_f16 (ffx16.hip): same arguments, its own weight streams (16 x 32 fragments)
+int launch_ffx16(const FfxArgs& f, bool bwd, hipStream_t s);
+// W [rows][cols] fp32 -> 16 x 32 fragment planes (tmp: rows * cols floats); perm 0 none, 1 / 2 the k order of the forward / backward second product
+int ffx16_pack(const float* W, int rows, int cols, int perm, float scale, float* tmp, unsigned short* out, hipStream_t s);
+int ffx16_build_stream(const unsigned short* p1, const unsigned short* p2, unsigned short* out, bool bwd, hipStream_t s);
+int init_ffx16_attributes();
 
 // Token-owning linear layer with K = 256 (tkl.hip): Y[m][n] = sum_k pro(X)[m][k] W[n][k] (+ bias[n]) (+ rowbias[rowvar[row0 + m / L]][n])
 // (+ resid[m][n]); pro = identity or LayerNorm(256).  fp16x3 products, delayed scale / maxima / range guard of ONE call site.

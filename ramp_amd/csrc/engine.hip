@@ -112,6 +112,7 @@ struct STBlock {
   float *a_qkv = nullptr, *a_z1 = nullptr, *a_ag = nullptr, *a_z2 = nullptr;
   // token-owning fused feed-forward (ffx.hip): the two weight streams, the weight scales of their first / second product
   unsigned short *ffx_f = nullptr, *ffx_b = nullptr; float ffx_wsi_w1 = 1.f, ffx_wsi_w2 = 1.f;
+  unsigned short *ffx16_f = nullptr, *ffx16_b = nullptr;     // the same streams in 16 x 32 fragments (ffx16.hip)
   // self-attention fused with the output projection (atk.hip): the projection's weight stream
   unsigned short* ato_w = nullptr; float ato_wsi = 1.f;
   unsigned short* abl_w = nullptr;       // weight stream of the fused attention backward + d(ln1) (atl.hip), scale = the wqkv_b planes'
@@ -204,6 +205,8 @@ struct ramp_ctx {
   int ff_fused = 150000;             // fp16x3 evaluations: FF1 -> GEGLU -> FF2 as one launch for M >= this many rows
                                      // (RAMP_FF_FUSED: 0 never, 1 always, n > 1 that threshold)
   int three_blocks = 1;              // launch plan: third resident block for the bias-only linears
+  int mfma16 = 1;                    // launch plan: the token-owning fused feed-forward on v_mfma_f32_16x16x32_f16 (ffx16.hip; 0: the 32x32x16 kernels of
+                                     // ffx.hip) -- the shape that holds the higher clock under the power cap (RAMP_MFMA16)
   int ffx_min_rows = 32768;          // fp16x3 evaluations: feed-forward pairs with at least this many tokens run the token-owning fused
                                      // kernels of ffx.hip, forward and backward (RAMP_FFX: 0 never, n that threshold)
   int tkl_min_rows = 65536;          // fp16x3 evaluations: K = 256 transformer linears (LN1 -> QKV, out-proj, d(o)) with at least this many
@@ -493,13 +496,14 @@ struct Run {
     RAMP_REQUIRE(c->site + 2 <= ramp_ctx::MAX_SITES, "too many GEMM call sites for the scale table");
     prof_pre(c, s, CAT_GEMM, 2.0 * M * (2048.0 * 256 + 256.0 * 1024), {M, bwd ? -3 : -2, 256, 2});
     FfxArgs f; f.M = M; f.X = X; f.Z1 = z1; f.Y = Y; f.stash = k.a_ag; f.ln_g = k.ln3_g; f.ln_b = k.ln3_b;
-    f.Wstream = bwd ? k.ffx_b : k.ffx_f; f.b1 = k.b1_pk; f.b2 = k.b2; f.range_flag = c->range_flag;
+    const bool s16 = c->mfma16 && k.ffx16_f;
+    f.Wstream = s16 ? (bwd ? k.ffx16_b : k.ffx16_f) : (bwd ? k.ffx_b : k.ffx_f); f.b1 = k.b1_pk; f.b2 = k.b2; f.range_flag = c->range_flag;
     f.amax_in1 = c->obs_in + c->site; f.amax_out1 = c->obs_out + c->site; f.site1 = c->site;
     f.amax_in2 = c->obs_in + c->site + 1; f.amax_out2 = c->obs_out + c->site + 1; f.site2 = c->site + 1;
     f.wsi1 = bwd ? k.ffx_wsi_w2 : k.ffx_wsi_w1; f.wsi2 = bwd ? k.ffx_wsi_w1 : k.ffx_wsi_w2;
-    f.ablate = c->ffx_ablate;
+    f.ablate = s16 ? 0 : c->ffx_ablate;
     c->site += 2;
-    int rc = launch_ffx(f, bwd, s);
+    int rc = s16 ? launch_ffx16(f, bwd, s) : launch_ffx(f, bwd, s);
     prof_post(c, s);
     c->launches++;
     return rc;
@@ -1210,6 +1214,7 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
     if (fe) c->ff_fused = atoi(fe);
     const char* xe = getenv("RAMP_FFX");
     if (xe) c->ffx_min_rows = atoi(xe);
+    if (const char* me = getenv("RAMP_MFMA16")) c->mfma16 = atoi(me) != 0;
     const char* ke = getenv("RAMP_TKL");
     if (ke) c->tkl_min_rows = atoi(ke);
     const char* tce = getenv("RAMP_TKC");
@@ -1243,7 +1248,7 @@ int ramp_create(const ramp_config* cfg, ramp_ctx** out) {
 
 int ramp_get_launch_plan(ramp_ctx* c, ramp_launch_plan* out) {
   RAMP_REQUIRE(c && out, "null argument");
-  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, c->tkl_min_rows, c->atk_min_rows, c->tkc_min_rows, c->tkw_min_rows};
+  *out = ramp_launch_plan{c->ff_fused, c->ffx_min_rows, c->share_prefix, c->three_blocks, c->x6_pipe, c->tkl_min_rows, c->atk_min_rows, c->tkc_min_rows, c->tkw_min_rows, c->mfma16};
   return 0;
 }
 int ramp_set_launch_plan(ramp_ctx* c, const ramp_launch_plan* p) {
@@ -1252,10 +1257,10 @@ int ramp_set_launch_plan(ramp_ctx* c, const ramp_launch_plan* p) {
   RAMP_REQUIRE(!c->finalized || (p->x6_pipe != 0) == (c->x6_pipe != 0), "x6_pipe is fixed once the weights are packed (ramp_finalize_weights)");
   const bool changed = p->ff_fused_rows != c->ff_fused || p->ffx_rows != c->ffx_min_rows || (p->share_prefix != 0) != (c->share_prefix != 0) ||
                        (p->three_blocks != 0) != (c->three_blocks != 0) || p->tkl_rows != c->tkl_min_rows || p->atk_rows != c->atk_min_rows ||
-                       p->tkc_rows != c->tkc_min_rows || p->tkw_rows != c->tkw_min_rows;
+                       p->tkc_rows != c->tkc_min_rows || p->tkw_rows != c->tkw_min_rows || (p->mfma16 != 0) != (c->mfma16 != 0);
   c->ff_fused = p->ff_fused_rows; c->ffx_min_rows = p->ffx_rows; c->tkl_min_rows = p->tkl_rows; c->share_prefix = p->share_prefix != 0;
   c->atk_min_rows = p->atk_rows; c->tkc_min_rows = p->tkc_rows; c->tkw_min_rows = p->tkw_rows;
-  c->three_blocks = p->three_blocks != 0; c->x6_pipe = p->x6_pipe != 0;
+  c->three_blocks = p->three_blocks != 0; c->x6_pipe = p->x6_pipe != 0; c->mfma16 = p->mfma16 != 0;
   if (changed && c->finalized) {   // other kernels from here on: captured graphs and kept calibrations belong to the old plan
     c->graph_key.clear(); c->r_key.clear();
     c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false; c->c_cal_valid = false;
@@ -1438,6 +1443,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
       unsigned short *p2f, *p2b;
       { float* q; CK(dev_alloc(c, &q, 256 * 1024 + 4)); p2f = reinterpret_cast<unsigned short*>(q); }
       { float* q; CK(dev_alloc(c, &q, 256 * 2048 + 4)); p2b = reinterpret_cast<unsigned short*>(q); }
+      unsigned short* p1x; { float* q; CK(dev_alloc(c, &q, 256 * 2048 + 4)); p1x = reinterpret_cast<unsigned short*>(q); }
       for (auto& st : c->sts)
         for (auto& k : st.blk) {
           const auto& e1 = c->x6.at(k.w1_pk); const auto& e1b = c->x6.at(k.w1_b);
@@ -1450,6 +1456,15 @@ int ramp_finalize_weights(ramp_ctx* c) {
           CK(ffx_pack_second(k.w1_b, 256, 2048, 1, 1.f / e1.w_scale_inv, tmp, p2b, 0));
           CK(ffx_build_stream(e2b.packed3, p2b, k.ffx_b, true, 0));
           k.ffx_wsi_w1 = e1.w_scale_inv; k.ffx_wsi_w2 = e2.w_scale_inv;
+          // the same two streams in 16 x 32 fragments for the v_mfma_f32_16x16x32_f16 kernels (ffx16.hip), same scales
+          float *sf6, *sb6; CK(dev_alloc(c, &sf6, 96 * 8192 + 4)); CK(dev_alloc(c, &sb6, 96 * 8192 + 4));
+          k.ffx16_f = reinterpret_cast<unsigned short*>(sf6); k.ffx16_b = reinterpret_cast<unsigned short*>(sb6);
+          CK(ffx16_pack(k.w1_pk, 2048, 256, 0, 1.f / e1.w_scale_inv, tmp, p1x, 0));
+          CK(ffx16_pack(k.w2_f, 256, 1024, 1, 1.f / e2.w_scale_inv, tmp, p2f, 0));
+          CK(ffx16_build_stream(p1x, p2f, k.ffx16_f, false, 0));
+          CK(ffx16_pack(k.w2_b, 1024, 256, 0, 1.f / e2.w_scale_inv, tmp, p1x, 0));
+          CK(ffx16_pack(k.w1_b, 256, 2048, 2, 1.f / e1.w_scale_inv, tmp, p2b, 0));
+          CK(ffx16_build_stream(p1x, p2b, k.ffx16_b, true, 0));
         }
     }
     if (c->gemm_mode == 2 && c->x6_pipe) {
@@ -1496,7 +1511,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
   RAMP_HIP_CHECK(hipDeviceSynchronize());
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
   CK(init_attention_attributes());
-  CK(init_ffx_attributes());
+  CK(init_ffx_attributes()); CK(init_ffx16_attributes());
   CK(init_tkl_attributes());
   CK(init_atk_attributes());
   CK(init_atl_attributes());
@@ -2273,7 +2288,7 @@ struct FfxPack {
   float *b1_pk = nullptr; float wsi_w1 = 1.f, wsi_w2 = 1.f;
 };
 // W1 [2048][256] (rows: 1024 a then 1024 g), W2 [256][1024]; everything allocated from `ar`
-int ffx_pack_all(DevArena& ar, const float* W1, const float* b1, const float* W2, FfxPack* out, hipStream_t s) {
+int ffx_pack_all(DevArena& ar, const float* W1, const float* b1, const float* W2, FfxPack* out, hipStream_t s, bool s16 = false) {
   auto maxabs = [&](const float* d, size_t n, float* sc) -> int {
     std::vector<float> hw(n);
     RAMP_HIP_CHECK(hipMemcpy(hw.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -2295,25 +2310,35 @@ int ffx_pack_all(DevArena& ar, const float* W1, const float* b1, const float* W2
   hipLaunchKernelGGL(permute3_kernel, dim3(2048), dim3(256), 0, s, W1, w1t, 2048, 256, 1, 1, 0, 2);      // [256][2048]
   hipLaunchKernelGGL(permute3_kernel, dim3(1024), dim3(256), 0, s, W2, w2t, 256, 1024, 1, 1, 0, 2);      // [1024][256]
   RAMP_HIP_CHECK(hipGetLastError());
-  CK(launch_pack_h3(w1_pk, p_w1, 2048, 256, sc1, s));
-  CK(ffx_pack_second(W2, 256, 1024, 0, sc2, tmp, p_w2p, s));
-  CK(launch_pack_h3(w2t, p_w2t, 1024, 256, sc2, s));
-  CK(ffx_pack_second(w1t, 256, 2048, 1, sc1, tmp, p_w1tp, s));
-  CK(ffx_build_stream(p_w1, p_w2p, out->stream_f, false, s));
-  CK(ffx_build_stream(p_w2t, p_w1tp, out->stream_b, true, s));
+  if (s16) {      // 16 x 32 fragments for the v_mfma_f32_16x16x32_f16 kernels (ffx16.hip)
+    CK(ffx16_pack(w1_pk, 2048, 256, 0, sc1, tmp, p_w1, s));
+    CK(ffx16_pack(W2, 256, 1024, 1, sc2, tmp, p_w2p, s));
+    CK(ffx16_pack(w2t, 1024, 256, 0, sc2, tmp, p_w2t, s));
+    CK(ffx16_pack(w1t, 256, 2048, 2, sc1, tmp, p_w1tp, s));
+    CK(ffx16_build_stream(p_w1, p_w2p, out->stream_f, false, s));
+    CK(ffx16_build_stream(p_w2t, p_w1tp, out->stream_b, true, s));
+  } else {
+    CK(launch_pack_h3(w1_pk, p_w1, 2048, 256, sc1, s));
+    CK(ffx_pack_second(W2, 256, 1024, 0, sc2, tmp, p_w2p, s));
+    CK(launch_pack_h3(w2t, p_w2t, 1024, 256, sc2, s));
+    CK(ffx_pack_second(w1t, 256, 2048, 1, sc1, tmp, p_w1tp, s));
+    CK(ffx_build_stream(p_w1, p_w2p, out->stream_f, false, s));
+    CK(ffx_build_stream(p_w2t, p_w1tp, out->stream_b, true, s));
+  }
   out->wsi_w1 = 1.f / sc1; out->wsi_w2 = 1.f / sc2;
   return 0;
 }
 }  // namespace
 
-int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
-                const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
-                float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+static int op_ffx_impl(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
+                       const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
+                       float* absmax_out_host, int32_t* range_flag_out_host, void* stream, bool s16) {
   RAMP_REQUIRE(z1 && W1 && b1 && W2 && b2 && ln_g && ln_b && z2 && M > 0, "null argument");
   hipStream_t s = as_stream(stream);
   DevArena ar;
   FfxPack pk;
-  CK(ffx_pack_all(ar, W1, b1, W2, &pk, s));
+  CK(ffx_pack_all(ar, W1, b1, W2, &pk, s, s16));
+  auto launch_ffx = [s16](const FfxArgs& a, bool bwd, hipStream_t st) { return s16 ? ramp::launch_ffx16(a, bwd, st) : ramp::launch_ffx(a, bwd, st); };
   const size_t mt = ((size_t)M + 127) / 128;
   float* stash = ar.alloc(mt * 128 * 2048); float* slots = ar.alloc(12);
   RAMP_REQUIRE(stash && slots, "hipMalloc failed");
@@ -2340,6 +2365,16 @@ int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* 
   }
   RAMP_HIP_CHECK(e);
   return rc;
+}
+int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
+                const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
+                float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  return op_ffx_impl(z1, dz, W1, b1, W2, b2, ln_g, ln_b, M, absmax_prev_host, z2, dz1, absmax_out_host, range_flag_out_host, stream, false);
+}
+int ramp_op_ffx16(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
+                  const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
+                  float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  return op_ffx_impl(z1, dz, W1, b1, W2, b2, ln_g, ln_b, M, absmax_prev_host, z2, dz1, absmax_out_host, range_flag_out_host, stream, true);
 }
 
 int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
@@ -2853,7 +2888,9 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     fill6(z1, (size_t)M * 256, 1u, 1.f); fill6(dz, (size_t)M * 256, 7u, 1.f); fill6(W1, 2048 * 256, 2u, 1.f / 16.f); fill6(W2, 256 * 1024, 3u, 1.f / 32.f);
     fill6(b1, 2048, 5u, 1.f); fill6(b2, 256, 6u, 1.f); fill6(lg, 256, 8u, 1.f); fill6(lb, 256, 9u, 1.f);
     FfxPack pk;
-    CK(ffx_pack_all(ar6, W1, b1, W2, &pk, s6));
+    const bool s16 = (flags >> 16) & 1;                  // flags bit 16: the v_mfma_f32_16x16x32_f16 pair (ffx16.hip)
+    CK(ffx_pack_all(ar6, W1, b1, W2, &pk, s6, s16));
+    auto launch_ffx = [s16](const FfxArgs& a, bool bwd, hipStream_t st) { return s16 ? ramp::launch_ffx16(a, bwd, st) : ramp::launch_ffx(a, bwd, st); };
     const float one[12] = {4.f, 2.f, 1.f, 1.f, 0, 0, 0, 0, 0, 0, 0, 0};
     RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, s6));
     FfxArgs f; f.M = M; f.X = z1; f.Z1 = z1; f.Y = out; f.stash = stash; f.ln_g = lg; f.ln_b = lb; f.Wstream = pk.stream_f; f.b1 = pk.b1_pk; f.b2 = b2;
@@ -2880,7 +2917,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
       std::vector<unsigned long long> h(256 * 4 * 6);
       RAMP_HIP_CHECK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
       double sm[6] = {0, 0, 0, 0, 0, 0}; int nw = 0;
-      for (int w = 0; w < 1024; ++w) if (h[w * 6 + 3]) { ++nw; for (int j = 0; j < 6; ++j) sm[j] += (double)h[w * 6 + j]; }
+      for (int w = 0; w < 1024; ++w) if (h[w * 6 + 5]) { ++nw; for (int j = 0; j < 6; ++j) sm[j] += (double)h[w * 6 + j]; }
       const double slabs = std::max(1, nw) * 96.0 * (double)((mt + 255) / 256);
       fprintf(stderr, "[ffx stamps] per slab (s_memtime ticks): vm wait %.0f, barrier %.0f, DMA issue %.0f, body %.0f (%d waves); shader clock %.0f MHz\n",
               sm[0] / slabs, sm[1] / slabs, sm[2] / slabs, sm[3] / slabs, nw, sm[5] > 0 ? sm[4] / sm[5] * 100.0 : 0.0);

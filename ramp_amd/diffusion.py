@@ -349,23 +349,43 @@ class _GaussianDiffusionBase(nn.Module):
         return x_out, chain
 
     # ------------------------------------------------------------------ loops (reference signatures)
+    @staticmethod
+    def _is_fused_ddpm_step(sample_fn) -> bool:
+        """True for the two step functions the fused job implements: this package's ``ddpm_sample_fn`` and the reference's own
+        (``mpd.models.diffusion_models.sample_functions.ddpm_sample_fn``, recognised by name and module so that a driver that
+        still imports it from there keeps the fast path)."""
+        if sample_fn is None or sample_fn is ddpm_sample_fn:      # (None = "the default": the reference would fail on the call)
+            return True
+        mod = getattr(sample_fn, '__module__', '') or ''
+        return getattr(sample_fn, '__name__', None) == 'ddpm_sample_fn' and mod.startswith('mpd.') and mod.endswith('sample_functions')
+
     @torch.no_grad()
     def p_sample_loop(self, shape, hard_conds, context=None, return_chain=False, traj_normalized=None,
                       obstacle_pts=None, sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=0,
                       noise_std_extra_schedule_fn=None, **sample_kwargs):
-        """diffusion_model_static.py:232-256 / diffusion_model_3d.py:185-218 (resample_steps = 1)."""
+        """diffusion_model_static.py:232-256 / diffusion_model_3d.py:185-218 (resample_steps = 1).  With the stock
+        ``ddpm_sample_fn`` the whole loop is ONE fused job (``ramp_sample``: captured graph, noise and schedule tables on the
+        device); any other ``sample_fn`` is honoured the way the reference honours it -- called once per step with the
+        reference's arguments -- on the eager loop below."""
+        if not self._is_fused_ddpm_step(sample_fn):
+            return self._p_sample_loop_stepwise(shape, hard_conds, context, return_chain, traj_normalized, obstacle_pts, sample_fn,
+                                                n_diffusion_steps_without_noise, noise_std_extra_schedule_fn, sample_kwargs)
         device = self._device()
         B = shape[0]
         philox = self.noise_source == "philox"
         x = None if philox else torch.randn(shape, device=device)
         noises = [x]
-        steps, scales = [], []
+        steps, raw = [], []
         for i in reversed(range(-n_diffusion_steps_without_noise, self.n_diffusion_steps)):
-            t = max(i, 0)                                           # sample_functions.py:25-27
-            steps.append(t)
+            steps.append(max(i, 0))                                 # sample_functions.py:25-27
+            raw.append(i)
             if not philox:
                 noises.append(torch.randn_like(x))                  # drawn every step, zeroed at t == 0
-            scales.append(1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(i)))
+        if noise_std_extra_schedule_fn is None:
+            scales = [1.0] * len(steps)
+        else:       # the reference hands the schedule function t[0], a 0-d long tensor on the device (sample_functions.py:24, 41-44)
+            ts = torch.tensor(raw, device=device, dtype=torch.long)
+            scales = [float(noise_std_extra_schedule_fn(ts[j])) for j in range(len(raw))]
         # compose: ddpm_sample_fn calls p_mean_variance_compose, which has no APF hook (static.py:188-229)
         apf = [1 if (self.APF and self._supports_apf and not self.compose and j > self.apf_ddpm['after']) else 0
                for j in range(len(steps))]
@@ -375,6 +395,35 @@ class _GaussianDiffusionBase(nn.Module):
         if return_chain:
             return x_out, chain.permute(1, 0, 2, 3)       # reference stacks along dim=1
         return x_out
+
+    @torch.no_grad()
+    def _p_sample_loop_stepwise(self, shape, hard_conds, context, return_chain, traj_normalized, obstacle_pts, sample_fn,
+                                n_diffusion_steps_without_noise, noise_std_extra_schedule_fn, sample_kwargs):
+        """The reference's loop, statement for statement, for a caller-supplied step function (diffusion_model_static.py:232-256):
+        per step ``x, values = sample_fn(self, x, hard_conds, context, t, ...)`` with ``t`` a (B,) long tensor on the device, then
+        ``apply_hard_conditioning``.  The step function reaches the HIP kernels through this class's single-step API
+        (``p_mean_variance`` -> ``ramp_score`` + ``ramp_cfg_mean``, ``ramp_hard_cond``); noise comes from ``torch.randn`` whatever
+        ``noise_source`` says (the step function draws its own)."""
+        device = self._device()
+        B = shape[0]
+        pts = obstacle_pts if self.compose else obstacle_pts.unsqueeze(0)        # static.py:239-240
+        x = torch.randn(shape, device=device)
+        x = apply_hard_conditioning(x, hard_conds)
+        chain = [x] if return_chain else None
+        if noise_std_extra_schedule_fn is not None:      # one of the reference's **sample_kwargs
+            sample_kwargs = dict(sample_kwargs, noise_std_extra_schedule_fn=noise_std_extra_schedule_fn)
+        forward_t = 0
+        for i in reversed(range(-n_diffusion_steps_without_noise, self.n_diffusion_steps)):
+            t = make_timesteps(B, i, device)
+            x, _values = sample_fn(self, x, hard_conds, context, t, traj_normalized=traj_normalized, obstacle_pts=pts,
+                                   forward_t=forward_t, compose=self.compose, **sample_kwargs)
+            x = apply_hard_conditioning(x.contiguous(), hard_conds)
+            if return_chain:
+                chain.append(x)
+            forward_t += 1
+        if return_chain:
+            return x, torch.stack(chain, dim=1)
+        return x
 
     def ddim_set_timesteps(self, num_inference_steps) -> np.ndarray:
         self.num_inference_steps = num_inference_steps

@@ -150,7 +150,7 @@ class TemporalUnetInference(nn.Module):
         plan = _lib.RampLaunchPlan()
         _lib.check(lib.ramp_get_launch_plan(h, C.byref(plan)), "ramp_get_launch_plan")
         for k, v in kw.items():
-            if k not in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe", "tkl_rows", "atk_rows", "tkc_rows", "tkw_rows"):
+            if k not in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe", "tkl_rows", "atk_rows", "tkc_rows", "tkw_rows", "mfma16"):
                 raise KeyError(f"unknown launch-plan field {k!r}")
             setattr(plan, k, int(v))
         _lib.check(lib.ramp_set_launch_plan(h, C.byref(plan)), "ramp_set_launch_plan")
@@ -166,7 +166,7 @@ class TemporalUnetInference(nn.Module):
     def get_launch_plan(self) -> dict:
         plan = _lib.RampLaunchPlan()
         _lib.check(_lib.load().ramp_get_launch_plan(self.ctx(), C.byref(plan)), "ramp_get_launch_plan")
-        return {k: getattr(plan, k) for k in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe", "tkl_rows", "atk_rows", "tkc_rows", "tkw_rows")}
+        return {k: getattr(plan, k) for k in ("ff_fused_rows", "ffx_rows", "share_prefix", "three_blocks", "x6_pipe", "tkl_rows", "atk_rows", "tkc_rows", "tkw_rows", "mfma16")}
 
     def prepare_time_table(self, T: int):
         if T > self._T_table:

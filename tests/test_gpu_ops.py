@@ -366,8 +366,10 @@ def test_fp16x3_dynamic_range_sweep(kind, wkind):
 
 
 @pytest.mark.parametrize("M", [128, 293, 4173])
-def test_ffx_fused_feed_forward_against_float64_autograd(M):
-    """The token-owning fused feed-forward kernels (ffx.hip) through the C ABI (ramp_op_ffx): forward
+@pytest.mark.parametrize("entry", ["ramp_op_ffx16", "ramp_op_ffx"])
+def test_ffx_fused_feed_forward_against_float64_autograd(M, entry):
+    """The token-owning fused feed-forward kernels through the C ABI -- ramp_op_ffx16: the v_mfma_f32_16x16x32_f16 pair the
+    product runs (ffx16.hip, round 6); ramp_op_ffx: the 32x32x16 pair (ffx.hip, ramp_launch_plan.mfma16 = 0) -- forward
     z2 = z1 + W2 (a gelu(g)) + b2, [a | g] = W1 LN(z1) + b1 (layers_attention_mini.py:38-45, 147) and its input gradient
     dz1 = dz + J^T dz (LayerNorm backward included), against float64 torch autograd; M not a multiple of the 128-token
     tile; the operand maxima each launch records are the true ones, and scaling from them leaves the result unchanged to
@@ -391,9 +393,9 @@ def test_ffx_fused_feed_forward_against_float64_autograd(M):
     out, flag = (C.c_float * 4)(), C.c_int32(0)
 
     def go(prev):
-        _lib.check(_lib.load().ramp_op_ffx(_lib.ptr(z1), _lib.ptr(dz), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
-                                           _lib.ptr(g), _lib.ptr(b), M, (C.c_float * 4)(*prev), _lib.ptr(z2), _lib.ptr(dz1), out,
-                                           C.byref(flag), None), "ramp_op_ffx")
+        _lib.check(getattr(_lib.load(), entry)(_lib.ptr(z1), _lib.ptr(dz), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+                                               _lib.ptr(g), _lib.ptr(b), M, (C.c_float * 4)(*prev), _lib.ptr(z2), _lib.ptr(dz1), out,
+                                               C.byref(flag), None), entry)
         return rel(z2.double().cpu().numpy(), z2r.cpu().numpy()), rel(dz1.double().cpu().numpy(), dz1r.cpu().numpy())
 
     e = go([0.0, 0.0, 0.0, 0.0])                              # unscaled operands (the first, calibrating use of a call site)
@@ -678,6 +680,8 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("fused FF1->GEGLU->FF2 forward (ff_fwd_kernel)", 393216, 2048, 256, 1, 1, 5, 0, False),
     ("token-owning fused feed-forward, forward (ffx)", 393216, 2048, 256, 1, 1, 6, 0, False),
     ("token-owning fused feed-forward, backward (ffx)", 393216, 2048, 256, 1, 1, 7, 0, False),
+    ("token-owning fused feed-forward on 16x16x32 MFMAs, forward (ffx16)", 393216, 2048, 256, 1, 1, 6, 1 << 16, False),
+    ("token-owning fused feed-forward on 16x16x32 MFMAs, backward (ffx16)", 393216, 2048, 256, 1, 1, 7, 1 << 16, False),
     ("token-owning LN1 -> QKV (tkl)", 393216, 768, 256, 1, 1, 8, 1, False),
     ("token-owning out-projection with bias and residual (tkl)", 393216, 256, 256, 1, 1, 8, 2, False),
     ("token-owning d(ln1) with LayerNorm-1 backward (tklb)", 393216, 256, 768, 1, 1, 9, 0, False),
@@ -717,6 +721,7 @@ SOAK_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags
     ("abl L=48", 393216, 256, 768, 1, 48, 15, 0), ("abl L=6", 49152, 256, 768, 1, 6, 15, 0), ("ato L=48", 393216, 256, 256, 1, 48, 10, 1),
     ("atb L=24", 196608, 256, 256, 1, 24, 13, 0), ("ffx forward", 393216, 2048, 256, 1, 1, 6, 0), ("ffx backward", 393216, 2048, 256, 1, 1, 7, 0),
     ("tkl LN1->QKV", 393216, 768, 256, 1, 1, 8, 1), ("tklb", 196608, 256, 768, 1, 1, 9, 0),
+    ("ffx16 forward", 393216, 2048, 256, 1, 1, 6, 1 << 16), ("ffx16 backward", 393216, 2048, 256, 1, 1, 7, 1 << 16),
 ]
 
 

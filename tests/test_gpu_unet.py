@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 CASES = [("2d_h48", 4, 48, False), ("3d_h48", 6, 48, True), ("3d_h64", 6, 64, True), ("2d_h40", 4, 40, False)]
 
 
-@pytest.mark.parametrize("gemm_mode", ["fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "fp16x3-tok", "fp16x3-atk", "fp16x3-tkc", "fp16x3-tkw", "bf16x6", "fp32"])
+@pytest.mark.parametrize("gemm_mode", ["fp16x3", "fp16x3-fusedff", "fp16x3-ffx", "fp16x3-tok", "fp16x3-atk", "fp16x3-tkc", "fp16x3-tkw", "fp16x3-m32", "bf16x6", "fp32"])
 @pytest.mark.parametrize("tag,S,H,o3", CASES)
 def test_score_against_reference_fixture(tag, S, H, o3, gemm_mode):
     """forward_no_energy, eps and every per-module output / output-gradient tap of the reference

@@ -36,6 +36,9 @@ PLANS = {   # launch plans the parity tests force onto the small fixtures (ramp_
     "atk": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=0, tkw_rows=0),       # + self-attention fused with the out-projection (atk.hip)
     "tkc": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=1, tkw_rows=0),       # + the narrow k = 5 convolutions on sample-owning waves (tkc.hip): round 4's bench plan
     "tkw": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=1, tkw_rows=1),       # + the wide k = 5 convolutions with GroupNorm + Mish fused around them (tkw.hip): the bench's plan
+    # round 6: the fused feed-forward of every plan above runs on v_mfma_f32_16x16x32_f16 (ffx16.hip, mfma16 = 1 by default); this one keeps
+    # the 32x32x16 pair of ffx.hip under the same fixtures
+    "m32": dict(ff_fused_rows=0, ffx_rows=1, tkl_rows=1, atk_rows=1, tkc_rows=1, tkw_rows=1, mfma16=0),
 }
 
 
