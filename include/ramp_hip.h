@@ -420,13 +420,25 @@ int ramp_debug_read(ramp_ctx* ctx, const char* kind, const char* module, float* 
                     int64_t* n_copied, void* stream);
 
 /* bookkeeping for bench / profiling */
-/* fp16x3 mode only: waits for `stream`, then *flag = 1 if any GEMM of the last ramp_sample found an operand that,
- * scaled by the previous evaluation's maximum, left the fp16 range (the results of that call must be discarded and the
- * job re-run with gemm_mode bf16x6); always 0 in the other modes. */
+/* fp16x3 mode only: waits for `stream`, then *flag != 0 if any GEMM of the last ramp_sample found an operand that, scaled by
+ * the previous evaluation's maximum, left the fp16 range (the results of that call must be discarded and the job repeated:
+ * ramp_set_fallback); always 0 in the other modes.  Round 6: the guard's state is logged on the device after every evaluation
+ * of a job; a flagged status also records WHICH evaluation raised it first (ramp_range_trip). */
 int ramp_range_status(ramp_ctx* ctx, int32_t* flag, void* stream);
-/* fp16x3 mode: bf16x6_only != 0 makes the following ramp_sample calls run every evaluation with the bf16x6 kernels
- * (what the Python wrapper does to repeat a job whose range flag was raised); 0 restores fp16x3. */
-int ramp_set_fallback(ramp_ctx* ctx, int32_t bf16x6_only);
+/* the first flagged evaluation (0-based index into ramp_sample_params.t) and the highest flagged GEMM call site of it, as the last
+ * flagged ramp_range_status found them; *eval = -1 when the last status was clean.  `site` may be NULL. */
+int ramp_range_trip(ramp_ctx* ctx, int32_t* eval, int32_t* site);
+/* fp16x3 mode: how the following ramp_sample calls run.
+ *   0  normally (fp16x3, every evaluation scaled from its predecessor's operand maxima);
+ *   1  every evaluation on the bf16x6 kernels (range-free, 1.83 x the time);
+ *   2  (round 6) fp16x3 again, but the evaluation ramp_range_trip reports AND its successor run as CALIBRATING ones -- bf16x6 kernels
+ *      that record every call site's true operand maximum: they cannot overflow, and what follows is scaled from maxima that are
+ *      right whether the excursion persists or was a one-evaluation spike.
+ *      This is what the Python wrapper does first to repeat a flagged job (diffusion_model_static.py:232-256 as one job): the
+ *      repeat is a function of the job alone (same inputs, same bits, whatever ran before), costs 1.06 x a steady job and stays
+ *      on the fast kernels; only if the repeat is flagged too (a second, later excursion) does the job run a third time in
+ *      mode 1.  Needs a flagged ramp_range_status on record. */
+int ramp_set_fallback(ramp_ctx* ctx, int32_t mode);
 /* fp16x3 mode: where a sampling job's FIRST score evaluation takes its operand scales from (every later one: the evaluation before it).
  * on = 1 (default, round 5): from the context's CANONICAL calibration -- one bf16x6 evaluation that only records the operand maxima, run once,
  * outside any job, on x ~ N(0, I) drawn with a fixed Philox seed under the job's hard conditions at the job's first timestep (x_T of every job

@@ -28,6 +28,7 @@ What is captured:
   cost_cases.npz              compute_collision_with_pointcloud / compute_trajectory_costs
   boundary_cases.npz          public helper methods of the sampler class + predict_epsilon=False (one p_mean_variance, a DDPM chain)
   unet2d_h48_outlier.npz      the 2-D score evaluation with outlier-channel weights (8 rows of every to_out / ff.net.2 x 2^9)
+  chain_ddpm_outlier.npz      the T = 25 DDPM chain on those weights (fp32 reference run + its float64 twin)
 """
 from __future__ import annotations
 
@@ -493,6 +494,36 @@ def gen_outlier_unet():
     gen_unet("2d_h48_outlier", m, sp, synth.make_cloud(6, 64, 2, seed=42), 4, 7, seed=10)
 
 
+def gen_outlier_chain():
+    """The T = 25 DDPM chain (B = 4, the cloud / hard conditions of chain_ddpm_plain) on the outlier-channel weights: where the delayed
+    (previous-evaluation) operand scales of the fp16x3 mode meet operands that move along a chain.  ``chain`` is the
+    reference's fp32 run, ``chain64`` the same run with model, noise and cloud in float64: the yardstick for what ANY fp32 evaluation can
+    reproduce free-running."""
+    m, sp, _ = build_unet(4, 48, False, outliers=True)
+    B, H, S = 4, sp.horizon, sp.state_dim
+    cloud = synth.make_cloud(6, 64, 2, seed=42)
+    noise = synth.make_noise((26, B, H, S), seed=1234)
+    chain, used = run_static(m, sp, 25, B, cloud, noise, ddim=False, use_apf=False)
+    assert used == 26 and chain.shape == (26, B, H, S)
+    torch.set_default_dtype(torch.float64)
+    try:
+        m.double()
+        dm = quiet(StaticGaussianDiffusionModel, model=m, variance_schedule="exponential", n_diffusion_steps=25,
+                   predict_epsilon=True, compose=False, use_apf=False).double()
+        dm.eval(); dm.ddim = False
+        m.reset_cache()
+        hc = {k: torch.from_numpy(v).double() for k, v in synth.default_hard_conds(S, H).items()}
+        with NoiseInjector([torch.from_numpy(n).double() for n in noise]):
+            chain64 = dm.run_inference(None, hc, n_samples=B, horizon=H, return_chain=True, traj_normalized=torch.zeros(H, S),
+                                       obstacle_pts=torch.from_numpy(cloud).double(), sample_fn=ddpm_sample_fn,
+                                       noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=0).detach().numpy()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    d = np.abs(chain - chain64).reshape(26, -1).max(1)
+    print(f"    outlier chain: reference fp32 vs its float64 twin, final {d[-1]:.2e} max {d.max():.2e}; max |x| {np.abs(chain).max():.2f}")
+    save("chain_ddpm_outlier.npz", chain=chain, chain64=chain64, noise=noise, cloud=cloud, T=25)
+
+
 def gen_apf():
     arrs = {}
     cloud = synth.make_cloud(6, 64, 2, seed=42).reshape(-1, 2)
@@ -811,6 +842,8 @@ def main():
         gen_boundary(m2, sp2); return
     if len(sys.argv) > 1 and sys.argv[1] == "outlier":
         gen_outlier_unet(); return
+    if len(sys.argv) > 1 and sys.argv[1] == "outlier_chain":
+        gen_outlier_chain(); return
     if len(sys.argv) > 1 and sys.argv[1] == "cost":
         gen_cost(); return
     if len(sys.argv) > 1 and sys.argv[1] == "apf":

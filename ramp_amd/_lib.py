@@ -139,6 +139,7 @@ PROTOTYPES = {
     "ramp_set_fallback": (C.c_int, [C.c_void_p, C.c_int32]),
     "ramp_set_calibration_reuse": (C.c_int, [C.c_void_p, C.c_int32]),
     "ramp_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "ramp_range_trip": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ramp_workspace_bytes": (C.c_int, [C.c_void_p, c_i64p]),
     "ramp_launch_count": (C.c_int, [C.c_void_p, c_i64p]),
 }

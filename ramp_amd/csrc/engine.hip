@@ -53,6 +53,7 @@ __global__ void permute3_kernel(const float* __restrict__ in, float* __restrict_
 }
 // (a kernel node rather than a memset node: in the T = 50 jobs (config 5) the memset nodes of the captured graph were
 //  replayed with a stale fill pattern -- 0x1c1c1c1c instead of 0 -- on ROCm 7.2; eager runs and T = 25 graphs were fine)
+__global__ void log_flag_kernel(const int* __restrict__ flag, int* __restrict__ log, int j) { if (threadIdx.x == 0) log[j] = *flag; }
 __global__ void zero_words_kernel(unsigned* __restrict__ p, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0u;
@@ -171,6 +172,12 @@ struct ramp_ctx {
   float* s_cloud = nullptr; size_t s_cloud_cap = 0;
   // graph cache
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; std::string graph_key;   // [0] first evaluation calibrates, [1] it continues
+  // Round 6: a job the range guard flagged is repeated IN fp16x3 (ramp_set_fallback(ctx, 2)): the guard's state after every evaluation of a
+  // job is logged on the device (trip_log[j]), ramp_range_status finds the first flagged evaluation, and the repeat runs exactly that
+  // evaluation as a calibrating one (bf16x6 kernels that record every call site's operand maximum: range-free, and its successor is scaled
+  // from maxima that are true) -- a function of the job alone, 1.03 x a steady job instead of the 1.83 x of an all-bf16x6 repeat
+  int* trip_log = nullptr; int trip_log_cap = 0; int last_job_steps = 0; int trip_eval = -1; int trip_site = -1; int rerun = 0;
+  hipGraphExec_t graph_rerun = nullptr; std::string graph_rerun_key;
   // fp16x3 calibration kept from one ramp_sample to the next of the same job shape (ramp_set_calibration_reuse): the
   // job's first evaluation then reads the maxima the previous job's first evaluation recorded (table 2).  A job becomes
   // the next one's calibration only when ramp_range_status has reported it clean.
@@ -179,6 +186,8 @@ struct ramp_ctx {
   // a fixed seed with the job's hard conditions, at the job's first timestep (table 2) -- instead of whatever the previous job left behind: no
   // job contains a bf16x6 evaluation, and a job's result does not depend on what ran before it on the context (ramp_set_calibration_reuse)
   bool c_cal_valid = false; std::string c_cal_key; unsigned long long* c_cal_rec = nullptr;
+  std::map<std::string, float*> c_cal_saved;     // canonical tables already computed, by key: switching between job shapes copies 4 KB instead of re-evaluating
+  std::vector<float*> c_cal_free;                // their buffers after an invalidation (scene / plan change), for reuse
   // receding-horizon replanning (ramp_replan): fixed device buffers the captured graphs read, the graph of a replan whose
   // first evaluation calibrates ([0]) and of one that continues from the previous replan's operand maxima ([1])
   float *r_noise = nullptr, *r_hist = nullptr, *r_xclean = nullptr, *r_best = nullptr, *r_plen = nullptr, *r_smooth = nullptr,
@@ -1659,7 +1668,7 @@ int ramp_score(ramp_ctx* c, const float* x, int32_t B, int32_t n_rp, int32_t t, 
   return 0;
 }
 
-static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, bool chain, bool steady) {
+static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, bool chain, bool steady, int cal_eval = -1) {
   const int B = p->B, H = c->cfg.horizon, S = c->cfg.state_dim;
   const size_t HS = (size_t)H * S, n = (size_t)B * HS;
   HardConds hc; hc.idx = c->s_hard_idx; hc.val = c->s_hard_val; hc.n = p->n_hard;
@@ -1675,6 +1684,7 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
   ap.win = p->apf.window; ap.thr = p->apf.threshold; ap.strength = p->apf.strength;
   if (c->gemm_mode == 2) {
     hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<unsigned*>(c->range_flag), 1);
+    if (!c->force_x6) hipLaunchKernelGGL(zero_words_kernel, dim3((p->n_steps + 255) / 256), dim3(256), 0, s, reinterpret_cast<unsigned*>(c->trip_log), p->n_steps);
     RAMP_HIP_CHECK(hipGetLastError());
   }
   for (int j = 0; j < p->n_steps; ++j) {
@@ -1682,7 +1692,10 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
       // evaluation 0 runs fp16x3 scaled from the context's CANONICAL maxima (table 2: canonical_calibration below) -- or, with
       // ramp_set_calibration_reuse(ctx, 0), calibrates itself (bf16x6 + recorded operand maxima); evaluation j >= 1 runs fp16x3
       // scaled from j - 1
-      c->phase = (j == 0 && !steady) ? 1 : 2;
+      // (j == cal_eval, cal_eval + 1: the evaluation the range guard flagged first in this job's previous run calibrates instead -- see
+      // ramp_ctx::trip_log -- and so does its successor: an excursion that is gone one step later (a spike) would otherwise trip the guard
+      // again from the other side, its successor being scaled from the spike's maxima; 3 % of a job per calibrating evaluation)
+      c->phase = ((j == 0 && !steady) || j == cal_eval || (cal_eval >= 0 && j == cal_eval + 1)) ? 1 : 2;
       c->obs_out = c->obs + (j & 1) * ramp_ctx::MAX_SITES;
       c->obs_in = c->obs + (j == 0 ? 2 : ((j & 1) ^ 1)) * ramp_ctx::MAX_SITES;
       hipLaunchKernelGGL(zero_words_kernel, dim3(ramp_ctx::MAX_SITES / 256), dim3(256), 0, s,
@@ -1697,6 +1710,10 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
     const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s, shared ? comb : nullptr);
     c->phase = 0;
     CK(rc_score);
+    if (c->gemm_mode == 2 && !c->force_x6) {
+      hipLaunchKernelGGL(log_flag_kernel, dim3(1), dim3(64), 0, s, c->range_flag, c->trip_log, j);
+      RAMP_HIP_CHECK(hipGetLastError());
+    }
     CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = shared ? 1 : p->n_rp;
     m.w0 = (float)p->w0; m.w1 = (float)p->w1; m.w0p1 = (float)(1.0 + p->w0);
     m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised; m.predict_x0 = p->predict_x0 != 0;
@@ -1724,7 +1741,7 @@ static int sample_body(ramp_ctx* c, const ramp_sample_params* p, hipStream_t s, 
 
 // The calibration every job's first evaluation is scaled from (fp16x3 mode): ONE score evaluation on the bf16x6 kernels that only records the
 // operand maxima of every GEMM call site (phase 1) into table 2, on a CANONICAL input -- x ~ N(0, I) from Philox4x32-10 with a fixed seed, the
-// job's hard conditions applied, at the job's first timestep -- not on anybody's data: x_T of every job is a draw of the same distribution, the
+// at the job's first timestep -- not on anybody's data, not even the job's start / goal values: x_T of every job is a draw of the same distribution, the
 // recorded maxima only pick power-of-two scales (the operand may then grow 2^9.9-fold before the range guard fires, elements down to 2^-8 of the
 // maximum keep all 22 bits), and the guard covers a caller whose x_T is something else.  Runs eagerly on the job's stream, outside its graph,
 // once per (batch, first timestep, hard-condition layout, scene).
@@ -1737,9 +1754,9 @@ static int canonical_calibration(ramp_ctx* c, const ramp_sample_params* p, hipSt
     RAMP_HIP_CHECK(hipStreamSynchronize(s));       // (rec is a stack array)
   }
   RAMP_REQUIRE((H * S) % 4 == 0, "H * S must be a multiple of 4");
+  // (round 6, ADVICE r5: NO hard conditions on the canonical input -- with the caller's start / goal applied, table 2 depended on the values of
+  // whichever job triggered it, and a later job with other values inherited scales a fresh context would not have chosen)
   CK(launch_philox_normal(c->s_x, (long)B * H * S, c->c_cal_rec, s));
-  HardConds hc; hc.idx = c->s_hard_idx; hc.val = c->s_hard_val; hc.n = p->n_hard;
-  CK(launch_hard_cond(c->s_x, hc, B, H, S, s));
   c->phase = 1;
   c->obs_out = c->obs + 2 * ramp_ctx::MAX_SITES; c->obs_in = c->obs;
   hipLaunchKernelGGL(zero_words_kernel, dim3(ramp_ctx::MAX_SITES / 256), dim3(256), 0, s, reinterpret_cast<unsigned*>(c->obs_out), ramp_ctx::MAX_SITES);
@@ -1782,6 +1799,10 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
   const bool chain = chain_out != nullptr;
   const size_t n_noise = (p->ddim ? 1 : (size_t)p->n_steps + 1) * n;
   CK(ensure_sampler_buffers(c, B, p->n_rp, p->n_steps, chain));
+  if (p->n_steps > c->trip_log_cap) {
+    float* q; const int cap = std::max(256, p->n_steps);
+    CK(dev_alloc(c, &q, cap)); c->trip_log = reinterpret_cast<int*>(q); c->trip_log_cap = cap; c->graph_key.clear();
+  }
   for (int j = 0; j < p->n_hard; ++j) RAMP_REQUIRE(p->hard_idx_host[j] >= 0 && p->hard_idx_host[j] < H, "hard index out of range");
   if (!c->s_hard_idx) { float* q; CK(dev_alloc(c, &q, 256)); c->s_hard_idx = reinterpret_cast<int*>(q); }
   RAMP_REQUIRE(p->n_hard <= 256, "too many hard conditions");
@@ -1830,41 +1851,68 @@ int ramp_sample(ramp_ctx* c, const ramp_sample_params* p, const float* noise, fl
   steady = h3 && c->cal_reuse;
   c->s_calibrated = false; c->s_pending = false;
   if (steady) {
-    // what the canonical maxima depend on: batch, row variants, first timestep, hard conditions (their values are part of the canonical input)
+    // what the canonical maxima depend on: batch, row variants and their weights, first timestep (the scene and the launch plan invalidate it
+    // where they change) -- nothing of the caller's data
     std::string ck;
     auto putc = [&](const void* q, size_t b) { ck.append(static_cast<const char*>(q), b); };
-    putc(&p->B, 4); putc(&p->n_rp, 4); putc(p->t, 4); putc(&p->n_hard, 4); putc(&p->w0, 8); putc(&p->w1, 8);
-    if (p->n_hard) putc(p->hard_idx_host, 4 * p->n_hard);
+    putc(&p->B, 4); putc(&p->n_rp, 4); putc(p->t, 4); putc(&p->w0, 8); putc(&p->w1, 8);
     const int sp = c->share_prefix; putc(&sp, 4);
+    if (!c->c_cal_valid) {                                  // (scene / plan / mode changed: every saved table is stale; its buffer is reused)
+      for (auto& kv : c->c_cal_saved) c->c_cal_free.push_back(kv.second);
+      c->c_cal_saved.clear();
+    }
     if (!c->c_cal_valid || c->c_cal_key != ck) {
-      CK(canonical_calibration(c, p, s));
+      float* t2 = c->obs + 2 * ramp_ctx::MAX_SITES;
+      auto it = c->c_cal_saved.find(ck);
+      if (it != c->c_cal_saved.end()) {                      // a job shape seen before: its table back into place
+        RAMP_HIP_CHECK(hipMemcpyAsync(t2, it->second, ramp_ctx::MAX_SITES * sizeof(float), hipMemcpyDeviceToDevice, s));
+      } else {
+        CK(canonical_calibration(c, p, s));
+        if (c->c_cal_saved.size() < 16) {
+          float* keep = nullptr;
+          if (!c->c_cal_free.empty()) { keep = c->c_cal_free.back(); c->c_cal_free.pop_back(); }
+          else CK(dev_alloc(c, &keep, ramp_ctx::MAX_SITES));
+          RAMP_HIP_CHECK(hipMemcpyAsync(keep, t2, ramp_ctx::MAX_SITES * sizeof(float), hipMemcpyDeviceToDevice, s));
+          c->c_cal_saved[ck] = keep;
+        }
+      }
       c->c_cal_valid = true; c->c_cal_key = ck;
       c->launches = 0;
     }
   }
+  const int cal_eval = (h3 && c->rerun) ? c->trip_eval : -1;
+  c->last_job_steps = h3 ? p->n_steps : 0;
   if (!p->use_graph) {
-    CK(sample_body(c, p, s, chain, steady));
+    CK(sample_body(c, p, s, chain, steady, cal_eval));
   } else {
     if (key != c->graph_key) {
       for (auto& g : c->graph_exec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-      c->graph_key = key;
+      if (c->graph_rerun) { (void)hipGraphExecDestroy(c->graph_rerun); c->graph_rerun = nullptr; }
+      c->graph_key = key; c->graph_rerun_key.clear();
     }
     const int which = steady ? 1 : 0;
-    if (!c->graph_exec[which]) {
+    hipGraphExec_t* slot = &c->graph_exec[which];
+    if (cal_eval >= 0) {     // the repeat of a flagged job: a graph of its own (kept: a checkpoint that trips at one evaluation does so every job)
+      std::string rk = key; rk.append(reinterpret_cast<const char*>(&cal_eval), 4); rk.append(reinterpret_cast<const char*>(&which), 4);
+      if (rk != c->graph_rerun_key && c->graph_rerun) { (void)hipGraphExecDestroy(c->graph_rerun); c->graph_rerun = nullptr; }
+      c->graph_rerun_key = rk;
+      slot = &c->graph_rerun;
+    }
+    if (!*slot) {
       hipStream_t cs;
       RAMP_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
       RAMP_HIP_CHECK(hipStreamSynchronize(s));
       RAMP_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-      int rc = sample_body(c, p, cs, chain, steady);
+      int rc = sample_body(c, p, cs, chain, steady, cal_eval);
       hipGraph_t g = nullptr;
       hipError_t e = hipStreamEndCapture(cs, &g);
       if (rc != 0) { if (g) (void)hipGraphDestroy(g); (void)hipStreamDestroy(cs); return rc; }
       if (e != hipSuccess) { (void)hipStreamDestroy(cs); RAMP_HIP_CHECK(e); }
-      e = hipGraphInstantiate(&c->graph_exec[which], g, nullptr, nullptr, 0);
+      e = hipGraphInstantiate(slot, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g); (void)hipStreamDestroy(cs);
       RAMP_HIP_CHECK(e);
     }
-    RAMP_HIP_CHECK(hipGraphLaunch(c->graph_exec[which], s));
+    RAMP_HIP_CHECK(hipGraphLaunch(*slot, s));
   }
   if (chain_out) RAMP_HIP_CHECK(hipMemcpyAsync(chain_out, c->s_chain, (size_t)(p->n_steps + 1) * n * 4, hipMemcpyDeviceToDevice, s));
   if (x_out) RAMP_HIP_CHECK(hipMemcpyAsync(x_out, c->s_x, n * 4, hipMemcpyDeviceToDevice, s));
@@ -1907,6 +1955,10 @@ static int replan_body(ramp_ctx* c, const ramp_replan_params* p, hipStream_t s, 
     const int rc_score = score_all(c, c->s_x, B, p->n_rp, p->t[j], nullptr, c->s_eps, s, shared ? comb : nullptr);
     c->phase = 0;
     CK(rc_score);
+    if (c->gemm_mode == 2 && !c->force_x6) {
+      hipLaunchKernelGGL(log_flag_kernel, dim3(1), dim3(64), 0, s, c->range_flag, c->trip_log, j);
+      RAMP_HIP_CHECK(hipGetLastError());
+    }
     CfgMeanArgs m; m.x = c->s_x; m.eps = c->s_eps; m.B = B; m.HS = (int)HS; m.n_rp = shared ? 1 : p->n_rp;
     m.w0 = (float)p->w; m.w1 = 0.f; m.w0p1 = (float)(1.0 + p->w);
     m.sqrt_recip = p->sqrt_recip[j]; m.sqrt_recipm1 = p->sqrt_recipm1[j]; m.clip = p->clip_denoised; m.predict_x0 = p->predict_x0 != 0;
@@ -3216,9 +3268,12 @@ int ramp_profile_read_kernels(ramp_ctx* c, int32_t n, double* ms, double* flops,
   return 0;
 }
 
-int ramp_set_fallback(ramp_ctx* c, int32_t bf16x6_only) {
+int ramp_set_fallback(ramp_ctx* c, int32_t mode) {
   RAMP_REQUIRE(c, "null argument");
-  c->force_x6 = bf16x6_only ? 1 : 0;
+  RAMP_REQUIRE(mode >= 0 && mode <= 2, "ramp_set_fallback: mode 0 (none), 1 (every evaluation on the bf16x6 kernels) or 2 (fp16x3, the flagged evaluation calibrating)");
+  RAMP_REQUIRE(mode != 2 || c->trip_eval >= 0, "ramp_set_fallback(ctx, 2): no flagged evaluation on record (ramp_range_status of a flagged ramp_sample first)");
+  c->force_x6 = mode == 1 ? 1 : 0;
+  c->rerun = mode == 2 ? 1 : 0;
   c->score_calibrated = false; c->r_calibrated = false; c->s_calibrated = false; c->s_pending = false;      // (the canonical table 2 survives: nothing writes it in a bf16x6 job)
   return 0;
 }
@@ -3233,7 +3288,19 @@ int ramp_range_status(ramp_ctx* c, int32_t* flag, void* stream) {
   if (c->range_flag) {
     RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
     RAMP_HIP_CHECK(hipMemcpy(flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (!c->rerun) { c->trip_eval = -1; c->trip_site = -1; }      // (a repeat keeps its predecessor's record: what it was built from)
+    if (*flag && !c->rerun && c->last_job_steps > 0 && c->trip_log) {      // the first evaluation of the last job that left the guard raised
+      std::vector<int> log((size_t)c->last_job_steps);
+      RAMP_HIP_CHECK(hipMemcpy(log.data(), c->trip_log, log.size() * sizeof(int), hipMemcpyDeviceToHost));
+      for (int j = 0; j < c->last_job_steps; ++j) if (log[j]) { c->trip_eval = j; c->trip_site = log[j] - 1; break; }
+    }
   }
+  return 0;
+}
+int ramp_range_trip(ramp_ctx* c, int32_t* eval, int32_t* site) {
+  RAMP_REQUIRE(c && eval, "null argument");
+  *eval = c->trip_eval;
+  if (site) *site = c->trip_site;
   return 0;
 }
 int ramp_set_calibration_reuse(ramp_ctx* c, int32_t on) {

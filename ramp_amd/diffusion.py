@@ -75,6 +75,9 @@ class _GaussianDiffusionBase(nn.Module):
         self.model = model
         self.fp16_fallback = fp16_fallback      # fp16x3 range guard tripped -> repeat the job in bf16x6 (else raise)
         self.range_fallbacks = 0                # jobs / replans the fp16x3 range guard sent to the bf16x6 kernels so far
+        self.range_reruns = 0                   # jobs the guard flagged and that were repeated in fp16x3 (the flagged evaluation calibrating)
+        self.fp16_rerun = True                  # False: a flagged job goes straight to the bf16x6 repeat (rounds 2-5)
+        self.last_job_mode = None               # arithmetic of the last sampling job's RESULT: 'fp16x3', 'fp16x3-rerun', 'bf16x6', 'fp32'
         # "torch": the reference's torch.randn / randn_like draws (sample_functions.py:36; what the parity runs patch);
         # "philox": the job draws its noise INSIDE the captured graph (ramp_sample_params.noise_mode 1), stream
         # (noise_seed, running offset) -- host-replicable through ramp_philox_normal / tests.util.philox_normal
@@ -332,20 +335,41 @@ class _GaussianDiffusionBase(nn.Module):
                                        _lib.current_stream()), "ramp_sample")
             flag = C.c_int32(0)
             _lib.check(lib.ramp_range_status(m.ctx(), C.byref(flag), _lib.current_stream()), "ramp_range_status")
+            self.last_job_mode = {0: "fp16x3", 1: "fp32", 2: "bf16x6", 3: "fp16x3"}[m.gemm_mode]      # (0: the library default)
             if flag.value:
-                # an operand left the range the delayed fp16 scaling assumed: the result is discarded and the same job
-                # (same noise) is repeated with the range-free bf16x6 kernels -- never a silently degraded answer
+                # an operand left the range the delayed fp16 scaling assumed: the result is discarded and the same job (same noise) is
+                # repeated -- never a silently degraded answer.  First IN fp16x3 with the evaluation that raised the guard run as a
+                # calibrating one (range-free, and its successor is scaled from true maxima: ramp_set_fallback(ctx, 2)); only if that
+                # repeat is flagged as well, with every evaluation on the bf16x6 kernels.
                 if not self.fp16_fallback:
                     raise _lib.RampHipError("fp16x3 GEMM: an operand left the fp16 range between two score evaluations "
                                             f"(call site {flag.value - 1}); use gemm_mode='bf16x6'")
-                warnings.warn(f"fp16x3 range guard tripped at GEMM call site {flag.value - 1}: repeating the job in bf16x6")
-                self.range_fallbacks += 1
-                _lib.check(lib.ramp_set_fallback(m.ctx(), 1), "ramp_set_fallback")
-                try:
-                    _lib.check(lib.ramp_sample(m.ctx(), C.byref(p), _lib.ptr(noise), _lib.ptr(chain), _lib.ptr(x_out),
-                                               _lib.current_stream()), "ramp_sample")
-                finally:
-                    _lib.check(lib.ramp_set_fallback(m.ctx(), 0), "ramp_set_fallback")
+                ev, site = C.c_int32(-1), C.c_int32(-1)
+                _lib.check(lib.ramp_range_trip(m.ctx(), C.byref(ev), C.byref(site)), "ramp_range_trip")
+
+                def again(mode):
+                    _lib.check(lib.ramp_set_fallback(m.ctx(), mode), "ramp_set_fallback")
+                    try:
+                        _lib.check(lib.ramp_sample(m.ctx(), C.byref(p), _lib.ptr(noise), _lib.ptr(chain), _lib.ptr(x_out),
+                                                   _lib.current_stream()), "ramp_sample")
+                        f2 = C.c_int32(0)
+                        _lib.check(lib.ramp_range_status(m.ctx(), C.byref(f2), _lib.current_stream()), "ramp_range_status")
+                    finally:
+                        _lib.check(lib.ramp_set_fallback(m.ctx(), 0), "ramp_set_fallback")
+                    return f2.value
+
+                again_flag = 1
+                if ev.value >= 0 and self.fp16_rerun:
+                    warnings.warn(f"fp16x3 range guard tripped in evaluation {ev.value} (GEMM call site {site.value}): repeating the job "
+                                  "in fp16x3 with that evaluation calibrating")
+                    self.range_reruns += 1
+                    again_flag = again(2)
+                    self.last_job_mode = "fp16x3-rerun"
+                if again_flag:
+                    warnings.warn(f"fp16x3 range guard tripped at GEMM call site {flag.value - 1}: repeating the job in bf16x6")
+                    self.range_fallbacks += 1
+                    again(1)
+                    self.last_job_mode = "bf16x6"
         return x_out, chain
 
     # ------------------------------------------------------------------ loops (reference signatures)
