@@ -239,7 +239,8 @@ def profile_gemm(dm, B, cloud, hard_conds):
     return out
 
 
-PMC_FILE = "profiles/r05_pmc_traffic.json"
+PMC_FILE = next((f for f in ("profiles/r06_pmc_traffic.json", "profiles/r05_pmc_traffic.json")
+                 if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), f))), "profiles/r06_pmc_traffic.json")
 SUSTAINED_FP32EQ_TFLOPS = 510.0        # profiles/r02_power_clocks.txt, r03_power_clocks.txt: the bare fp16x3 MFMA + LDS-read loop sustains 491-530 TFLOP/s (fp32-
                                        # equivalent) at the 1.4 kW socket limit, i.e. 0.59-0.64 of the 833.3 nominal ceiling
 STASH_BYTES_PER_ROW_EVAL = 4.0e6       # what ONE score evaluation must keep per network row for the input
@@ -552,14 +553,18 @@ def main():
         avg_us = fx_ms * 1e3 / max(fx_n, 1)
         result["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            # field history, so that round-over-round parsers do not mix definitions: rounds 1-4 `frac` = the whole split-precision
+            # GEMM class (now `class_frac`); round 5 on `frac` = `frac_ffx` = the dominant kernel pair alone
+            "frac_ffx": achieved / peak, "frac_definition": "dominant kernel pair (fused feed-forward) since round 5; rounds 1-4: class_frac",
             "traffic": traffic, "traffic_source": traffic_src,
             "hbm_frac": (traffic / (avg_us * 1e-6) / 1e12 / PEAK_HBM_TBS) if traffic else None,
-            "kernel": "ramp::ffx_kernel<BWD = false | true> (ffx.hip): LN3 -> FF1 -> GEGLU -> FF2 + residual and its input gradient as "
-                      "token-owning waves, all 16 transformer blocks, forward and dX; 1.573 MFLOP (algorithmic, fp32) per token and direction",
+            "kernel": "ramp::ffx16_kernel<BWD = false | true> (ffx16.hip, v_mfma_f32_16x16x32_f16; ramp_launch_plan.mfma16 = 0: ramp::ffx_kernel, "
+                      "ffx.hip, 32x32x16): LN3 -> FF1 -> GEGLU -> FF2 + residual and its input gradient as token-owning waves, all 16 transformer "
+                      "blocks, forward and dX; 1.573 MFLOP (algorithmic, fp32) per token and direction",
             "peak_note": "achieved = ALGORITHMIC fp32 FLOPs of the ffx launches (tokens x 1.573 MFLOP) / their summed HIP-event time on the "
                          "launch stream; peak = the pipe the kernel executes on, fp16 dense MFMA 2500 TFLOP/s, divided by the 3 fp16 "
-                         "products it spends per fp32 product (833.3); recompute from profiles/r05_kernel_stats.csv: "
-                         "sum(tokens) x 1.573e6 / TotalDurationNs of the two ffx_kernel rows",
+                         "products it spends per fp32 product (833.3); recompute from profiles/r06_kernel_stats.csv: "
+                         "sum(tokens) x 1.573e6 / TotalDurationNs of the two ffx16_kernel rows",
             "executed_fp16_tflops": FP16_PRODUCTS_PER_FP32 * achieved,
             "frac_vs_fp32_matrix_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
             "launches_per_step": fx_n, "avg_launch_us": avg_us,
@@ -580,7 +585,9 @@ def main():
             "sustained_ceiling_tflops": SUSTAINED_FP32EQ_TFLOPS,
             "frac_of_sustained": achieved / SUSTAINED_FP32EQ_TFLOPS,
             "class_note": "the GEMM class mixes fp16x3 launches (833.3 ceiling) with the exact-fp32 N = 32 layers (157.3 ceiling) and, in a "
-                          "job that calibrates, bf16x6 launches: class_frac is a lower bound for the fp16x3 kernels",
+                          "job that calibrates, bf16x6 launches: class_frac is a lower bound for the fp16x3 kernels; the fused tkw / tkc launches "
+                          "carry their GroupNorm + Mish TIME inside the class while only the convolution FLOPs are counted (round 5 on), so the "
+                          "class figure is deflated by that much and `norm_rows` shrank partly for accounting reasons",
             "kernel_time_ms_by_class": {k: round(v["ms"], 3) for k, v in prof.items()},
         }
     elif rank == 0:

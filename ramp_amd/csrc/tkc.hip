@@ -380,7 +380,8 @@ void tkc_kernel(TkcArgs a, int n_tiles) {
   amax = fmaxf(amax, __shfl_xor(amax, 4)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 1));
   // ONE atomic per block, behind a plain read of the slot (2048 same-address atomics at the tail of a 20-40 us launch cost 20 us: common.h)
   __syncthreads();
-  record_amax_block_guarded<true>(a.amax_out, amax, reinterpret_cast<float*>(smem + WBYTES), a.range_flag, s_in, a.site);
+  // (exact mode: every tile was scaled from its own maximum -- nothing can be out of range, and s_in is just the LAST tile's scale: no guard)
+  record_amax_block_guarded<true>(a.amax_out, amax, reinterpret_cast<float*>(smem + WBYTES), exact ? nullptr : a.range_flag, s_in, a.site);
 }
 
 bool tkc_applicable(int M, int L, int N, int K, int* ng) {

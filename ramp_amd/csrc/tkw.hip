@@ -439,7 +439,7 @@ namespace {
 bool tw_geometry(int L, int N, int K, TwGeom* g) {
   if (L < 3 || TW_TB % L != 0) return false;
   if (!(N == 128 || N == 256 || N == 512)) return false;
-  if (K < 32 || K % 32 != 0 || K > 512) return false;
+  if (K < 32 || K > 512 || (K & (K - 1)) != 0) return false;      // powers of two only: the tap / chunk indexing shifts and masks by K / 32, KC / 32 (K = 96 indexed taps up to 7)
   const int rows = TW_TB + 2 * (TW_TB / L + 1);
   // chunks of at most 128 operand channels: the tile (rows x (4 KC + 16) bytes) then leaves room for TWO blocks per CU (2 x 78 KB), so that one
   // block's staging / epilogue (memory latency, GroupNorm arithmetic) runs beside the other's MFMA phase -- with one wave per SIMD nothing overlaps

@@ -97,6 +97,16 @@ def test_config2_full_size_against_embedded_reference_trajectories():
     _free(dm, d4)
 
 
+def _golden_rows_exact_fp32(cls, S, H, T, g, n_rows):
+    """The embedded golden rows alone (B = n_rows) on the exact-fp32 MFMA mode -- the one mode whose arithmetic is the reference's -- free-running:
+    the bars of the full-size fp16x3 job are asserted on it too; rows are independent, so B does not matter."""
+    u = build_unet(S, H, True, max_rows=2 * n_rows, gemm_mode="fp32")
+    dm = cls(model=u, n_diffusion_steps=T, predict_epsilon=True, use_graph=True).eval().to("cuda")
+    c = _run(dm, [torch.from_numpy(n).cuda() for n in g["noise"]], dev(g["cloud"]), n_rows).cpu().numpy()
+    _free(dm)
+    return c
+
+
 def test_config3_full_size_against_embedded_reference_trajectories():
     """BASELINE configs[2]: Maze3D, B = 4096, H = 48, S = 6, T = 25 DDPM, w = 5.75, 20 x 200 = 4000-point cloud."""
     from ramp_amd.models import GaussianDiffusionModel3d
@@ -124,6 +134,10 @@ def test_config3_full_size_against_embedded_reference_trajectories():
     # from the reference (whose own chain is 2.4e-4 from the truth).  Bars: as close to the truth as 3 x the reference's own distance and
     # 2 x the worst measured; the sharp accuracy statement is per step (tests/test_gpu_sampler.py, assert_as_accurate_as_the_reference)
     assert e_gpu < 3 * e_ref and e_gpu < 2.5e-4 and err.max() < 4.5e-4
+    c32 = _golden_rows_exact_fp32(GaussianDiffusionModel3d, 6, 48, 25, g, 2)
+    e32 = np.abs(c32 - truth).max(); r32 = np.abs(c32 - g["chain"]).max()
+    print(f"   the same rows on the exact-fp32 MFMA mode: vs reference {r32:.2e}, vs float64 truth {e32:.2e} (ratio {e32 / e_ref:.2f})")
+    assert e32 < 3 * e_ref and e32 < 2.5e-4 and r32 < 4.5e-4                # the SAME bars: they describe the chain, not the emulation
     hcb = {k: torch.from_numpy(v).cuda().unsqueeze(0).expand(B, -1) for k, v in synth.default_hard_conds(6, 48).items()}
     tf = []                                                      # EVERY step from the reference's own previous state
     for j in range(25):
@@ -157,6 +171,10 @@ def test_config5_per_gpu_shard_full_size():
     print(f"config 5 shard: embedded golden rows free-running max {err.max():.2e} (final {err[-1]:.2e}); vs float64 truth: reference {e_ref:.2e}, HIP {e_gpu:.2e} (ratio {e_gpu / e_ref:.2f})")
     # (chaotic, see config 3: measured 5.6e-4 from the truth (the reference itself: 4.3e-4), 6.6e-4 from the reference; T = 50 steps of 12x amplification)
     assert e_gpu < 3 * e_ref and e_gpu < 1.1e-3 and err.max() < 1.3e-3
+    c32 = _golden_rows_exact_fp32(GaussianDiffusionModel3d, 6, 64, 50, g, 2)
+    e32 = np.abs(c32 - truth).max(); r32 = np.abs(c32 - g["chain"]).max()
+    print(f"   the same rows on the exact-fp32 MFMA mode: vs reference {r32:.2e}, vs float64 truth {e32:.2e} (ratio {e32 / e_ref:.2f})")
+    assert e32 < 3 * e_ref and e32 < 1.1e-3 and r32 < 1.3e-3                # the SAME bars: they describe the chain, not the emulation
     hcb = {k: torch.from_numpy(v).cuda().unsqueeze(0).expand(B, -1) for k, v in synth.default_hard_conds(6, 64).items()}
     tf = []                                                      # EVERY step from the reference's own previous state
     for j in range(50):

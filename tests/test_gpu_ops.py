@@ -569,6 +569,47 @@ def test_abl_attention_backward_with_ln1_backward_against_float64_autograd(L, R)
     assert flag2 == 1
 
 
+def test_abl_per_sample_accuracy_under_a_magnitude_spread():
+    """The documented trade-off of one power-of-two scale per operand TENSOR, measured per sample: the sample-owning kernels
+    judge "operand shrank" on the block's maximum, so a trajectory whose gradients are 2^10 below its batch neighbours' raises no flag; its
+    d(qkv) tiles then sit 2^10 below the scale's target and keep 11 + 1 significand bits instead of 22 -- an ABSOLUTE accuracy of 2^-30 of the
+    tensor's maximum, i.e. ~2^-20 relative to that sample's own.  ramp_op_abl, L = 48, 8 samples, sample 5's d(o) scaled by 2^-10: every
+    sample's error relative to ITS OWN largest gradient, the quiet sample's next to the others'."""
+    import ctypes as C
+    from ramp_amd import _lib
+    L, R = 48, 8
+    M = R * L
+    gen = torch.Generator(device="cpu").manual_seed(4711)
+    z = (torch.randn(M, 256, generator=gen) * 1.5 + 0.3)
+    ln_g = 1.0 + 0.2 * torch.randn(256, generator=gen)
+    ln_b = 0.1 * torch.randn(256, generator=gen)
+    Wqkv = torch.randn(768, 256, generator=gen) / 16.0
+    dout = torch.randn(M, 256, generator=gen)
+    dout[5 * L:6 * L] *= 2.0 ** -10
+    zd = z.double().clone().requires_grad_(True)
+    ln = torch.nn.functional.layer_norm(zd, (256,), ln_g.double(), ln_b.double(), 1e-5)
+    qkv64 = ln @ Wqkv.double().t()
+    y = qkv64.reshape(R, L, 3, 4, 64)
+    q, k, v = y[:, :, 0].transpose(1, 2), y[:, :, 1].transpose(1, 2), y[:, :, 2].transpose(1, 2)
+    o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).transpose(1, 2).reshape(M, 256)
+    o.backward(dout.double())
+    ref = zd.grad.numpy().reshape(R, L * 256)
+    got = torch.full((M, 256), float("nan"), device="cuda")
+    amax, flag = C.c_float(0), C.c_int32(0)
+    add = torch.zeros(M, 256, device="cuda")
+    lib = _lib.load()
+    args = (_lib.ptr(qkv64.detach().float().cuda()), _lib.ptr(dout.cuda()), _lib.ptr(Wqkv.t().contiguous().cuda()), _lib.ptr(z.cuda()), _lib.ptr(ln_g.cuda()), _lib.ptr(add))
+    _lib.check(lib.ramp_op_abl(*args, M, L, 0.0, _lib.ptr(got), C.byref(amax), C.byref(flag), None), "ramp_op_abl")
+    _lib.check(lib.ramp_op_abl(*args, M, L, amax.value, _lib.ptr(got), C.byref(amax), C.byref(flag), None), "ramp_op_abl")      # scaled from the tensor maximum
+    assert flag.value == 0                                         # no guard trip: the block's maximum is in range
+    out = got.cpu().numpy().astype(np.float64).reshape(R, L * 256)
+    per = np.abs(out - ref).max(1) / np.abs(ref).max(1)
+    print("abl, per-sample error relative to the sample's own largest gradient: " + " ".join(f"{e:.1e}" for e in per) + "  (sample 5: d(o) x 2^-10)")
+    others = np.delete(per, 5)
+    assert others.max() < 4e-6                                     # fp32 rounding, as everywhere
+    assert per[5] < 2.0 ** -17, per[5]                             # 2^-30 of the tensor maximum = 2^-20 of its own, with head room for the accumulation
+
+
 @pytest.mark.parametrize("L,R,N,K,extras", [(48, 3, 32, 32, True), (48, 9, 64, 64, True), (24, 7, 64, 32, False), (24, 8, 32, 64, True), (12, 33, 64, 64, True),
                                             (16, 5, 64, 64, False), (32, 3, 32, 32, True), (8, 41, 64, 64, True), (48, 4096, 32, 32, True)])
 @pytest.mark.parametrize("backward", [False, True])
@@ -811,6 +852,23 @@ def test_tkw_conv_groupnorm_mish_forward(L, K, N, R, K1, extras):
     es = max(rel(st[:, :, 0].cpu().numpy(), mean), rel(st[:, :, 1].cpu().numpy(), rstd))
     print(f"tkw fwd L={L} {K}->{N} rows={R} extras={extras}: stash {ec:.2e} stats {es:.2e} y {ey:.2e}")
     assert ec < 3e-6 and es < 3e-6 and ey < 5e-6
+
+
+def test_tkw_refuses_operand_widths_that_are_not_powers_of_two():
+    """the kernel's tap / chunk indexing shifts and masks by K / 32 and KC / 32, so K = 96 (a multiple of 32 that used to pass
+    the geometry check) indexed taps up to 7 and read past the weight planes; K = 384 broke the GroupNorm-backward group reduction.  The
+    network never has such widths (channels are 32 x 2^k); through ramp_op_tkw they must be an error return, not a silent wrong result."""
+    for K, N in ((96, 128), (384, 256), (160, 128)):
+        M, L = 96, 6
+        X = torch.randn(M, K, device="cuda"); W = torch.randn(5, N, K, device="cuda"); Y = torch.empty(M, N, device="cuda")
+        Cs = torch.empty(M, N, device="cuda"); st = torch.empty(M // L, 8, 2, device="cuda")
+        b = torch.zeros(N, device="cuda"); gam = torch.ones(N, device="cuda")
+        amax, flag = C.c_float(0.0), C.c_int32(0)
+        rc = _lib.load().ramp_op_tkw(_lib.ptr(X), None, 0, _lib.ptr(W), _lib.ptr(b), None, None, None, None, None, None,
+                                     _lib.ptr(gam), _lib.ptr(b), None, M, L, N, K, 1, N, 1.0, _lib.ptr(Y), None, _lib.ptr(Cs), _lib.ptr(st),
+                                     C.byref(amax), C.byref(flag), S())
+        assert rc != 0, (K, N)
+        assert "tkw" in _lib.load().ramp_last_error().decode()
 
 
 TKW_BWD = [   # L, K (= C_out of the forward layer), N (= C_in), samples, N1 (output split)
