@@ -598,7 +598,8 @@ def test_abl_per_sample_accuracy_under_a_magnitude_spread():
     amax, flag = C.c_float(0), C.c_int32(0)
     add = torch.zeros(M, 256, device="cuda")
     lib = _lib.load()
-    args = (_lib.ptr(qkv64.detach().float().cuda()), _lib.ptr(dout.cuda()), _lib.ptr(Wqkv.t().contiguous().cuda()), _lib.ptr(z.cuda()), _lib.ptr(ln_g.cuda()), _lib.ptr(add))
+    keep = (qkv64.detach().float().cuda(), dout.cuda(), Wqkv.t().contiguous().cuda(), z.cuda(), ln_g.cuda(), add)      # (alive across the launches)
+    args = tuple(_lib.ptr(t_) for t_ in keep)
     _lib.check(lib.ramp_op_abl(*args, M, L, 0.0, _lib.ptr(got), C.byref(amax), C.byref(flag), None), "ramp_op_abl")
     _lib.check(lib.ramp_op_abl(*args, M, L, amax.value, _lib.ptr(got), C.byref(amax), C.byref(flag), None), "ramp_op_abl")      # scaled from the tensor maximum
     assert flag.value == 0                                         # no guard trip: the block's maximum is in range
