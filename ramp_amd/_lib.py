@@ -10,6 +10,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libramp_hip.so")
+TOOLS_LIB_PATH = os.path.join(HERE, "lib", "libramp_hip_tools.so")
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -122,8 +123,6 @@ PROTOTYPES = {
     "ramp_op_abl": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_tkw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 11 + [C.c_int32] * 6 + [C.c_float] + [C.c_void_p] * 4 + [c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_tklb": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
-    "ramp_bench_gemm": (C.c_int, [C.c_int32] * 9 + [c_f32p, C.c_void_p]),
-    "ramp_stress_gemm": (C.c_int, [C.c_int32] * 8 + [c_i64p, c_f32p, C.c_void_p]),
     "ramp_op_groupnorm": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p]),
     "ramp_op_groupnorm_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p]),
     "ramp_op_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]),
@@ -144,7 +143,14 @@ PROTOTYPES = {
     "ramp_launch_count": (C.c_int, [C.c_void_p, c_i64p]),
 }
 
+# Diagnostics, exported by ramp_amd/lib/libramp_hip_tools.so only (csrc/bench.hip: the product library carries no harness code)
+TOOL_PROTOTYPES = {
+    "ramp_bench_gemm": (C.c_int, [C.c_int32] * 9 + [c_f32p, C.c_void_p]),
+    "ramp_stress_gemm": (C.c_int, [C.c_int32] * 8 + [c_i64p, c_f32p, C.c_void_p]),
+}
+
 _lib: Optional[C.CDLL] = None
+_tools: Optional[C.CDLL] = None
 
 
 class RampHipError(RuntimeError):
@@ -176,9 +182,35 @@ def load() -> C.CDLL:
     return lib
 
 
+def load_tools() -> C.CDLL:
+    """The tools library: every object of the product library plus the micro-benchmark / stress harness (ramp_bench_gemm,
+    ramp_stress_gemm; csrc/bench.hip).  For tests/ and ramp_amd/tools/ only -- nothing in the product path imports it."""
+    global _tools
+    if _tools is not None:
+        return _tools
+    import torch  # noqa: F401  (one HIP runtime per process: see load())
+    path = os.environ.get("RAMP_HIP_TOOLS_LIB") or TOOLS_LIB_PATH
+    if not os.path.exists(path):
+        raise RampHipError(f"{path} not found: build it with `python -m ramp_amd.build`")
+    lib = C.CDLL(path)
+    for name, (res, args) in list(PROTOTYPES.items()) + list(TOOL_PROTOTYPES.items()):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _tools = lib
+    return lib
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().ramp_last_error()
+        raise RampHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def check_tools(rc: int, what: str = "") -> None:
+    """check() for a call made through load_tools() (each library keeps its own thread-local error message)."""
+    if rc != 0:
+        msg = load_tools().ramp_last_error()
         raise RampHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 

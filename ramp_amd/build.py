@@ -10,7 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libramp_hip.so")
-SOURCES = ["gemm.hip", "ffx.hip", "ffx16.hip", "tkl.hip", "atk.hip", "atl.hip", "tkc.hip", "tkw.hip", "rowops.hip", "attention.hip", "sampler.hip", "scene.hip", "metrics.hip", "engine.hip"]
+TOOLS_LIB = os.path.join(LIBDIR, "libramp_hip_tools.so")
+# the product library: kernels + engine.hip (context, schedule, sampler, graphs) + ops.hip (context-free kernel-level entry points)
+SOURCES = ["gemm.hip", "ffx.hip", "ffx16.hip", "tkl.hip", "atk.hip", "atl.hip", "tkc.hip", "tkw.hip", "rowops.hip", "attention.hip", "sampler.hip", "scene.hip", "metrics.hip", "engine.hip", "ops.hip"]
+# the tools library = the same objects + the micro-benchmark / stress harness (ramp_bench_gemm, ramp_stress_gemm): tests/ and ramp_amd/tools/ only
+TOOLS_SOURCES = ["bench.hip"]
 # default GEMM mode 2 = fp16x3 split with delayed operand scaling, 1 = bf16x6 split (both fp32-accurate, see gemm.hip);
 # 0 = exact fp32 MFMA
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DRAMP_DEFAULT_GEMM_MODE=2"]
@@ -41,7 +45,7 @@ def stale_sources(force: bool = False):
     objdir = os.path.join(LIBDIR, "obj")
     headers = header_deps()
     jobs = []
-    for src in SOURCES:
+    for src in SOURCES + TOOLS_SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(op, [sp] + headers):
@@ -70,13 +74,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if verbose:
                     print(f"[ramp_amd.build] compiled {os.path.basename(sp)}", file=sys.stderr)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-        if verbose:
-            print(f"[ramp_amd.build] linked {LIB}", file=sys.stderr)
+    tobjs = objs + [os.path.join(objdir, s.replace(".hip", ".o")) for s in TOOLS_SOURCES]
+    for lib, oo in ((LIB, objs), (TOOLS_LIB, tobjs)):
+        if force or jobs or _stale(lib, oo):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + oo
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+            if verbose:
+                print(f"[ramp_amd.build] linked {lib}", file=sys.stderr)
     return LIB
 
 

@@ -6,8 +6,7 @@
 // (UnetInference.py:176-224) and EnergyGradFunction (UnetInference.py:19-37) whose
 // autograd.grad is replaced by the explicit dX chain below (all parameters are frozen, so no
 // dW / db products exist anywhere).
-#include "common.h"
-#include "../../include/ramp_hip.h"
+#include "engine_util.h"
 
 #include <algorithm>
 #include <array>
@@ -35,57 +34,6 @@ int device_cu_count() {
   return cached[dev];
 }
 const char* last_error_cstr() { return g_err.c_str(); }
-
-// ---------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------
-__global__ void permute3_kernel(const float* __restrict__ in, float* __restrict__ out, int D0, int D1, int D2,
-                                int p0, int p1, int p2) {
-  // out[i_p0][i_p1][i_p2] = in[i0][i1][i2]
-  const long n = (long)D0 * D1 * D2;
-  const int dims[3] = {D0, D1, D2};
-  const int O1 = dims[p1], O2 = dims[p2];
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
-    int i[3];
-    i[2] = (int)(idx % D2); i[1] = (int)((idx / D2) % D1); i[0] = (int)(idx / ((long)D1 * D2));
-    out[((long)i[p0] * O1 + i[p1]) * O2 + i[p2]] = in[idx];
-  }
-}
-// (a kernel node rather than a memset node: in the T = 50 jobs (config 5) the memset nodes of the captured graph were
-//  replayed with a stale fill pattern -- 0x1c1c1c1c instead of 0 -- on ROCm 7.2; eager runs and T = 25 graphs were fine)
-__global__ void log_flag_kernel(const int* __restrict__ flag, int* __restrict__ log, int j) { if (threadIdx.x == 0) log[j] = *flag; }
-__global__ void zero_words_kernel(unsigned* __restrict__ p, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = 0u;
-}
-// rows of ff.net.0.proj (2F, K) -> tiles of [G a-rows | G matching g-rows] (EPI_GEGLU_FWD; G = 64 for the block-level LDS
-// epilogue, 32 for the wave-private epilogue of the pipelined kernels); K = 1 for the bias
-__global__ void geglu_pack_kernel(const float* __restrict__ in, float* __restrict__ out, int F, int K, int G) {
-  const long n = (long)2 * F * K;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
-    const int p = (int)(idx / K), k = (int)(idx - (long)p * K);
-    const int t = p / (2 * G), c = p - t * 2 * G;
-    const int src = c < G ? G * t + c : F + G * t + (c - G);
-    out[idx] = in[(long)src * K + k];
-  }
-}
-__global__ void fill_pattern_kernel(int* out, const int* pat, int n_pat, int n) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = pat[i % n_pat];
-}
-
-struct DevArena {
-  std::vector<void*> blocks;
-  size_t total = 0;
-  ~DevArena() { for (void* p : blocks) (void)hipFree(p); }
-  float* alloc(size_t n_floats) {
-    void* p = nullptr;
-    size_t bytes = std::max<size_t>(n_floats, 4) * sizeof(float);
-    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    blocks.push_back(p);
-    total += bytes;
-    return static_cast<float*>(p);
-  }
-};
 
 struct ConvW {       // k=5 conv as 5-tap GEMM
   float* fwd = nullptr;   // [5][Cout][Cin]
@@ -274,7 +222,6 @@ static void prof_post(ramp_ctx* c, hipStream_t s) {
 
 namespace {
 
-#define CK(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
 
 int dev_alloc(ramp_ctx* c, float** out, size_t n) {
   *out = c->arena.alloc(n);
@@ -1143,7 +1090,6 @@ int encode_scene_3d(ramp_ctx* c, const float* cloud, int No, int Np, float* out,
   return 0;
 }
 
-hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
 int ensure_sampler_buffers(ramp_ctx* c, int B, int n_rp, int n_steps, bool chain) {
   const size_t HS = (size_t)c->cfg.horizon * c->cfg.state_dim;
@@ -2138,1069 +2084,6 @@ int ramp_replan_costs(ramp_ctx* c, int32_t B, int32_t* mask_out, float* path_len
   RAMP_HIP_CHECK(hipMemcpyAsync(path_len_out, c->r_plen, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
   RAMP_HIP_CHECK(hipMemcpyAsync(smooth_out, c->r_smooth, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
   return 0;
-}
-
-// ---- kernel-level entry points ---------------------------------------------------------------------
-// The context-free entry points take small HOST arrays (window weights, waypoint indices).  They are staged through a
-// per-thread ring of device slots allocated once, so a call neither allocates nor synchronises; a slot is reused after
-// RING calls, by which time the stream-ordered kernel that read it has long been submitted behind 63 others.
-namespace {
-struct HostArgRing {
-  static constexpr int RING = 64, SLOT = 1024;       // bytes per slot: 129 window weights or 256 indices
-  // one ring per device (a thread that alternates devices keeps both); every slot carries the event recorded behind the
-  // kernel that reads it, on whatever stream that was: before a slot is reused the event is waited for, so calls on
-  // different streams cannot overwrite an array an earlier kernel has not read yet (normally complete long ago: 63 calls)
-  struct PerDevice { char* base = nullptr; int next = 0; hipEvent_t ev[RING] = {}; bool used[RING] = {}; };
-  std::map<int, PerDevice> rings;
-  int cur_dev = -1, cur_slot = -1;
-  int stage(const void* host, size_t bytes, hipStream_t s, void** out) {
-    RAMP_REQUIRE(bytes <= (size_t)SLOT, "host argument array too long");
-    int dev = 0; RAMP_HIP_CHECK(hipGetDevice(&dev));
-    PerDevice& r = rings[dev];
-    if (!r.base) RAMP_HIP_CHECK(hipMalloc(&r.base, (size_t)RING * SLOT));
-    const int slot = r.next++ % RING;
-    if (r.used[slot]) RAMP_HIP_CHECK(hipEventSynchronize(r.ev[slot]));
-    else { RAMP_HIP_CHECK(hipEventCreateWithFlags(&r.ev[slot], hipEventDisableTiming)); r.used[slot] = true; }
-    char* p = r.base + (size_t)slot * SLOT;
-    RAMP_HIP_CHECK(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, s));
-    *out = p; cur_dev = dev; cur_slot = slot;
-    return 0;
-  }
-  // after the kernel that reads the staged array has been launched on `s`
-  int done(hipStream_t s) {
-    if (cur_slot >= 0) RAMP_HIP_CHECK(hipEventRecord(rings[cur_dev].ev[cur_slot], s));
-    cur_slot = -1;
-    return 0;
-  }
-};
-thread_local HostArgRing g_ring;
-}  // namespace
-
-int ramp_apf(float* traj, int32_t B, int32_t H, int32_t S, const ramp_apf_params* p, void* stream) {
-  RAMP_REQUIRE(traj && p && p->cloud && p->window_weights_host, "null argument");
-  RAMP_REQUIRE(p->window >= 0 && p->window <= 64, "bad window");
-  hipStream_t s = as_stream(stream);
-  void* w = nullptr;
-  CK(g_ring.stage(p->window_weights_host, (2 * p->window + 1) * 4, s, &w));
-  ApfArgs a; a.traj = traj; a.cloud = p->cloud; a.window = static_cast<const float*>(w); a.B = B; a.H = H; a.S = S;
-  a.P = p->n_points; a.win = p->window; a.thr = p->threshold; a.strength = p->strength;
-  for (int q = 0; q < std::max(1, p->passes); ++q) CK(launch_apf(a, s));
-  return g_ring.done(s);
-}
-
-int ramp_apf_dynamic(float* traj, int32_t B, int32_t H, int32_t S, const double* points, int32_t n_points,
-                     double thr_query, double thr_force, double strength, int32_t window, int32_t affected,
-                     const float* goal, const int32_t* enable, void* stream) {
-  RAMP_REQUIRE(traj && points, "null argument");
-  ApfDynArgs a; a.traj = traj; a.points = points; a.goal = goal; a.enable = enable; a.B = B; a.H = H; a.S = S;
-  a.P = n_points; a.window = window; a.affected = affected; a.thr_query = thr_query; a.thr_force = thr_force;
-  a.strength = strength;
-  return launch_apf_dynamic(a, as_stream(stream));
-}
-
-int ramp_hard_cond(float* x, int32_t B, int32_t H, int32_t S, int32_t n, const int32_t* idx_host, const float* val,
-                   void* stream) {
-  RAMP_REQUIRE(x && (n == 0 || (idx_host && val)), "null argument");
-  if (n == 0) return 0;
-  RAMP_REQUIRE(n <= 256, "too many hard conditions");
-  for (int j = 0; j < n; ++j) RAMP_REQUIRE(idx_host[j] >= 0 && idx_host[j] < H, "hard index out of range");
-  hipStream_t s = as_stream(stream);
-  void* d = nullptr;
-  CK(g_ring.stage(idx_host, (size_t)n * 4, s, &d));
-  HardConds hc; hc.idx = static_cast<const int*>(d); hc.val = val; hc.n = n;
-  CK(launch_hard_cond(x, hc, B, H, S, s));
-  return g_ring.done(s);
-}
-
-int ramp_traj_costs(const float* traj, int32_t B, int32_t H, int32_t S, const float* cloud, int32_t n_points,
-                    float threshold, int32_t* mask, float* path_len, float* smooth, void* stream) {
-  RAMP_REQUIRE(traj && cloud && mask && path_len && smooth, "null argument");
-  return launch_traj_costs(traj, cloud, B, H, S, n_points, threshold, mask, path_len, smooth, as_stream(stream));
-}
-int ramp_traj_metrics(const float* traj, int32_t B, int32_t H, int32_t S, const float* box_centers, const float* box_sizes,
-                      int32_t n_boxes, float* intensity, float* path_len, float* smooth, void* stream) {
-  RAMP_REQUIRE(traj && intensity && path_len && smooth && (n_boxes == 0 || (box_centers && box_sizes)), "null argument");
-  return launch_traj_metrics(traj, B, H, S, box_centers, box_sizes, n_boxes, intensity, path_len, smooth, as_stream(stream));
-}
-int ramp_waypoint_variance(const float* traj, int32_t B, int32_t H, int32_t S, double* scratch, double* out, void* stream) {
-  RAMP_REQUIRE(traj && scratch && out, "null argument");
-  return launch_waypoint_variance(traj, B, H, S, scratch, out, as_stream(stream));
-}
-
-int ramp_cfg_mean(const float* x, const float* eps, int32_t B, int32_t HS, int32_t n_rp, double w0, double w1,
-                  float sqrt_recip, float sqrt_recipm1, float coef1, float coef2, int32_t clip, int32_t predict_x0, float* x0_out,
-                  float* mean_out, float* ecomb_out, void* stream) {
-  RAMP_REQUIRE(x && eps, "null argument");
-  CfgMeanArgs m; m.x = x; m.eps = eps; m.B = B; m.HS = HS; m.n_rp = n_rp; m.w0 = (float)w0; m.w1 = (float)w1;
-  m.w0p1 = (float)(1.0 + w0); m.sqrt_recip = sqrt_recip; m.sqrt_recipm1 = sqrt_recipm1; m.coef1 = coef1; m.coef2 = coef2;
-  m.clip = clip; m.predict_x0 = predict_x0 != 0; m.x0 = x0_out; m.mean = mean_out; m.ecomb = ecomb_out;
-  return launch_cfg_mean(m, as_stream(stream));
-}
-
-int ramp_ddim_finish(const float* x, const float* x0, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
-                     float dir_coef, float* x_out, int32_t B, int32_t H, int32_t S, void* stream) {
-  RAMP_REQUIRE(x && x0 && x_out, "null argument");
-  HardConds hc;
-  return launch_ddim_finish(x, x0, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, dir_coef, hc, x_out, nullptr, B, H, S,
-                            as_stream(stream));
-}
-
-int ramp_op_gemm(const float* A, const float* W, const float* bias, const float* resid, float* C, int32_t M, int32_t N,
-                 int32_t K, int32_t taps, int32_t shift0, int32_t shift_step, int32_t L, void* stream) {
-  return ramp_op_gemm_mode(A, W, bias, resid, C, M, N, K, taps, shift0, shift_step, L, 0, 0.f, nullptr, nullptr, stream);
-}
-
-int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const float* resid, float* C, int32_t M,
-                      int32_t N, int32_t K, int32_t taps, int32_t shift0, int32_t shift_step, int32_t L, int32_t mode,
-                      float a_absmax_prev, float* a_absmax_out_host, int32_t* range_flag_out_host, void* stream) {
-  RAMP_REQUIRE(A && W && C, "null argument");
-  RAMP_REQUIRE(mode >= 0 && mode <= 5 && mode != 4, "mode: 0 fp32, 1 bf16x6, 2 bf16x6 (LDS-staged weights), 3 fp16x3, 5 fp16x3 "
-                                       "sample-owning k = 5 convolution (tkc.hip)");
-  hipStream_t s = as_stream(stream);
-  if (mode == 5) {
-    RAMP_REQUIRE(taps == 5 && ((shift0 == -2 && shift_step == 1) || (shift0 == 2 && shift_step == -1)) && tkc_applicable(M, L, N, K, nullptr),
-                 "mode 5: a k = 5 convolution (or its input gradient) with C_in, C_out in {32, 64}, L >= 8 dividing 48 or 32");
-    DevArena ar;
-    std::vector<float> hw((size_t)5 * N * K);
-    RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
-    float mx = 0.f; for (float v : hw) mx = std::max(mx, std::fabs(v));
-    float sc = 1.f;
-    if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
-    unsigned short* pl = reinterpret_cast<unsigned short*>(ar.alloc(tkc_packed_halves(N, K) / 2 + 4));
-    float* sl = ar.alloc(4);
-    RAMP_REQUIRE(pl && sl, "hipMalloc failed");
-    CK(init_tkc_attributes());
-    CK(tkc_pack(W, N, K, sc, pl, s));
-    const float v[4] = {a_absmax_prev, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(sl, v, 16, hipMemcpyHostToDevice, s));
-    TkcArgs t; t.M = M; t.L = L; t.N = N; t.K = K; t.dir = shift_step; t.X = A; t.ldx = K; t.W = pl; t.bias = bias; t.resid = resid; t.ldr = N;
-    t.Y = C; t.ldy = N; t.amax_in = a_absmax_prev > 0.f ? sl : nullptr; t.amax_out = sl + 1; t.wsi = 1.f / sc; t.range_flag = reinterpret_cast<int*>(sl + 2);
-    int rc5 = launch_tkc(t, s);
-    hipError_t e5 = hipStreamSynchronize(s);
-    float back[4] = {0, 0, 0, 0};
-    if (rc5 == 0 && e5 == hipSuccess) {
-      e5 = hipMemcpy(back, sl, sizeof(back), hipMemcpyDeviceToHost);
-      if (a_absmax_out_host) *a_absmax_out_host = back[1];
-      if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
-    }
-    RAMP_HIP_CHECK(e5);
-    return rc5;
-  }
-  GemmArgs a; a.A = A; a.lda = K; a.W = W; a.bias = bias; a.resid = resid; a.ldr = N; a.C = C; a.ldc = N;
-  a.M = M; a.N = N; a.K = K; a.taps = taps; a.shift0 = shift0; a.shift_step = shift_step; a.L = L;
-  const long n = (long)taps * N * K;
-  const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
-  unsigned short* planes = nullptr; float* slots = nullptr;
-  int rc = 0;
-  if (mode == 3 && frag_ok) {
-    // the product's static weight scale: max |w| -> [2^10, 2^11)  (ramp_finalize_weights)
-    std::vector<float> hw(n);
-    RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, n * sizeof(float), hipMemcpyDeviceToHost));
-    float mx = 0.f; for (float v : hw) mx = std::max(mx, std::fabs(v));
-    float sc = 1.f;
-    if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
-    RAMP_HIP_CHECK(hipMalloc(&planes, 2 * n * sizeof(unsigned short)));
-    RAMP_HIP_CHECK(hipMalloc(&slots, 16));
-    const float v[4] = {a_absmax_prev, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(slots, v, 16, hipMemcpyHostToDevice, s));
-    rc = launch_pack_h3(W, planes, (long)taps * N, K, sc, s);
-    a.Wx = planes; a.wx_packed = 2; a.w_scale_inv = 1.f / sc;
-    a.a_absmax_in = a_absmax_prev > 0.f ? slots : nullptr; a.a_absmax_out = slots + 1;
-    a.range_flag = reinterpret_cast<int*>(slots + 2);
-  } else if (mode == 1 && frag_ok) {
-    RAMP_HIP_CHECK(hipMalloc(&planes, 3 * n * sizeof(unsigned short)));
-    rc = launch_pack_x6(W, planes, (long)taps * N, K, s);
-    a.Wx = planes; a.wx_packed = 1;
-  } else if ((mode == 1 || mode == 2) && N >= 128) {
-    RAMP_HIP_CHECK(hipMalloc(&planes, 3 * n * sizeof(unsigned short)));
-    rc = launch_split3(W, planes, n, s);
-    a.Wx = planes; a.wx_plane = n;
-  }
-  if (rc == 0) rc = launch_gemm(a, s);
-  hipError_t e = hipStreamSynchronize(s);
-  if (rc == 0 && e == hipSuccess && slots) {
-    float back[4] = {0, 0, 0, 0};
-    e = hipMemcpy(back, slots, 16, hipMemcpyDeviceToHost);
-    if (a_absmax_out_host) *a_absmax_out_host = back[1];
-    int fl; std::memcpy(&fl, &back[2], 4);
-    if (range_flag_out_host) *range_flag_out_host = fl;
-  } else {
-    if (a_absmax_out_host) *a_absmax_out_host = 0.f;
-    if (range_flag_out_host) *range_flag_out_host = 0;
-  }
-  if (planes) (void)hipFree(planes);
-  if (slots) (void)hipFree(slots);
-  RAMP_HIP_CHECK(e);
-  return rc;
-}
-// ---- the token-owning fused feed-forward (ffx.hip) on raw fp32 weights: packs exactly as ramp_finalize_weights does --------
-namespace {
-struct FfxPack {
-  unsigned short *stream_f = nullptr, *stream_b = nullptr;   // 96 x 32 KB each
-  float *b1_pk = nullptr; float wsi_w1 = 1.f, wsi_w2 = 1.f;
-};
-// W1 [2048][256] (rows: 1024 a then 1024 g), W2 [256][1024]; everything allocated from `ar`
-int ffx_pack_all(DevArena& ar, const float* W1, const float* b1, const float* W2, FfxPack* out, hipStream_t s, bool s16 = false) {
-  auto maxabs = [&](const float* d, size_t n, float* sc) -> int {
-    std::vector<float> hw(n);
-    RAMP_HIP_CHECK(hipMemcpy(hw.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
-    float mx = 0.f; for (float v : hw) mx = std::max(mx, std::fabs(v));
-    *sc = 1.f;
-    if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); *sc = std::ldexp(1.f, 11 - e); }
-    return 0;
-  };
-  float sc1 = 1.f, sc2 = 1.f;
-  CK(maxabs(W1, 2048 * 256, &sc1)); CK(maxabs(W2, 256 * 1024, &sc2));
-  float* w1_pk = ar.alloc(2048 * 256); out->b1_pk = ar.alloc(2048);
-  float* w1t = ar.alloc(2048 * 256); float* w2t = ar.alloc(1024 * 256); float* tmp = ar.alloc(2048 * 256);
-  auto planes = [&](size_t n) { return reinterpret_cast<unsigned short*>(ar.alloc(n + 4)); };   // 2 n halves
-  unsigned short *p_w1 = planes(2048 * 256), *p_w2p = planes(256 * 1024), *p_w2t = planes(1024 * 256), *p_w1tp = planes(256 * 2048);
-  out->stream_f = planes(96 * 8192); out->stream_b = planes(96 * 8192);
-  RAMP_REQUIRE(w1_pk && out->b1_pk && w1t && w2t && tmp && p_w1 && p_w2p && p_w2t && p_w1tp && out->stream_f && out->stream_b, "hipMalloc failed");
-  hipLaunchKernelGGL(geglu_pack_kernel, dim3(1024), dim3(256), 0, s, W1, w1_pk, 1024, 256, 32);
-  hipLaunchKernelGGL(geglu_pack_kernel, dim3(8), dim3(256), 0, s, b1, out->b1_pk, 1024, 1, 32);
-  hipLaunchKernelGGL(permute3_kernel, dim3(2048), dim3(256), 0, s, W1, w1t, 2048, 256, 1, 1, 0, 2);      // [256][2048]
-  hipLaunchKernelGGL(permute3_kernel, dim3(1024), dim3(256), 0, s, W2, w2t, 256, 1024, 1, 1, 0, 2);      // [1024][256]
-  RAMP_HIP_CHECK(hipGetLastError());
-  if (s16) {      // 16 x 32 fragments for the v_mfma_f32_16x16x32_f16 kernels (ffx16.hip)
-    CK(ffx16_pack(w1_pk, 2048, 256, 0, sc1, tmp, p_w1, s));
-    CK(ffx16_pack(W2, 256, 1024, 1, sc2, tmp, p_w2p, s));
-    CK(ffx16_pack(w2t, 1024, 256, 0, sc2, tmp, p_w2t, s));
-    CK(ffx16_pack(w1t, 256, 2048, 2, sc1, tmp, p_w1tp, s));
-    CK(ffx16_build_stream(p_w1, p_w2p, out->stream_f, false, s));
-    CK(ffx16_build_stream(p_w2t, p_w1tp, out->stream_b, true, s));
-  } else {
-    CK(launch_pack_h3(w1_pk, p_w1, 2048, 256, sc1, s));
-    CK(ffx_pack_second(W2, 256, 1024, 0, sc2, tmp, p_w2p, s));
-    CK(launch_pack_h3(w2t, p_w2t, 1024, 256, sc2, s));
-    CK(ffx_pack_second(w1t, 256, 2048, 1, sc1, tmp, p_w1tp, s));
-    CK(ffx_build_stream(p_w1, p_w2p, out->stream_f, false, s));
-    CK(ffx_build_stream(p_w2t, p_w1tp, out->stream_b, true, s));
-  }
-  out->wsi_w1 = 1.f / sc1; out->wsi_w2 = 1.f / sc2;
-  return 0;
-}
-}  // namespace
-
-static int op_ffx_impl(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
-                       const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
-                       float* absmax_out_host, int32_t* range_flag_out_host, void* stream, bool s16) {
-  RAMP_REQUIRE(z1 && W1 && b1 && W2 && b2 && ln_g && ln_b && z2 && M > 0, "null argument");
-  hipStream_t s = as_stream(stream);
-  DevArena ar;
-  FfxPack pk;
-  CK(ffx_pack_all(ar, W1, b1, W2, &pk, s, s16));
-  auto launch_ffx = [s16](const FfxArgs& a, bool bwd, hipStream_t st) { return s16 ? ramp::launch_ffx16(a, bwd, st) : ramp::launch_ffx(a, bwd, st); };
-  const size_t mt = ((size_t)M + 127) / 128;
-  float* stash = ar.alloc(mt * 128 * 2048); float* slots = ar.alloc(12);
-  RAMP_REQUIRE(stash && slots, "hipMalloc failed");
-  float host[12] = {0};
-  for (int i = 0; i < 4; ++i) host[i] = absmax_prev_host ? absmax_prev_host[i] : 0.f;
-  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
-  FfxArgs f; f.M = M; f.X = z1; f.Z1 = z1; f.Y = z2; f.stash = stash; f.ln_g = ln_g; f.ln_b = ln_b; f.Wstream = pk.stream_f;
-  f.b1 = pk.b1_pk; f.b2 = b2; f.range_flag = reinterpret_cast<int*>(slots + 8);
-  f.amax_in1 = host[0] > 0.f ? slots + 0 : nullptr; f.amax_out1 = slots + 4; f.wsi1 = pk.wsi_w1; f.site1 = 0;
-  f.amax_in2 = host[1] > 0.f ? slots + 1 : nullptr; f.amax_out2 = slots + 5; f.wsi2 = pk.wsi_w2; f.site2 = 1;
-  int rc = launch_ffx(f, false, s);
-  if (rc == 0 && dz && dz1) {
-    FfxArgs g; g.M = M; g.X = dz; g.Z1 = z1; g.Y = dz1; g.stash = stash; g.ln_g = ln_g; g.ln_b = ln_b; g.Wstream = pk.stream_b;
-    g.range_flag = reinterpret_cast<int*>(slots + 8);
-    g.amax_in1 = host[2] > 0.f ? slots + 2 : nullptr; g.amax_out1 = slots + 6; g.wsi1 = pk.wsi_w2; g.site1 = 2;
-    g.amax_in2 = host[3] > 0.f ? slots + 3 : nullptr; g.amax_out2 = slots + 7; g.wsi2 = pk.wsi_w1; g.site2 = 3;
-    rc = launch_ffx(g, true, s);
-  }
-  hipError_t e = hipStreamSynchronize(s);
-  if (rc == 0 && e == hipSuccess) {
-    e = hipMemcpy(host, slots, sizeof(host), hipMemcpyDeviceToHost);
-    if (absmax_out_host) for (int i = 0; i < 4; ++i) absmax_out_host[i] = host[4 + i];
-    if (range_flag_out_host) std::memcpy(range_flag_out_host, &host[8], 4);
-  }
-  RAMP_HIP_CHECK(e);
-  return rc;
-}
-int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
-                const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
-                float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
-  return op_ffx_impl(z1, dz, W1, b1, W2, b2, ln_g, ln_b, M, absmax_prev_host, z2, dz1, absmax_out_host, range_flag_out_host, stream, false);
-}
-int ramp_op_ffx16(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
-                  const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
-                  float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
-  return op_ffx_impl(z1, dz, W1, b1, W2, b2, ln_g, ln_b, M, absmax_prev_host, z2, dz1, absmax_out_host, range_flag_out_host, stream, true);
-}
-
-int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
-                const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
-                float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
-  RAMP_REQUIRE(X && W && Y && M > 0 && N >= 32 && N % 32 == 0 && N <= 768, "bad arguments");
-  hipStream_t s = as_stream(stream);
-  DevArena ar;
-  std::vector<float> hw((size_t)N * 256);
-  RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
-  float mx = 0.f;
-  for (float v : hw) mx = std::max(mx, std::fabs(v));
-  float sc = 1.f;
-  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
-  unsigned short* planes = reinterpret_cast<unsigned short*>(ar.alloc((size_t)N * 256 + 4));
-  float* slots = ar.alloc(4);
-  RAMP_REQUIRE(planes && slots, "hipMalloc failed");
-  CK(launch_pack_h3(W, planes, N, 256, sc, s));
-  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
-  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
-  TklArgs a; a.M = M; a.N = N; a.X = X; a.Y = Y; a.ldy = N; a.W = planes; a.bias = bias; a.resid = resid; a.ldr = N;
-  a.rowbias = rowbias; a.rowvar = rowvar; a.row0 = 0; a.rb_stride = N; a.L = L > 0 ? L : 1; a.n_var = n_var;
-  a.ln_g = ln_g; a.ln_b = ln_b; a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
-  a.range_flag = reinterpret_cast<int*>(slots + 2);
-  int rc = launch_tkl(a, s);
-  hipError_t e = hipStreamSynchronize(s);
-  float back[4] = {0, 0, 0, 0};
-  if (rc == 0 && e == hipSuccess) {
-    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
-    if (absmax_out_host) *absmax_out_host = back[1];
-    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
-  }
-  RAMP_HIP_CHECK(e);
-  return rc;
-}
-
-int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const float* resid, const float* rowbias, const int32_t* rowvar,
-                int32_t n_var, int32_t L, int32_t M, float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
-  RAMP_REQUIRE(qkv && Wo && resid && Y && M > 0 && L > 0, "bad arguments");
-  hipStream_t s = as_stream(stream);
-  DevArena ar;
-  std::vector<float> hw((size_t)256 * 256);
-  RAMP_HIP_CHECK(hipMemcpy(hw.data(), Wo, hw.size() * 4, hipMemcpyDeviceToHost));
-  float mx = 0.f;
-  for (float v : hw) mx = std::max(mx, std::fabs(v));
-  float sc = 1.f;
-  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
-  unsigned short* stream_w = reinterpret_cast<unsigned short*>(ar.alloc(8 * 8192 + 4));
-  float* slots = ar.alloc(4);
-  RAMP_REQUIRE(stream_w && slots, "hipMalloc failed");
-  CK(init_atk_attributes());
-  CK(ato_pack(Wo, sc, stream_w, s));
-  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
-  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
-  AtoArgs a; a.M = M; a.L = L; a.QKV = qkv; a.W = stream_w; a.bias = bias; a.resid = resid; a.Y = Y;
-  a.rowbias = rowbias; a.rowvar = rowvar; a.row0 = 0; a.rb_stride = 256; a.n_var = rowbias ? n_var : 0;
-  a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
-  a.range_flag = reinterpret_cast<int*>(slots + 2);
-  int rc = launch_ato(a, s);
-  hipError_t e = hipStreamSynchronize(s);
-  float back[4] = {0, 0, 0, 0};
-  if (rc == 0 && e == hipSuccess) {
-    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
-    if (absmax_out_host) *absmax_out_host = back[1];
-    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
-  }
-  RAMP_HIP_CHECK(e);
-  return rc;
-}
-
-int ramp_op_atb(const float* qkv, const float* dout, float* dqkv, int32_t M, int32_t L, void* stream) {
-  RAMP_REQUIRE(qkv && dout && dqkv && M > 0 && L > 0, "bad arguments");
-  AtbArgs a; a.M = M; a.L = L; a.QKV = qkv; a.dO = dout; a.dQKV = dqkv;
-  return launch_atb(a, as_stream(stream));
-}
-
-int ramp_op_abl(const float* qkv, const float* dout, const float* W, const float* z, const float* ln_g, const float* add, int32_t M, int32_t L,
-                float absmax_prev, float* out, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
-  RAMP_REQUIRE(qkv && dout && W && z && ln_g && add && out && M > 0 && L > 0, "bad arguments");
-  hipStream_t s = as_stream(stream);
-  DevArena ar;
-  std::vector<float> hw((size_t)256 * 768);
-  RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
-  float mx = 0.f;
-  for (float v : hw) mx = std::max(mx, std::fabs(v));
-  float sc = 1.f;
-  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
-  unsigned short* stream_w = reinterpret_cast<unsigned short*>(ar.alloc((size_t)256 * 768 + 4));
-  float* slots = ar.alloc(4);
-  RAMP_REQUIRE(stream_w && slots, "hipMalloc failed");
-  CK(init_atl_attributes());
-  CK(abl_pack(W, sc, stream_w, s));
-  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
-  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
-  AblArgs a; a.M = M; a.L = L; a.QKV = qkv; a.dO = dout; a.W = stream_w; a.Z = z; a.add = add; a.ln_g = ln_g; a.Y = out;
-  a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
-  a.range_flag = reinterpret_cast<int*>(slots + 2);
-  int rc = launch_abl(a, s);
-  hipError_t e = hipStreamSynchronize(s);
-  float back[4] = {0, 0, 0, 0};
-  if (rc == 0 && e == hipSuccess) {
-    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
-    if (absmax_out_host) *absmax_out_host = back[1];
-    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
-  }
-  RAMP_HIP_CHECK(e);
-  return rc;
-}
-
-int ramp_op_tkw(const float* X, const float* X2, int32_t K1, const float* W, const float* bias, const float* resid, const float* resid2,
-                const float* gn_c, const float* gn_stats, const float* gn_gamma, const float* gn_beta, const float* gamma, const float* beta,
-                const float* tbias, int32_t M, int32_t L, int32_t N, int32_t K, int32_t dir, int32_t N1, float absmax_prev, float* Y, float* Y2,
-                float* Cst, float* stats, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
-  RAMP_REQUIRE(X && W && Y && M > 0 && L > 0 && N % 32 == 0 && K % 16 == 0, "bad arguments");
-  hipStream_t s = as_stream(stream);
-  DevArena ar;
-  const size_t n = (size_t)5 * N * K;
-  if (N <= 64 && K <= 64) {      // the narrow layers: the same fusion on sample-owning WAVES (tkc.hip)
-    RAMP_REQUIRE(!X2 && !Y2 && tkc_applicable(M, L, N, K, nullptr), "narrow fused convolution: C_in, C_out in {32, 64}, L >= 8 dividing 48 or 32, one operand, one output");
-    std::vector<float> hw(n);
-    RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, n * 4, hipMemcpyDeviceToHost));
-    float mx = 0.f; for (float v : hw) mx = std::max(mx, std::fabs(v));
-    float sc = 1.f;
-    if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
-    unsigned short* pl = reinterpret_cast<unsigned short*>(ar.alloc(tkc_packed_halves(N, K) / 2 + 4));
-    float* sl = ar.alloc(4);
-    RAMP_REQUIRE(pl && sl, "hipMalloc failed");
-    CK(init_tkc_attributes());
-    CK(tkc_pack(W, N, K, sc, pl, s));
-    const float v[4] = {absmax_prev, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(sl, v, 16, hipMemcpyHostToDevice, s));
-    TkcArgs t; t.M = M; t.L = L; t.N = N; t.K = K; t.dir = dir; t.X = X; t.ldx = K; t.W = pl; t.bias = bias; t.resid = resid; t.ldr = N;
-    t.resid2 = resid2; t.ldr2 = N; t.Y = Y; t.ldy = N; t.amax_in = absmax_prev > 0.f ? sl : nullptr; t.amax_out = sl + 1; t.wsi = 1.f / sc;
-    t.range_flag = reinterpret_cast<int*>(sl + 2);
-    t.gn_c = gn_c; t.gn_stats = gn_stats; t.gn_gamma = gn_gamma; t.gn_beta = gn_beta;
-    t.Cst = Cst; t.stats = stats; t.gamma = gamma; t.beta = beta; t.tbias = tbias; t.eps = 1e-5f;
-    int rc5 = launch_tkc(t, s);
-    hipError_t e5 = hipStreamSynchronize(s);
-    float back[4] = {0, 0, 0, 0};
-    if (rc5 == 0 && e5 == hipSuccess) {
-      e5 = hipMemcpy(back, sl, sizeof(back), hipMemcpyDeviceToHost);
-      if (absmax_out_host) *absmax_out_host = back[1];
-      if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
-    }
-    RAMP_HIP_CHECK(e5);
-    return rc5;
-  }
-  std::vector<float> hw(n);
-  RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, n * 4, hipMemcpyDeviceToHost));
-  float mx = 0.f;
-  for (float v : hw) mx = std::max(mx, std::fabs(v));
-  float sc = 1.f;
-  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
-  unsigned short* planes = reinterpret_cast<unsigned short*>(ar.alloc(n + 4));
-  float* slots = ar.alloc(4);
-  RAMP_REQUIRE(planes && slots, "hipMalloc failed");
-  CK(init_tkw_attributes());
-  CK(launch_pack_h3(W, planes, (long)5 * N, K, sc, s));
-  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
-  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
-  TkwArgs a; a.M = M; a.L = L; a.N = N; a.K = K; a.dir = dir; a.X = X; a.ldx = X2 ? K1 : K; a.X2 = X2; a.ldx2 = X2 ? K - K1 : 0; a.K1 = X2 ? K1 : K;
-  a.gn_c = gn_c; a.gn_stats = gn_stats; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta; a.W = planes; a.wsi = 1.f / sc; a.bias = bias;
-  a.resid = resid; a.ldr = N; a.resid2 = resid2; a.ldr2 = N; a.Y = Y; a.ldy = Y2 ? N1 : N; a.Y2 = Y2; a.ldy2 = Y2 ? N - N1 : 0; a.N1 = Y2 ? N1 : N;
-  a.Cst = Cst; a.stats = stats; a.gamma = gamma; a.beta = beta; a.tbias = tbias; a.eps = 1e-5f;
-  a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.site = 0; a.range_flag = reinterpret_cast<int*>(slots + 2);
-  int rc = launch_tkw(a, s);
-  hipError_t e = hipStreamSynchronize(s);
-  float back[4] = {0, 0, 0, 0};
-  if (rc == 0 && e == hipSuccess) {
-    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
-    if (absmax_out_host) *absmax_out_host = back[1];
-    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
-  }
-  RAMP_HIP_CHECK(e);
-  return rc;
-}
-
-int ramp_op_tklb(const float* dqkv, const float* W, const float* z, const float* ln_g, const float* add, int32_t M,
-                 float absmax_prev, float* out, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
-  RAMP_REQUIRE(dqkv && W && z && ln_g && add && out && M > 0, "bad arguments");
-  hipStream_t s = as_stream(stream);
-  DevArena ar;
-  std::vector<float> hw((size_t)256 * 768);
-  RAMP_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost));
-  float mx = 0.f;
-  for (float v : hw) mx = std::max(mx, std::fabs(v));
-  float sc = 1.f;
-  if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 11 - e); }
-  unsigned short* planes = reinterpret_cast<unsigned short*>(ar.alloc((size_t)256 * 768 + 4));
-  float* slots = ar.alloc(4);
-  RAMP_REQUIRE(planes && slots, "hipMalloc failed");
-  CK(launch_pack_h3(W, planes, 256, 768, sc, s));
-  const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
-  RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
-  TklbArgs a; a.M = M; a.X = dqkv; a.Z = z; a.add = add; a.Y = out; a.W = planes; a.ln_g = ln_g;
-  a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
-  a.range_flag = reinterpret_cast<int*>(slots + 2);
-  int rc = launch_tklb(a, s);
-  hipError_t e = hipStreamSynchronize(s);
-  float back[4] = {0, 0, 0, 0};
-  if (rc == 0 && e == hipSuccess) {
-    e = hipMemcpy(back, slots, sizeof(back), hipMemcpyDeviceToHost);
-    if (absmax_out_host) *absmax_out_host = back[1];
-    if (range_flag_out_host) std::memcpy(range_flag_out_host, &back[2], 4);
-  }
-  RAMP_HIP_CHECK(e);
-  return rc;
-}
-
-// micro-benchmark of one GEMM shape on a named kernel: packs once, `warmup` + `iters` back-to-back launches on `stream`,
-// HIP events around the timed ones.  flags: 1 bias, 2 residual, 4 GEGLU-forward epilogue (N = 2F, writes the F-wide
-// product too), 8 A-multiplier operand (K = 2 * period).  Operands are allocated and filled here (uniform [-1, 1)).
-__global__ void fill_uniform_kernel(float* p, long n, unsigned seed, float scale) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
-    p[i] = ((float)(h >> 8) * (1.f / 8388608.f) - 1.f) * scale;
-  }
-}
-// ---- stress hook of the micro-benchmark: every launch's output against the first one's, bit for bit ------------------------
-namespace {
-__global__ void stress_cmp_kernel(const unsigned* __restrict__ a, const unsigned* __restrict__ b, long n, unsigned long long* mism) {
-  unsigned long long c = 0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) c += a[i] != b[i];
-  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(mism, c);
-}
-__global__ void stress_err_kernel(const float* __restrict__ a, const float* __restrict__ ref, long n, unsigned* out /* [max |a - ref|, max |ref|] as float bits */) {
-  float e = 0.f, r = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { e = fmaxf(e, fabsf(a[i] - ref[i])); r = fmaxf(r, fabsf(ref[i])); }
-  for (int m = 32; m >= 1; m >>= 1) { e = fmaxf(e, __shfl_xor(e, m)); r = fmaxf(r, __shfl_xor(r, m)); }
-  if ((threadIdx.x & 63) == 0) { atomicMax(out, __builtin_bit_cast(unsigned, e)); atomicMax(out + 1, __builtin_bit_cast(unsigned, r)); }
-}
-struct StressHook {
-  bool capture_ref = false;      // this run only provides the reference output (the exact-fp32 kernel)
-  float* first = nullptr; float* ref = nullptr; long n = 0; long launches = 0;
-  unsigned long long* mism = nullptr; unsigned* err = nullptr;
-  // after a launch that wrote `out` (n floats)
-  int check(const float* out, long nf, hipStream_t s) {
-    if (capture_ref) {
-      if (!ref) { RAMP_HIP_CHECK(hipMalloc(&ref, nf * 4)); n = nf; }
-      RAMP_HIP_CHECK(hipMemcpyAsync(ref, out, nf * 4, hipMemcpyDeviceToDevice, s));
-      return 0;
-    }
-    if (!mism) { RAMP_HIP_CHECK(hipMalloc(&mism, 16)); RAMP_HIP_CHECK(hipMemsetAsync(mism, 0, 16, s)); err = reinterpret_cast<unsigned*>(mism) + 2; }
-    if (!first) {
-      RAMP_HIP_CHECK(hipMalloc(&first, nf * 4));
-      RAMP_HIP_CHECK(hipMemcpyAsync(first, out, nf * 4, hipMemcpyDeviceToDevice, s));
-      if (ref && n == nf) hipLaunchKernelGGL(stress_err_kernel, dim3(2048), dim3(256), 0, s, out, ref, nf, err);
-    } else {
-      hipLaunchKernelGGL(stress_cmp_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const unsigned*>(out),
-                         reinterpret_cast<const unsigned*>(first), nf, mism);
-    }
-    ++launches;
-    RAMP_HIP_CHECK(hipGetLastError());
-    return 0;
-  }
-  ~StressHook() { if (first) (void)hipFree(first); if (ref) (void)hipFree(ref); if (mism) (void)hipFree(mism); }
-};
-thread_local StressHook* g_stress = nullptr;
-#define STRESS(ptr_, n_, s_) do { if (g_stress) CK(g_stress->check((ptr_), (long)(n_), (s_))); } while (0)
-}  // namespace
-
-int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags,
-                    int32_t warmup, int32_t iters, float* avg_us, void* stream) {
-  RAMP_REQUIRE(avg_us && iters > 0 && M > 0 && N > 0 && K > 0 && taps >= 1 && mode >= 0 && mode <= 17, "bad arguments");
-  if (mode == 17) {                                    // tkw.hip: wide k = 5 convolution on sample-owning blocks; flags 1: GroupNorm + Mish epilogue (forward),
-                                                       // 2: GroupNorm-backward operand (input gradient), 4: dir = -1, 8: residual, 16: bias
-    hipStream_t sw = as_stream(stream);
-    DevArena arw;
-    const bool epi = flags & 1, pro = flags & 2;
-    RAMP_REQUIRE(taps == 5 && tkw_applicable(M, L, N, K, pro, epi), "mode 17: k = 5, C_out in {128, 256, 512}, L >= 3 dividing 96");
-    float* X = arw.alloc((size_t)M * K); float* Y = arw.alloc((size_t)M * N); float* R = arw.alloc((size_t)M * N); float* Cs = arw.alloc((size_t)M * std::max(N, K));
-    float* W = arw.alloc((size_t)5 * N * K); float* b = arw.alloc(N); float* gm = arw.alloc(std::max(N, K)); float* bt = arw.alloc(std::max(N, K));
-    float* st = arw.alloc((size_t)(M / L) * 16); float* sl = arw.alloc(4); float* tmp = arw.alloc((size_t)M * K);
-    unsigned short* pl = reinterpret_cast<unsigned short*>(arw.alloc((size_t)5 * N * K + 4));
-    RAMP_REQUIRE(X && Y && R && Cs && W && b && gm && bt && st && sl && tmp && pl, "hipMalloc failed");
-    auto fill = [&](float* p, size_t n, unsigned seed, float scv) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sw, p, (long)n, seed, scv); };
-    fill(X, (size_t)M * K, 1u, 1.f); fill(R, (size_t)M * N, 4u, 1.f); fill(W, (size_t)5 * N * K, 2u, 1.f / std::sqrt(5.f * K)); fill(b, N, 5u, 1.f);
-    fill(gm, std::max(N, K), 6u, 1.f); fill(bt, std::max(N, K), 7u, 0.5f); fill(Cs, (size_t)M * std::max(N, K), 8u, 1.f);
-    CK(init_tkw_attributes());
-    float scp = 1.f; { int e; std::frexp(std::ldexp(1.f, 10) * std::sqrt(5.f * K), &e); scp = std::ldexp(1.f, e - 1); }
-    CK(launch_pack_h3(W, pl, (long)5 * N, K, scp, sw));
-    if (pro) {      // statistics of the tensor the backward normalises again (any consistent mean / rstd do)
-      GnArgs g; g.x = Cs; g.gamma = gm; g.beta = bt; g.y = tmp; g.stats = st; g.R = M / L; g.L = L; g.C = K; g.eps = 1e-5f; g.mish = 1;
-      CK(launch_gn_fwd(g, sw));
-    }
-    const float one[4] = {pro ? 8.f : 1.f, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, sw));
-    TkwArgs t; t.M = M; t.L = L; t.N = N; t.K = K; t.dir = (flags & 4) ? -1 : 1; t.X = X; t.ldx = K; t.K1 = K; t.W = pl; t.wsi = 1.f / scp; t.Y = Y; t.ldy = N; t.N1 = N;
-    if ((flags & 16) || epi) t.bias = b;
-    if (flags & 8) { t.resid = R; t.ldr = N; }
-    if (pro) { t.gn_c = Cs; t.gn_stats = st; t.gn_gamma = gm; t.gn_beta = bt; }
-    if (epi) { t.Cst = Cs; t.stats = st; t.gamma = gm; t.beta = bt; t.tbias = b; }
-    t.amax_in = sl; t.amax_out = sl + 1; t.range_flag = reinterpret_cast<int*>(sl + 2); t.ablate = (flags >> 8) & 7;
-    for (int i = 0; i < warmup; ++i) CK(launch_tkw(t, sw));
-    hipEvent_t e0, e1;
-    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-    RAMP_HIP_CHECK(hipEventRecord(e0, sw));
-    int rcw = 0;
-    for (int i = 0; i < iters && rcw == 0; ++i) { rcw = launch_tkw(t, sw); if (rcw == 0) STRESS(Y, (size_t)M * N, sw); }
-    RAMP_HIP_CHECK(hipEventRecord(e1, sw));
-    RAMP_HIP_CHECK(hipEventSynchronize(e1));
-    float msw = 0.f;
-    RAMP_HIP_CHECK(hipEventElapsedTime(&msw, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = msw * 1e3f / iters;
-    return rcw;
-  }
-  if (mode == 15 || mode == 16) {                      // attention backward + d(ln1) + LN1 backward: abl_kernel (15, atl.hip) / atb_kernel + tklb_kernel (16)
-    hipStream_t sb = as_stream(stream);
-    DevArena arb;
-    RAMP_REQUIRE(L >= 1 && M % L == 0, "mode 15 / 16: M must be whole samples of L tokens");
-    float* Q = arb.alloc((size_t)M * 768); float* D = arb.alloc((size_t)M * 256); float* G = arb.alloc((size_t)M * 768);
-    float* Z = arb.alloc((size_t)M * 256); float* Ad = arb.alloc((size_t)M * 256); float* Y = arb.alloc((size_t)M * 256);
-    float* Wq = arb.alloc((size_t)256 * 768); float* gam = arb.alloc(256); float* slots = arb.alloc(4);
-    unsigned short* ws = reinterpret_cast<unsigned short*>(arb.alloc((size_t)256 * 768 + 4));
-    unsigned short* pl = reinterpret_cast<unsigned short*>(arb.alloc((size_t)256 * 768 + 4));
-    RAMP_REQUIRE(Q && D && G && Z && Ad && Y && Wq && gam && slots && ws && pl, "hipMalloc failed");
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, Q, (long)M * 768, 1u, 1.5f);
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, D, (long)M * 256, 3u, 1.f);
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, Z, (long)M * 256, 5u, 1.f);
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, Ad, (long)M * 256, 7u, 1.f);
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(64), dim3(256), 0, sb, Wq, 256l * 768, 9u, 1.f / 16.f);
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(1), dim3(256), 0, sb, gam, 256l, 11u, 1.f);
-    CK(init_atl_attributes()); CK(init_tkl_attributes());
-    CK(abl_pack(Wq, 16384.f, ws, sb));
-    CK(launch_pack_h3(Wq, pl, 256, 768, 16384.f, sb));
-    const float host[4] = {4.f, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, sb));
-    AblArgs t; t.M = M; t.L = L; t.QKV = Q; t.dO = D; t.W = ws; t.Z = Z; t.add = Ad; t.ln_g = gam; t.Y = Y;
-    t.amax_in = slots; t.amax_out = slots + 1; t.wsi = 1.f / 16384.f; t.range_flag = nullptr;
-    AtbArgs tb; tb.M = M; tb.L = L; tb.QKV = Q; tb.dO = D; tb.dQKV = G;
-    TklbArgs tl; tl.M = M; tl.X = G; tl.Z = Z; tl.add = Ad; tl.Y = Y; tl.W = pl; tl.ln_g = gam;
-    tl.amax_in = slots; tl.amax_out = slots + 1; tl.wsi = 1.f / 16384.f;
-    unsigned long long* stamps = nullptr;
-    if (flags & 256) {
-      RAMP_REQUIRE(mode == 15, "stamps: mode 15");
-      stamps = reinterpret_cast<unsigned long long*>(arb.alloc(256 * 4 * 10 * 2));
-      RAMP_REQUIRE(stamps, "hipMalloc failed");
-      RAMP_HIP_CHECK(hipMemsetAsync(stamps, 0, 256 * 4 * 10 * 8, sb));
-      t.stamps = stamps;
-    }
-    auto go = [&]() -> int { if (mode == 15) return launch_abl(t, sb); int rc = launch_atb(tb, sb); return rc ? rc : launch_tklb(tl, sb); };
-    for (int i = 0; i < warmup; ++i) CK(go());
-    hipEvent_t e0, e1;
-    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-    RAMP_HIP_CHECK(hipEventRecord(e0, sb));
-    int rcb = 0;
-    for (int i = 0; i < iters && rcb == 0; ++i) { rcb = go(); if (rcb == 0) STRESS(Y, (size_t)M * 256, sb); }
-    RAMP_HIP_CHECK(hipEventRecord(e1, sb));
-    RAMP_HIP_CHECK(hipEventSynchronize(e1));
-    float msb = 0.f;
-    RAMP_HIP_CHECK(hipEventElapsedTime(&msb, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = msb * 1e3f / iters;
-    if (rcb == 0 && stamps) {
-      std::vector<unsigned long long> hst(256 * 4 * 10);
-      RAMP_HIP_CHECK(hipMemcpy(hst.data(), stamps, hst.size() * 8, hipMemcpyDeviceToHost));
-      double sm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int nw = 0;
-      for (int w = 0; w < 1024; ++w) if (hst[w * 10 + 8]) { ++nw; for (int j = 0; j < 10; ++j) sm[j] += (double)hst[w * 10 + j]; }
-      const int n_tiles = (M + 191) / 192;
-      const double tiles = std::max(1, nw) * (double)((n_tiles + 255) / 256);
-      fprintf(stderr, "[abl stamps] per wave tile (s_memtime ticks, %d waves): head-start waits %.0f, S^T + softmax %.0f, d(o) / v waits %.0f, dP + dS + planes + P turned %.0f, "
-              "turn + contract (x 24) %.0f, slab waits + barriers (x 48) %.0f, slab bodies %.0f, epilogue + loop tops %.0f; whole kernel %.0f per tile; shader clock %.0f MHz\n",
-              nw, sm[0] / tiles, sm[1] / tiles, sm[2] / tiles, sm[3] / tiles, sm[4] / tiles, sm[5] / tiles, sm[6] / tiles, sm[7] / tiles, sm[8] / tiles,
-              sm[9] > 0 ? sm[8] / sm[9] * 100.0 : 0.0);
-    }
-    return rcb;
-  }
-  if (mode == 13 || mode == 14) {                      // attention backward: atb_kernel (13, atk.hip) / attn2_bwd_kernel (14, attention.hip); L = tokens per sample
-    hipStream_t sb = as_stream(stream);
-    DevArena arb;
-    RAMP_REQUIRE(L >= 1 && M % L == 0, "mode 13 / 14: M must be whole samples of L tokens");
-    float* Q = arb.alloc((size_t)M * 768); float* D = arb.alloc((size_t)M * 256); float* G = arb.alloc((size_t)M * 768);
-    RAMP_REQUIRE(Q && D && G, "hipMalloc failed");
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, Q, (long)M * 768, 1u, 1.5f);
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sb, D, (long)M * 256, 3u, 1.f);
-    AtbArgs t; t.M = M; t.L = L; t.QKV = Q; t.dO = D; t.dQKV = G;
-    auto go = [&]() -> int { return mode == 13 ? launch_atb(t, sb) : launch_attn_bwd(Q, D, G, M / L, L, sb); };
-    for (int i = 0; i < warmup; ++i) CK(go());
-    hipEvent_t e0, e1;
-    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-    RAMP_HIP_CHECK(hipEventRecord(e0, sb));
-    int rcb = 0;
-    for (int i = 0; i < iters && rcb == 0; ++i) { rcb = go(); if (rcb == 0) STRESS(G, (size_t)M * 768, sb); }
-    RAMP_HIP_CHECK(hipEventRecord(e1, sb));
-    RAMP_HIP_CHECK(hipEventSynchronize(e1));
-    float msb = 0.f;
-    RAMP_HIP_CHECK(hipEventElapsedTime(&msb, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = msb * 1e3f / iters;
-    return rcb;
-  }
-  if (mode == 12) {                                    // tkc.hip: k = 5 convolution with C_in, C_out in {32, 64} on sample-owning waves; flags 1 bias, 2 residual, 4 input gradient,
-                                                       // 8 GroupNorm + Mish epilogue, 16 GroupNorm-backward operand
-    hipStream_t sc = as_stream(stream);
-    DevArena arc;
-    RAMP_REQUIRE(taps == 5 && tkc_applicable(M, L, N, K, nullptr), "mode 12: k = 5, C in {32, 64}, L >= 8 dividing 48 or 32");
-    float* X = arc.alloc((size_t)M * K); float* Y = arc.alloc((size_t)M * N); float* R = arc.alloc((size_t)M * N); float* W = arc.alloc((size_t)5 * N * K);
-    float* b = arc.alloc(N); float* sl = arc.alloc(4);
-    float* Cs = arc.alloc((size_t)M * 64); float* gm = arc.alloc(64); float* bt = arc.alloc(64); float* st = arc.alloc((size_t)(M / L) * 16);
-    unsigned short* pl = reinterpret_cast<unsigned short*>(arc.alloc(tkc_packed_halves(N, K) / 2 + 4));
-    RAMP_REQUIRE(X && Y && R && W && b && sl && pl && Cs && gm && bt && st, "hipMalloc failed");
-    auto fill = [&](float* p, size_t n, unsigned seed, float scv) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sc, p, (long)n, seed, scv); };
-    fill(X, (size_t)M * K, 1u, 1.f); fill(R, (size_t)M * N, 4u, 1.f); fill(W, (size_t)5 * N * K, 2u, 1.f / 16.f); fill(b, N, 5u, 1.f);
-    CK(init_tkc_attributes());
-    CK(tkc_pack(W, N, K, 16384.f, pl, sc));
-    const float one[4] = {(flags & 16) ? 8.f : 1.f, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, sc));
-    TkcArgs t; t.M = M; t.L = L; t.N = N; t.K = K; t.dir = (flags & 4) ? -1 : 1; t.X = X; t.ldx = K; t.W = pl; t.Y = Y; t.ldy = N;
-    if (flags & 1) t.bias = b;
-    if (flags & 2) { t.resid = R; t.ldr = N; }
-    if (flags & 24) { fill(gm, 64, 6u, 1.f); fill(bt, 64, 7u, 0.5f); fill(Cs, (size_t)M * 64, 8u, 1.f); }
-    if (flags & 16) {
-      GnArgs g; g.x = Cs; g.gamma = gm; g.beta = bt; g.y = Y; g.stats = st; g.R = M / L; g.L = L; g.C = K; g.eps = 1e-5f; g.mish = 1;
-      RAMP_REQUIRE(N >= K, "mode 12 with flag 16: the scratch of the statistics pass is the output");
-      CK(launch_gn_fwd(g, sc));
-      t.gn_c = Cs; t.gn_stats = st; t.gn_gamma = gm; t.gn_beta = bt;
-    }
-    if (flags & 8) { t.bias = b; t.Cst = Cs; t.stats = st; t.gamma = gm; t.beta = bt; t.tbias = b; }
-    t.amax_in = sl; t.amax_out = sl + 1; t.wsi = 1.f / 16384.f; t.range_flag = reinterpret_cast<int*>(sl + 2);
-    for (int i = 0; i < warmup; ++i) CK(launch_tkc(t, sc));
-    hipEvent_t e0, e1;
-    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-    RAMP_HIP_CHECK(hipEventRecord(e0, sc));
-    int rcc = 0;
-    for (int i = 0; i < iters && rcc == 0; ++i) { rcc = launch_tkc(t, sc); if (rcc == 0) STRESS(Y, (size_t)M * N, sc); }
-    RAMP_HIP_CHECK(hipEventRecord(e1, sc));
-    RAMP_HIP_CHECK(hipEventSynchronize(e1));
-    float msc = 0.f;
-    RAMP_HIP_CHECK(hipEventElapsedTime(&msc, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = msc * 1e3f / iters;
-    return rcc;
-  }
-  if (mode == 10 || mode == 11) {                      // atk.hip: self-attention + out-projection in one launch (10) / the pair it replaces:
-                                                       // attn2_fwd + token-owning out-projection (11).  L = tokens per sample; flags 1: row-variant constant
-    hipStream_t sa = as_stream(stream);
-    DevArena ara;
-    RAMP_REQUIRE(L >= 1 && M % L == 0, "mode 10 / 11: M must be whole samples of L tokens");
-    float* Q = ara.alloc((size_t)M * 768); float* R = ara.alloc((size_t)M * 256); float* Y = ara.alloc((size_t)M * 256); float* O = ara.alloc((size_t)M * 256);
-    float* W = ara.alloc(256 * 256); float* b = ara.alloc(256); float* rbv = ara.alloc(4 * 256); float* sl = ara.alloc(4);
-    int* rv = reinterpret_cast<int*>(ara.alloc((size_t)M / L + 4));
-    unsigned short* ws = reinterpret_cast<unsigned short*>(ara.alloc(8 * 8192 + 4));
-    unsigned short* p8 = reinterpret_cast<unsigned short*>(ara.alloc((size_t)256 * 256 + 4));
-    RAMP_REQUIRE(Q && R && Y && O && W && b && rbv && sl && rv && ws && p8, "hipMalloc failed");
-    auto fill = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, sa, p, (long)n, seed, sc); };
-    fill(Q, (size_t)M * 768, 1u, 1.5f); fill(R, (size_t)M * 256, 4u, 1.f); fill(W, 256 * 256, 2u, 1.f / 16.f); fill(b, 256, 5u, 1.f); fill(rbv, 1024, 6u, 1.f);
-    const int pat[2] = {0, 1};
-    int* dpat = reinterpret_cast<int*>(ara.alloc(4));
-    RAMP_REQUIRE(dpat, "hipMalloc failed");
-    RAMP_HIP_CHECK(hipMemcpyAsync(dpat, pat, sizeof(pat), hipMemcpyHostToDevice, sa));
-    hipLaunchKernelGGL(fill_pattern_kernel, dim3(64), dim3(256), 0, sa, rv, dpat, 2, M / L);
-    CK(init_atk_attributes());
-    CK(ato_pack(W, 16384.f, ws, sa));
-    CK(launch_pack_h3(W, p8, 256, 256, 16384.f, sa));
-    const float one[4] = {1.5f, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, sa));
-    AtoArgs a; a.M = M; a.L = L; a.QKV = Q; a.W = ws; a.bias = b; a.resid = R; a.Y = Y; a.amax_in = sl; a.amax_out = sl + 1; a.wsi = 1.f / 16384.f;
-    a.range_flag = reinterpret_cast<int*>(sl + 2);
-    if (flags & 1) { a.rowbias = rbv; a.rowvar = rv; a.rb_stride = 256; a.n_var = 2; }
-    TklArgs t; t.M = M; t.N = 256; t.X = O; t.Y = Y; t.ldy = 256; t.W = p8; t.bias = b; t.resid = R; t.ldr = 256; t.amax_in = sl; t.amax_out = sl + 1; t.wsi = 1.f / 16384.f;
-    t.range_flag = reinterpret_cast<int*>(sl + 2);
-    if (flags & 1) { t.rowbias = rbv; t.rowvar = rv; t.rb_stride = 256; t.L = L; t.n_var = 2; }
-    auto go = [&]() -> int {
-      if (mode == 10) return launch_ato(a, sa);
-      if (int rc = launch_attn_fwd(Q, O, M / L, L, sa)) return rc;
-      return launch_tkl(t, sa);
-    };
-    unsigned long long* stamps = nullptr;
-    if (flags & 256) {                                   // the stamped twin: where a head step's cycles go
-      stamps = reinterpret_cast<unsigned long long*>(ara.alloc(256 * 4 * 8 * 2));
-      RAMP_REQUIRE(stamps && mode == 10 && (flags & 1), "stamps: mode 10 with flags & 1");
-      RAMP_HIP_CHECK(hipMemsetAsync(stamps, 0, 256 * 4 * 8 * 8, sa));
-      a.stamps = stamps; a.ablate = (flags >> 9) & 7;
-    }
-    for (int i = 0; i < warmup; ++i) CK(go());
-    hipEvent_t e0, e1;
-    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-    RAMP_HIP_CHECK(hipEventRecord(e0, sa));
-    int rca = 0;
-    for (int i = 0; i < iters && rca == 0; ++i) { rca = go(); if (rca == 0) STRESS(Y, (size_t)M * 256, sa); }
-    RAMP_HIP_CHECK(hipEventRecord(e1, sa));
-    RAMP_HIP_CHECK(hipEventSynchronize(e1));
-    float msa = 0.f;
-    RAMP_HIP_CHECK(hipEventElapsedTime(&msa, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = msa * 1e3f / iters;
-    if (rca == 0 && stamps) {
-      std::vector<unsigned long long> hst(256 * 4 * 8);
-      RAMP_HIP_CHECK(hipMemcpy(hst.data(), stamps, hst.size() * 8, hipMemcpyDeviceToHost));
-      double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nw = 0;
-      for (int w = 0; w < 1024; ++w) if (hst[w * 8 + 6]) { ++nw; for (int j = 0; j < 8; ++j) sm[j] += (double)hst[w * 8 + j]; }
-      const int T4 = 192, n_tiles = (M + T4 - 1) / T4;
-      const double steps = std::max(1, nw) * 4.0 * (double)((n_tiles + 255) / 256);
-      fprintf(stderr, "[ato stamps] per head step (s_memtime ticks, %d waves): epilogue + loop top %.0f, head-start wait %.0f, S^T + softmax %.0f, PV %.0f, "
-              "barriers %.0f, DMA issue + slab bodies %.0f; whole kernel %.0f per step; shader clock %.0f MHz\n",
-              nw, sm[0] / steps, sm[1] / steps, sm[2] / steps, sm[3] / steps, sm[4] / steps, sm[5] / steps, sm[6] / steps, sm[7] > 0 ? sm[6] / sm[7] * 100.0 : 0.0);
-    }
-    return rca;
-  }
-  if (mode == 6 || mode == 7) {                        // ffx.hip: fused feed-forward with token-owning waves, forward / backward
-    hipStream_t s6 = as_stream(stream);
-    DevArena ar6;
-    const size_t mt = ((size_t)M + 127) / 128;
-    float* z1 = ar6.alloc((size_t)M * 256); float* dz = ar6.alloc((size_t)M * 256); float* out = ar6.alloc((size_t)M * 256);
-    float* W1 = ar6.alloc(2048 * 256); float* W2 = ar6.alloc(256 * 1024); float* b1 = ar6.alloc(2048); float* b2 = ar6.alloc(256);
-    float* lg = ar6.alloc(256); float* lb = ar6.alloc(256); float* stash = ar6.alloc(mt * 128 * 2048); float* sl = ar6.alloc(12);
-    RAMP_REQUIRE(z1 && dz && out && W1 && W2 && b1 && b2 && lg && lb && stash && sl, "hipMalloc failed");
-    auto fill6 = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s6, p, (long)n, seed, sc); };
-    fill6(z1, (size_t)M * 256, 1u, 1.f); fill6(dz, (size_t)M * 256, 7u, 1.f); fill6(W1, 2048 * 256, 2u, 1.f / 16.f); fill6(W2, 256 * 1024, 3u, 1.f / 32.f);
-    fill6(b1, 2048, 5u, 1.f); fill6(b2, 256, 6u, 1.f); fill6(lg, 256, 8u, 1.f); fill6(lb, 256, 9u, 1.f);
-    FfxPack pk;
-    const bool s16 = (flags >> 16) & 1;                  // flags bit 16: the v_mfma_f32_16x16x32_f16 pair (ffx16.hip)
-    CK(ffx_pack_all(ar6, W1, b1, W2, &pk, s6, s16));
-    auto launch_ffx = [s16](const FfxArgs& a, bool bwd, hipStream_t st) { return s16 ? ramp::launch_ffx16(a, bwd, st) : ramp::launch_ffx(a, bwd, st); };
-    const float one[12] = {4.f, 2.f, 1.f, 1.f, 0, 0, 0, 0, 0, 0, 0, 0};
-    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, s6));
-    FfxArgs f; f.M = M; f.X = z1; f.Z1 = z1; f.Y = out; f.stash = stash; f.ln_g = lg; f.ln_b = lb; f.Wstream = pk.stream_f; f.b1 = pk.b1_pk; f.b2 = b2;
-    f.amax_in1 = sl; f.amax_out1 = sl + 4; f.wsi1 = pk.wsi_w1; f.amax_in2 = sl + 1; f.amax_out2 = sl + 5; f.wsi2 = pk.wsi_w2; f.site2 = 1;
-    f.range_flag = reinterpret_cast<int*>(sl + 8); f.ablate = (flags >> 8) & 255;
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ar6.alloc(256 * 4 * 6 * 2));
-    if (f.ablate & 64) { RAMP_REQUIRE(stamps, "hipMalloc failed"); RAMP_HIP_CHECK(hipMemsetAsync(stamps, 0, 256 * 4 * 6 * 8, s6)); f.stamps = stamps; }
-    FfxArgs g = f; g.X = dz; g.Wstream = pk.stream_b; g.amax_in1 = sl + 2; g.amax_out1 = sl + 6; g.wsi1 = pk.wsi_w2; g.amax_in2 = sl + 3; g.amax_out2 = sl + 7; g.wsi2 = pk.wsi_w1;
-    CK(launch_ffx(f, false, s6));                        // the backward kernel reads this stash
-    auto go6 = [&]() { return mode == 6 ? launch_ffx(f, false, s6) : launch_ffx(g, true, s6); };
-    for (int i = 0; i < warmup; ++i) CK(go6());
-    hipEvent_t e0, e1;
-    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-    RAMP_HIP_CHECK(hipEventRecord(e0, s6));
-    int rc6 = 0;
-    for (int i = 0; i < iters && rc6 == 0; ++i) { rc6 = go6(); if (rc6 == 0) STRESS(out, (size_t)M * 256, s6); }
-    RAMP_HIP_CHECK(hipEventRecord(e1, s6));
-    RAMP_HIP_CHECK(hipEventSynchronize(e1));
-    float ms6 = 0.f;
-    RAMP_HIP_CHECK(hipEventElapsedTime(&ms6, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = ms6 * 1e3f / iters;
-    if (rc6 == 0 && (f.ablate & 64)) {                   // per-wave cycle sums of the LAST launch, averaged, on stderr
-      std::vector<unsigned long long> h(256 * 4 * 6);
-      RAMP_HIP_CHECK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
-      double sm[6] = {0, 0, 0, 0, 0, 0}; int nw = 0;
-      for (int w = 0; w < 1024; ++w) if (h[w * 6 + 5]) { ++nw; for (int j = 0; j < 6; ++j) sm[j] += (double)h[w * 6 + j]; }
-      const double slabs = std::max(1, nw) * 96.0 * (double)((mt + 255) / 256);
-      fprintf(stderr, "[ffx stamps] per slab (s_memtime ticks): vm wait %.0f, barrier %.0f, DMA issue %.0f, body %.0f (%d waves); shader clock %.0f MHz\n",
-              sm[0] / slabs, sm[1] / slabs, sm[2] / slabs, sm[3] / slabs, nw, sm[5] > 0 ? sm[4] / sm[5] * 100.0 : 0.0);
-    }
-    return rc6;
-  }
-  if (mode == 9) {                                     // tkl.hip, tklb_kernel: d(ln1) + LayerNorm-1 backward (N, K ignored: 768 -> 256)
-    hipStream_t s9 = as_stream(stream);
-    DevArena ar9;
-    float* X9 = ar9.alloc((size_t)M * 768); float* Z9 = ar9.alloc((size_t)M * 256); float* A9 = ar9.alloc((size_t)M * 256); float* Y9 = ar9.alloc((size_t)M * 256);
-    float* W9 = ar9.alloc((size_t)256 * 768); float* lg = ar9.alloc(256); float* sl = ar9.alloc(4);
-    unsigned short* p9 = reinterpret_cast<unsigned short*>(ar9.alloc((size_t)256 * 768 + 4));
-    RAMP_REQUIRE(X9 && Z9 && A9 && Y9 && W9 && lg && sl && p9, "hipMalloc failed");
-    auto fill9 = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s9, p, (long)n, seed, sc); };
-    fill9(X9, (size_t)M * 768, 1u, 1.f); fill9(Z9, (size_t)M * 256, 3u, 1.f); fill9(A9, (size_t)M * 256, 4u, 1.f); fill9(W9, (size_t)256 * 768, 2u, 1.f / 16.f); fill9(lg, 256, 8u, 1.f);
-    CK(launch_pack_h3(W9, p9, 256, 768, 16384.f, s9));
-    const float one[4] = {1.f, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, s9));
-    TklbArgs a; a.M = M; a.X = X9; a.Z = Z9; a.add = A9; a.Y = Y9; a.W = p9; a.ln_g = lg; a.amax_in = sl; a.amax_out = sl + 1; a.wsi = 1.f / 16384.f;
-    a.range_flag = reinterpret_cast<int*>(sl + 2);
-    for (int i = 0; i < warmup; ++i) CK(launch_tklb(a, s9));
-    hipEvent_t e0, e1;
-    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-    RAMP_HIP_CHECK(hipEventRecord(e0, s9));
-    int rc9 = 0;
-    for (int i = 0; i < iters && rc9 == 0; ++i) { rc9 = launch_tklb(a, s9); if (rc9 == 0) STRESS(Y9, (size_t)M * 256, s9); }
-    RAMP_HIP_CHECK(hipEventRecord(e1, s9));
-    RAMP_HIP_CHECK(hipEventSynchronize(e1));
-    float ms9 = 0.f;
-    RAMP_HIP_CHECK(hipEventElapsedTime(&ms9, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = ms9 * 1e3f / iters;
-    return rc9;
-  }
-  if (mode == 8) {                                     // tkl.hip: token-owning linear, K = 256; flags: 1 LayerNorm first, 2 bias + residual, >> 8 ablation
-    hipStream_t s8 = as_stream(stream);
-    DevArena ar8;
-    RAMP_REQUIRE(K == 256 && N % 32 == 0 && N <= 768, "mode 8: K = 256, N a multiple of 32 up to 768");
-    float* X8 = ar8.alloc((size_t)M * 256); float* Y8 = ar8.alloc((size_t)M * N); float* R8 = ar8.alloc((size_t)M * N);
-    float* W8 = ar8.alloc((size_t)N * 256); float* b8 = ar8.alloc(N); float* lg = ar8.alloc(256); float* lb = ar8.alloc(256); float* sl = ar8.alloc(4);
-    unsigned short* p8 = reinterpret_cast<unsigned short*>(ar8.alloc((size_t)N * 256 + 4));
-    RAMP_REQUIRE(X8 && Y8 && R8 && W8 && b8 && lg && lb && sl && p8, "hipMalloc failed");
-    auto fill8 = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s8, p, (long)n, seed, sc); };
-    fill8(X8, (size_t)M * 256, 1u, 1.f); fill8(R8, (size_t)M * N, 4u, 1.f); fill8(W8, (size_t)N * 256, 2u, 1.f / 16.f); fill8(b8, N, 5u, 1.f);
-    fill8(lg, 256, 8u, 1.f); fill8(lb, 256, 9u, 1.f);
-    CK(launch_pack_h3(W8, p8, N, 256, 16384.f, s8));
-    const float one[4] = {(flags & 1) ? 4.f : 1.f, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, s8));
-    TklArgs a; a.M = M; a.N = N; a.X = X8; a.Y = Y8; a.ldy = N; a.W = p8; a.amax_in = sl; a.amax_out = sl + 1; a.wsi = 1.f / 16384.f;
-    a.range_flag = reinterpret_cast<int*>(sl + 2); a.ablate = (flags >> 8) & 255;
-    if (flags & 1) { a.ln_g = lg; a.ln_b = lb; }
-    if (flags & 2) { a.bias = b8; a.resid = R8; a.ldr = N; }
-    for (int i = 0; i < warmup; ++i) CK(launch_tkl(a, s8));
-    hipEvent_t e0, e1;
-    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-    RAMP_HIP_CHECK(hipEventRecord(e0, s8));
-    int rc8 = 0;
-    for (int i = 0; i < iters && rc8 == 0; ++i) { rc8 = launch_tkl(a, s8); if (rc8 == 0) STRESS(Y8, (size_t)M * N, s8); }
-    RAMP_HIP_CHECK(hipEventRecord(e1, s8));
-    RAMP_HIP_CHECK(hipEventSynchronize(e1));
-    float ms8 = 0.f;
-    RAMP_HIP_CHECK(hipEventElapsedTime(&ms8, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = ms8 * 1e3f / iters;
-    return rc8;
-  }
-  if (mode == 5) {                                     // the fused FF1 -> GEGLU -> FF2 kernel (N, K ignored: 256 -> 2 x 1024 -> 256)
-    hipStream_t s5 = as_stream(stream);
-    DevArena ar5;
-    float* A5 = ar5.alloc((size_t)M * 256); float* W1 = ar5.alloc(2048 * 256); float* W2 = ar5.alloc(256 * 1024);
-    float* st5 = ar5.alloc((size_t)M * 2048); float* z1 = ar5.alloc((size_t)M * 256); float* z2 = ar5.alloc((size_t)M * 256);
-    float* b1 = ar5.alloc(2048); float* b2 = ar5.alloc(256); float* sl = ar5.alloc(8);
-    unsigned short* p1 = reinterpret_cast<unsigned short*>(ar5.alloc(2048 * 256 + 4));
-    unsigned short* p2 = reinterpret_cast<unsigned short*>(ar5.alloc(256 * 1024 + 4));
-    RAMP_REQUIRE(A5 && W1 && W2 && st5 && z1 && z2 && b1 && b2 && sl && p1 && p2, "hipMalloc failed");
-    auto fill5 = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s5, p, (long)n, seed, sc); };
-    fill5(A5, (size_t)M * 256, 1u, 1.f); fill5(W1, 2048 * 256, 2u, 1.f / 16.f); fill5(W2, 256 * 1024, 3u, 1.f / 32.f);
-    fill5(z1, (size_t)M * 256, 4u, 1.f); fill5(b1, 2048, 5u, 1.f); fill5(b2, 256, 6u, 1.f);
-    const float one[8] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
-    RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, 32, hipMemcpyHostToDevice, s5));
-    CK(launch_pack_h3(W1, p1, 2048, 256, 16384.f, s5)); CK(launch_pack_h3(W2, p2, 256, 1024, 32768.f, s5));
-    GemmArgs g1; g1.A = A5; g1.lda = 256; g1.W = W1; g1.Wx = p1; g1.wx_packed = 2; g1.w_scale_inv = 1.f / 16384.f; g1.bias = b1;
-    g1.C = st5; g1.ldc = 2048; g1.M = M; g1.N = 2048; g1.K = 256; g1.epi = EPI_GEGLU_FWD; g1.geglu_group = 32;
-    g1.a_absmax_in = sl; g1.a_absmax_out = sl + 1; g1.range_flag = reinterpret_cast<int*>(sl + 2); g1.ablate = (flags >> 8) & 31;
-    GemmArgs g2; g2.W = W2; g2.Wx = p2; g2.wx_packed = 2; g2.w_scale_inv = 1.f / 32768.f; g2.bias = b2; g2.resid = z1; g2.ldr = 256;
-    g2.C = z2; g2.ldc = 256; g2.M = M; g2.N = 256; g2.K = 1024;
-    g2.a_absmax_in = sl + 4; g2.a_absmax_out = sl + 5; g2.range_flag = reinterpret_cast<int*>(sl + 6); g2.site_id = 1;
-    for (int i = 0; i < warmup; ++i) CK(launch_ff_fwd(g1, g2, s5));
-    hipEvent_t e0, e1;
-    RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-    RAMP_HIP_CHECK(hipEventRecord(e0, s5));
-    int rc5 = 0;
-    for (int i = 0; i < iters && rc5 == 0; ++i) { rc5 = launch_ff_fwd(g1, g2, s5); if (rc5 == 0) STRESS(z2, (size_t)M * 256, s5); }
-    RAMP_HIP_CHECK(hipEventRecord(e1, s5));
-    RAMP_HIP_CHECK(hipEventSynchronize(e1));
-    float ms5 = 0.f;
-    RAMP_HIP_CHECK(hipEventElapsedTime(&ms5, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = ms5 * 1e3f / iters;
-    return rc5;
-  }
-  hipStream_t s = as_stream(stream);
-  DevArena ar;
-  auto fill = [&](float* p, size_t n, unsigned seed, float sc) {
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s, p, (long)n, seed, sc);
-  };
-  const bool geglu = flags & 4, amul = flags & 8;
-  const int Ka = amul ? K / 2 : K;
-  float* A = ar.alloc((size_t)M * Ka); float* W = ar.alloc((size_t)taps * N * K); float* C = ar.alloc((size_t)M * N);
-  float* bias = ar.alloc(N); float* R = (flags & 2) ? ar.alloc((size_t)M * N) : nullptr;
-  float* aux = geglu ? ar.alloc((size_t)M * N / 2) : nullptr; float* mul = amul ? ar.alloc((size_t)M * K) : nullptr;
-  float* slots = ar.alloc(4);
-  RAMP_REQUIRE(A && W && C && bias && slots && (!(flags & 2) || R) && (!geglu || aux) && (!amul || mul), "hipMalloc failed");
-  fill(A, (size_t)M * Ka, 1u, 1.f); fill(W, (size_t)taps * N * K, 2u, 1.f / std::sqrt((float)K * taps)); fill(bias, N, 3u, 1.f);
-  if (R) fill(R, (size_t)M * N, 4u, 1.f);
-  if (mul) fill(mul, (size_t)M * K, 5u, 1.f);
-  RAMP_HIP_CHECK(hipMemsetAsync(slots, 0, 16, s));
-  const float one = 1.f;
-  RAMP_HIP_CHECK(hipMemcpyAsync(slots, &one, 4, hipMemcpyHostToDevice, s));
-  GemmArgs a; a.A = A; a.lda = Ka; a.W = W; a.bias = (flags & 1) ? bias : nullptr; a.resid = R; a.ldr = N; a.C = C; a.ldc = N;
-  a.M = M; a.N = N; a.K = K; a.taps = taps; a.L = L;
-  if (taps > 1) { a.shift0 = -(taps / 2); a.shift_step = 1; }
-  if (geglu) { a.epi = EPI_GEGLU_FWD; a.aux_out = aux; a.ld_aux = N / 2; a.geglu_group = (mode == 1 || mode == 3) ? 32 : 64; }
-  if (amul) { a.Amul = mul; a.lda_mul = K; a.a_period = Ka; }
-  a.tile_pref = (flags & 16) ? 1 : (flags & 32) ? 3 : 0;
-  a.ablate = ((flags >> 8) & 255) | ((flags & (1 << 30)) ? 256 : 0);
-  const long n = (long)taps * N * K;
-  const bool frag_ok = N >= 64 && N % 32 == 0 && K % 16 == 0;
-  unsigned short* planes = nullptr;
-  RAMP_REQUIRE(mode != 4, "mode 4 (the experimental LDS-DMA tile GEMM) was removed from the library in round 5");
-  if (mode == 3 && frag_ok) {
-    planes = reinterpret_cast<unsigned short*>(ar.alloc((size_t)n + 4));
-    RAMP_REQUIRE(planes, "hipMalloc failed");
-    const float sc = std::ldexp(1.f, 10) * std::sqrt((float)K * taps);      // max |w| ~ 1 / sqrt(K taps)
-    float scp = 1.f; { int e; std::frexp(sc, &e); scp = std::ldexp(1.f, e - 1); }
-    CK(launch_pack_h3(W, planes, (long)taps * N, K, scp, s));
-    a.Wx = planes; a.wx_packed = 2; a.w_scale_inv = 1.f / scp;
-    a.a_absmax_in = slots; a.a_absmax_out = slots + 1; a.range_flag = reinterpret_cast<int*>(slots + 2);
-  } else if (mode == 1 && frag_ok) {
-    planes = reinterpret_cast<unsigned short*>(ar.alloc((3 * (size_t)n + 1) / 2 + 4));
-    RAMP_REQUIRE(planes, "hipMalloc failed");
-    CK(launch_pack_x6(W, planes, (long)taps * N, K, s));
-    a.Wx = planes; a.wx_packed = 1;
-  } else if ((mode == 1 || mode == 2) && N >= 128) {
-    planes = reinterpret_cast<unsigned short*>(ar.alloc((3 * (size_t)n + 1) / 2 + 4));
-    RAMP_REQUIRE(planes, "hipMalloc failed");
-    CK(launch_split3(W, planes, n, s));
-    a.Wx = planes; a.wx_plane = n;
-  }
-  auto go = [&]() { return launch_gemm(a, s); };
-  for (int i = 0; i < warmup; ++i) CK(go());
-  hipEvent_t e0, e1;
-  RAMP_HIP_CHECK(hipEventCreate(&e0)); RAMP_HIP_CHECK(hipEventCreate(&e1));
-  RAMP_HIP_CHECK(hipEventRecord(e0, s));
-  int rc = 0;
-  for (int i = 0; i < iters && rc == 0; ++i) { rc = go(); if (rc == 0) STRESS(C, (size_t)M * N, s); }
-  RAMP_HIP_CHECK(hipEventRecord(e1, s));
-  RAMP_HIP_CHECK(hipEventSynchronize(e1));
-  float ms = 0.f;
-  RAMP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  *avg_us = ms * 1e3f / iters;
-  return rc;
-}
-
-int ramp_stress_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, int32_t mode, int32_t flags, int32_t iters,
-                     int64_t* mismatching_words, float* rel_err_vs_fp32, void* stream) {
-  RAMP_REQUIRE(mismatching_words && iters >= 2, "bad arguments");
-  StressHook hook;
-  float us = 0.f;
-  g_stress = &hook;
-  int rc = 0;
-  if (rel_err_vs_fp32 && mode >= 1 && mode <= 3) {     // the same operands (seeded fills) on the exact-fp32 MFMA kernel first
-    hook.capture_ref = true;
-    rc = ramp_bench_gemm(M, N, K, taps, L, 0, flags & 0xff, 0, 1, &us, stream);
-    hook.capture_ref = false;
-  }
-  if (rc == 0) rc = ramp_bench_gemm(M, N, K, taps, L, mode, flags, 0, iters, &us, stream);
-  g_stress = nullptr;
-  if (rc != 0) return rc;
-  unsigned long long h[2] = {0, 0};
-  RAMP_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-  if (hook.mism) RAMP_HIP_CHECK(hipMemcpy(h, hook.mism, 16, hipMemcpyDeviceToHost));
-  RAMP_REQUIRE(hook.launches == iters, "stress hook did not see every launch");
-  *mismatching_words = (int64_t)h[0];
-  if (rel_err_vs_fp32) {
-    const unsigned e = (unsigned)(h[1] & 0xffffffffu), r = (unsigned)(h[1] >> 32);
-    const float ef = __builtin_bit_cast(float, e), rf = __builtin_bit_cast(float, r);
-    *rel_err_vs_fp32 = (hook.ref && rf > 0.f) ? ef / rf : -1.f;
-  }
-  return 0;
-}
-
-int ramp_op_groupnorm(const float* x, const float* gamma, const float* beta, const float* tbias, const float* resid,
-                      float* y, float* stats, int32_t R, int32_t L, int32_t C, float eps, int32_t mish, void* stream) {
-  RAMP_REQUIRE(x && gamma && beta && y, "null argument");
-  GnArgs g; g.x = x; g.gamma = gamma; g.beta = beta; g.tbias = tbias; g.resid = resid; g.y = y; g.stats = stats;
-  g.R = R; g.L = L; g.C = C; g.eps = eps; g.mish = mish;
-  return launch_gn_fwd(g, as_stream(stream));
-}
-int ramp_op_groupnorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta,
-                          const float* add, float* dx, int32_t R, int32_t L, int32_t C, int32_t mish, void* stream) {
-  RAMP_REQUIRE(dy && x && stats && gamma && beta && dx, "null argument");
-  GnBwdArgs g; g.dy = dy; g.x = x; g.stats = stats; g.gamma = gamma; g.beta = beta; g.add = add; g.dx = dx;
-  g.R = R; g.L = L; g.C = C; g.mish = mish;
-  return launch_gn_bwd(g, as_stream(stream));
-}
-int ramp_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t n_tok, void* stream) {
-  RAMP_REQUIRE(x && gamma && beta && y, "null argument");
-  return launch_ln_fwd(x, gamma, beta, y, n_tok, as_stream(stream));
-}
-int ramp_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
-                          int32_t n_tok, void* stream) {
-  RAMP_REQUIRE(dy && x && gamma && dx, "null argument");
-  return launch_ln_bwd(dy, x, gamma, add, dx, n_tok, as_stream(stream));
-}
-int ramp_op_geglu(const float* ag, float* hg, int32_t n_tok, int32_t F, void* stream) {
-  RAMP_REQUIRE(ag && hg, "null argument");
-  return launch_geglu_fwd(ag, hg, n_tok, F, as_stream(stream));
-}
-int ramp_op_geglu_bwd(const float* dhg, const float* ag, float* dag, int32_t n_tok, int32_t F, void* stream) {
-  RAMP_REQUIRE(dhg && ag && dag, "null argument");
-  return launch_geglu_bwd(dhg, ag, dag, n_tok, F, as_stream(stream));
-}
-int ramp_op_attention(const float* qkv, float* o, int32_t R, int32_t L, void* stream) {
-  RAMP_REQUIRE(qkv && o, "null argument");
-  return launch_attn_fwd(qkv, o, R, L, as_stream(stream));
-}
-int ramp_op_attention_bwd(const float* qkv, const float* dout, float* dqkv, int32_t R, int32_t L, void* stream) {
-  RAMP_REQUIRE(qkv && dout && dqkv, "null argument");
-  return launch_attn_bwd(qkv, dout, dqkv, R, L, as_stream(stream));
 }
 
 int ramp_debug_read(ramp_ctx* c, const char* kind, const char* module, float* out, int64_t n_floats,

@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 cases = ((48, 4096), (48, 8192), (24, 8192), (12, 8192), (6, 8192))
 if len(sys.argv) > 1:
     cases = cases[:int(sys.argv[1])] if sys.argv[1].isdigit() else cases
@@ -18,11 +18,11 @@ for L, R in cases:
         best = 1e30
         for _ in range(2):
             us = C.c_float(0)
-            _lib.check(lib.ramp_bench_gemm(M, 256, 256, 1, L, mode, 0, 3, 10, C.byref(us), None), "ramp_bench_gemm")
+            _lib.check_tools(lib.ramp_bench_gemm(M, 256, 256, 1, L, mode, 0, 3, 10, C.byref(us), None), "ramp_bench_gemm")
             best = min(best, us.value)
         row.append(best)
     print(f"L={L:3d} rows={R:5d} tokens={M:7d}: abl {row[0]:8.1f} us   atb + tklb {row[1]:8.1f} us   x{row[1] / row[0]:.2f}", flush=True)
 if "--stamps" in sys.argv:
     us = C.c_float(0)
-    _lib.check(lib.ramp_bench_gemm(48 * 8192, 256, 256, 1, 48, 15, 256, 2, 5, C.byref(us), None), "ramp_bench_gemm")
+    _lib.check_tools(lib.ramp_bench_gemm(48 * 8192, 256, 256, 1, 48, 15, 256, 2, 5, C.byref(us), None), "ramp_bench_gemm")
     print(f"stamped twin: {us.value:.1f} us", flush=True)

@@ -6,7 +6,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 for L, R in ((48, 4096), (48, 8192), (24, 8192), (12, 8192), (6, 8192)):
     M = L * R
     row = []
@@ -14,7 +14,7 @@ for L, R in ((48, 4096), (48, 8192), (24, 8192), (12, 8192), (6, 8192)):
         best = 1e30
         for _ in range(2):
             us = C.c_float(0)
-            _lib.check(lib.ramp_bench_gemm(M, 256, 256, 1, L, mode, 0, 3, 10, C.byref(us), None), "ramp_bench_gemm")
+            _lib.check_tools(lib.ramp_bench_gemm(M, 256, 256, 1, L, mode, 0, 3, 10, C.byref(us), None), "ramp_bench_gemm")
             best = min(best, us.value)
         row.append(best)
     by = M * 7168.0

@@ -10,7 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 samples = []
 stop = False
 
@@ -30,7 +30,7 @@ def run(label, M, N, K, mode, flags, secs=4.0, flops=None):
     us = C.c_float()
     t0 = time.time(); n0 = len(samples); last = 0.0
     while time.time() - t0 < secs:
-        _lib.check(lib.ramp_bench_gemm(M, N, K, 1, 1, mode, flags, 1, 200, C.byref(us), None))
+        _lib.check_tools(lib.ramp_bench_gemm(M, N, K, 1, 1, mode, flags, 1, 200, C.byref(us), None))
         last = us.value
     got = samples[n0:]
     sc = [int(s[1][0]) for s in got[len(got) // 2:] if s[1]]; pw = [float(s[2][0]) for s in got[len(got) // 2:] if s[2]]

@@ -6,12 +6,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 
 
 def t(M, mode, flags=0, iters=4):
     us = C.c_float()
-    _lib.check(lib.ramp_bench_gemm(M, 2048, 256, 1, 1, mode, flags, 2, iters, C.byref(us), None))
+    _lib.check_tools(lib.ramp_bench_gemm(M, 2048, 256, 1, 1, mode, flags, 2, iters, C.byref(us), None))
     return us.value
 
 

@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 dev = "cuda:0"
 
 
@@ -35,7 +35,7 @@ def check(M, seed=0):
     flag = C.c_int32(0)
     # first call: d(ag) unscaled (its maximum unknown); second call: scaled from the maximum the first recorded
     for it in range(2):
-        _lib.check(lib.ramp_op_ffx(_lib.ptr(z1), _lib.ptr(dz), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(g),
+        _lib.check_tools(lib.ramp_op_ffx(_lib.ptr(z1), _lib.ptr(dz), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(g),
                                    _lib.ptr(b), M, prev, _lib.ptr(z2), _lib.ptr(dz1), out, C.byref(flag), None), "ramp_op_ffx")
         e1 = (z2.double() - z2r).abs().max().item() / z2r.abs().max().item()
         e2 = (dz1.double() - dz1r).abs().max().item() / dz1r.abs().max().item()
@@ -47,7 +47,7 @@ def check(M, seed=0):
 
 def t(M, mode, flags=0, iters=5, N=2048, K=256):
     us = C.c_float()
-    _lib.check(lib.ramp_bench_gemm(M, N, K, 1, 1, mode, flags, 2, iters, C.byref(us), None))
+    _lib.check_tools(lib.ramp_bench_gemm(M, N, K, 1, 1, mode, flags, 2, iters, C.byref(us), None))
     return us.value
 
 

@@ -7,13 +7,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 M = 393216
 
 
 def t(N, K, flags, iters=6):
     us = C.c_float()
-    _lib.check(lib.ramp_bench_gemm(M, N, K, 1, 1, 3, flags, 2, iters, C.byref(us), None))
+    _lib.check_tools(lib.ramp_bench_gemm(M, N, K, 1, 1, 3, flags, 2, iters, C.byref(us), None))
     return us.value
 
 

@@ -6,12 +6,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 
 
 def bench(M, N, K, mode, taps=1, L=1, flags=0, iters=10, warmup=3):
     us = C.c_float()
-    _lib.check(lib.ramp_bench_gemm(M, N, K, taps, L, _lib.GEMM_MODES[mode], flags, warmup, iters, C.byref(us), None))
+    _lib.check_tools(lib.ramp_bench_gemm(M, N, K, taps, L, _lib.GEMM_MODES[mode], flags, warmup, iters, C.byref(us), None))
     tf = 2.0 * M * N * K * taps / (us.value * 1e-6) / 1e12
     print(f"{mode:8s} M={M:7d} N={N:5d} K={K:5d} taps={taps} flags={flags}: {us.value:9.1f} us  {tf:6.1f} TFLOP/s", flush=True)
     return us.value

@@ -10,5 +10,5 @@ M, N, K = (int(v) for v in sys.argv[1:4])
 mode = sys.argv[4] if len(sys.argv) > 4 else "fp16x3"
 flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 us = C.c_float()
-_lib.check(_lib.load().ramp_bench_gemm(M, N, K, 1, 1, _lib.GEMM_MODES[mode], flags, 2, 5, C.byref(us), None))
+_lib.check_tools(_lib.load_tools().ramp_bench_gemm(M, N, K, 1, 1, _lib.GEMM_MODES[mode], flags, 2, 5, C.byref(us), None))
 print(f"{mode} {M}x{N}x{K} flags {flags}: {us.value:.1f} us")

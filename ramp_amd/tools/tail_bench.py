@@ -1,10 +1,10 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
-lib = _lib.load()
+lib = _lib.load_tools()
 def t(M, N, K, taps, L, flags, iters=20):
     us = C.c_float()
-    _lib.check(lib.ramp_bench_gemm(M, N, K, taps, L, 3, flags, 3, iters, C.byref(us), None))
+    _lib.check_tools(lib.ramp_bench_gemm(M, N, K, taps, L, 3, flags, 3, iters, C.byref(us), None))
     return us.value
 for (M, N, K, taps, fl) in [(49152, 256, 256, 1, 3), (49152, 256, 1024, 1, 3), (49152, 256, 2048, 1, 3), (49152, 256, 768, 1, 3), (49152, 768, 256, 1, 1), (49152, 1024, 256, 1, 1), (49152, 256, 256, 5, 1),
                             (98304, 256, 256, 1, 3), (98304, 256, 1024, 1, 3)]:

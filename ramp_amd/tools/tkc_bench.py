@@ -7,14 +7,14 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 
 
 def t(M, N, K, L, mode, flags):
     best = 1e30
     for _ in range(2):
         us = C.c_float(0)
-        _lib.check(lib.ramp_bench_gemm(M, N, K, 5, L, mode, flags, 3, 10, C.byref(us), None), "ramp_bench_gemm")
+        _lib.check_tools(lib.ramp_bench_gemm(M, N, K, 5, L, mode, flags, 3, 10, C.byref(us), None), "ramp_bench_gemm")
         best = min(best, us.value)
     return best
 

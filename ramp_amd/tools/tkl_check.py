@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 dev = "cuda:0"
 
 
@@ -41,7 +41,7 @@ def check(M, N, ln, epi, seed=0, L=6):
     worst = 0.0
     for prev in (0.0, xmax):            # unscaled operand, then scaled from the maximum
         Y.fill_(float("nan"))
-        _lib.check(lib.ramp_op_tkl(p(X), p(W), p(bias), p(resid), p(rowbias), p(rowvar), n_var if epi & 2 else 0, L, p(g), p(b), M, N,
+        _lib.check_tools(lib.ramp_op_tkl(p(X), p(W), p(bias), p(resid), p(rowbias), p(rowvar), n_var if epi & 2 else 0, L, p(g), p(b), M, N,
                                    prev, p(Y), C.byref(out), C.byref(flag), None), "ramp_op_tkl")
         e = (Y.double() - ref).abs().max().item() / ref.abs().max().item()
         print(f"M={M} N={N} ln={int(ln)} epi={epi} prev={prev:.3f}: rel err {e:.2e}, recorded max {out.value:.4f} (expected {xmax:.4f}), "
@@ -53,7 +53,7 @@ def check(M, N, ln, epi, seed=0, L=6):
 
 def t(M, N, mode, flags=0, iters=10, K=256):
     us = C.c_float()
-    _lib.check(lib.ramp_bench_gemm(M, N, K, 1, 1, mode, flags, 3, iters, C.byref(us), None))
+    _lib.check_tools(lib.ramp_bench_gemm(M, N, K, 1, 1, mode, flags, 3, iters, C.byref(us), None))
     return us.value
 
 
@@ -75,7 +75,7 @@ if __name__ == "__main__":
             us = C.c_float()
             best = 1e30
             for _ in range(2):
-                _lib.check(lib.ramp_bench_gemm(M, 256, 768, 1, 1, 9, 0, 3, 10, C.byref(us), None)); best = min(best, us.value)
+                _lib.check_tools(lib.ramp_bench_gemm(M, 256, 768, 1, 1, 9, 0, 3, 10, C.byref(us), None)); best = min(best, us.value)
             b = min(t(M, 256, 3, 0, K=768) for _ in range(2))
             fl = 2.0 * M * 256 * 768
             print(f"M={M} d(ln1) + LN1 backward: tklb {best:7.1f} us ({fl / best / 1e6:4.0f} TF)   tile kernel alone {b:7.1f} us ({fl / b / 1e6:4.0f} TF; + ln_bwd)", flush=True)

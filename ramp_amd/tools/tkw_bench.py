@@ -8,13 +8,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ramp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_tools()
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 
 
 def t(M, N, K, L, mode, flags, taps=5):
     us = C.c_float(0)
-    _lib.check(lib.ramp_bench_gemm(M, N, K, taps, L, mode, flags, 5, 30, C.byref(us), None), "ramp_bench_gemm")
+    _lib.check_tools(lib.ramp_bench_gemm(M, N, K, taps, L, mode, flags, 5, 30, C.byref(us), None), "ramp_bench_gemm")
     return us.value
 
 

@@ -751,7 +751,7 @@ def test_gemm_variants_are_bitwise_stable_under_stress(name, M, N, K, taps, L, m
     rounding of the exact-fp32 MFMA kernel's on the same operands."""
     import ctypes as C
     mism, err = C.c_int64(-1), C.c_float(-2.0)
-    _lib.check(_lib.load().ramp_stress_gemm(M, N, K, taps, L, mode, flags, 300, C.byref(mism), C.byref(err) if vs_fp32 else None, None),
+    _lib.check_tools(_lib.load_tools().ramp_stress_gemm(M, N, K, taps, L, mode, flags, 300, C.byref(mism), C.byref(err) if vs_fp32 else None, None),
                "ramp_stress_gemm")
     print(f"{name}: 300 launches, {mism.value} differing words" + (f", first launch vs exact fp32: {err.value:.2e}" if vs_fp32 else ""))
     assert mism.value == 0, name
@@ -775,7 +775,7 @@ def test_soak_2000_launches_bitwise(name, M, N, K, taps, L, mode, flags):
     the suite runs on, not only the builder's (engineering 12)."""
     import ctypes as C
     mism = C.c_int64(-1)
-    _lib.check(_lib.load().ramp_stress_gemm(M, N, K, taps, L, mode, flags, 2000, C.byref(mism), None, None), "ramp_stress_gemm")
+    _lib.check_tools(_lib.load_tools().ramp_stress_gemm(M, N, K, taps, L, mode, flags, 2000, C.byref(mism), None, None), "ramp_stress_gemm")
     print(f"{name}: 2000 launches, {mism.value} differing words")
     assert mism.value == 0, name
 

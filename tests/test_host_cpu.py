@@ -25,6 +25,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} not exported"
         assert name in _lib.PROTOTYPES, f"{name} not bound in ramp_amd/_lib.py"
     assert lib.ramp_version() >= 1
+    # round 6: the micro-benchmark / stress harness is a tools-only library (csrc/bench.hip, include/ramp_hip_tools.h); the product
+    # library exports none of it, the tools library exports everything
+    import subprocess
+    exported = set(re.findall(r" T (ramp_[a-z0-9_]+)", subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout))
+    assert not [n for n in exported if n.startswith(("ramp_bench", "ramp_stress"))], "diagnostics leaked into the product library"
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))      # nothing undeclared either
+    thdr = open(os.path.join(ROOT, "include", "ramp_hip_tools.h")).read()
+    tdecl = set(re.findall(r"\b(ramp_[a-z0-9_]+)\s*\(", thdr)) - {"ramp_ctx"}
+    assert tdecl == set(_lib.TOOL_PROTOTYPES), (tdecl, set(_lib.TOOL_PROTOTYPES))
+    tools = _lib.load_tools()
+    for name in sorted(tdecl | declared):
+        assert hasattr(tools, name), f"{name} not exported by the tools library"
 
 
 def test_no_cpu_fallback():
