@@ -49,7 +49,25 @@ template <int V> using QO = std::integral_constant<int, V>;
 
 }  // namespace
 
-// ABL: 0 the product; 64 = whole-kernel clock stamp per wave (s_memtime / s_memrealtime) into f.stamps [block][wave][6] slots 4, 5
+namespace {
+// two floats x s (s a power of two) -> one dword of each fp16 plane, four instructions: hi = rn16(x s) and lo = rn16(x s - hi) both by
+// v_fma_mix{lo,hi}_f16 (fp32 fma rounded to fp16 once; x s and x s - hi are exact in fp32, so these are the bits of split4 on x s) -- no
+// separate scale multiply, no conversions back (7 instructions per pair the plain way).  MEASURED, NOT USED: 3 % (forward) / 7 % (backward) fewer
+// vector instructions in the loop and 0.4-0.9 % MORE time -- the asm pairs are invisible to sched_group_barrier and bunch where the compiler
+// drops them, as round 4 found for the 32x32x16 kernels; kept as the ABL 1 twin
+__device__ __forceinline__ void split2x(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+  unsigned h, l;
+  asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]"
+      : "=&v"(h) : "v"(x0), "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(l) : "v"(x0), "v"(x1), "v"(s), "v"(h));
+  hi = h; lo = l;
+}
+}  // namespace
+
+// ABL: 0 the product; 1 = the packs through split2x (A/B twin, same bits: measured 0.4-0.9 % SLOWER, profiles/r06_ab_same_box.txt); 64 = whole-kernel clock stamp per wave (s_memtime / s_memrealtime) into f.stamps [block][wave][6] slots 4, 5
 template <bool BWD, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ffx16_kernel(FfxArgs f, int n_mt) {
@@ -333,7 +351,7 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
             hq[q][e] = qa[q & 1][e] * s1q[e];                                // a * gelu(g)
           }
           amax_pin(amax2, hq[q][2 * hf], hq[q][2 * hf + 1]);
-          hq[q][2 * hf] *= s_2; hq[q][2 * hf + 1] *= s_2;
+          if (!(ABL & 1)) { hq[q][2 * hf] *= s_2; hq[q][2 * hf + 1] *= s_2; }      // (ABL 1: the scale rides in the split, split2x)
           if (hf == 1) {
             float* p = stash_w + (long)u * 8192;
             __builtin_nontemporal_store(s1q, reinterpret_cast<f32x4*>(p + (2 * q) * 256));      // (non-temporal: ffx.hip)
@@ -347,15 +365,19 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
         const f32x4 d = acc1[par][0][q] * os1;
         const f32x4 da = d * st1[q], dg = d * st2[q];
         amax_pin(amax2, da[0], da[1]); amax_pin(amax2, da[2], da[3]); amax_pin(amax2, dg[0], dg[1]); amax_pin(amax2, dg[2], dg[3]);
-        hq[q] = da * s_2; hq[4 + q] = dg * s_2;
+        if (!(ABL & 1)) { hq[q] = da * s_2; hq[4 + q] = dg * s_2; } else { hq[q] = da; hq[4 + q] = dg; }
       }
     };
     // B operand of token half t (backward: tt = 2 w + t): elements jj = 0..3 from the ft = 0 quad, 4..7 from the ft = 1 quad
-    auto pack1 = [&](int tt) __attribute__((always_inline)) { split8(hq[2 * tt], hq[2 * tt + 1], HB[tt][0], HB[tt][1]); };
     auto pack_half = [&](int t, int hf) __attribute__((always_inline)) {
       unsigned h0, h1, l0, l1;
-      split4(hq[2 * t + hf], h0, h1, l0, l1);
+      if (!(ABL & 1)) split4(hq[2 * t + hf], h0, h1, l0, l1);
+      else { const f32x4 v = hq[2 * t + hf]; split2x(v[0], v[1], s_2, h0, l0); split2x(v[2], v[3], s_2, h1, l1); }
       HB[t][0][2 * hf] = h0; HB[t][0][2 * hf + 1] = h1; HB[t][1][2 * hf] = l0; HB[t][1][2 * hf + 1] = l1;
+    };
+    auto pack1 = [&](int tt) __attribute__((always_inline)) {
+      if (!(ABL & 1)) split8(hq[2 * tt], hq[2 * tt + 1], HB[tt][0], HB[tt][1]);
+      else { pack_half(tt, 0); pack_half(tt, 1); }
     };
     auto E_step = [&](int u, int par, int idx, int n, int pack_from) __attribute__((always_inline)) {
       if constexpr (!BWD) {
@@ -615,6 +637,7 @@ int launch_ffx16(const FfxArgs& f, bool bwd, hipStream_t s) {
   const int nb = std::min(n_mt, device_cu_count());          // one 4-wave block per CU
 #define F6_GO(B, A) hipLaunchKernelGGL((ffx16_kernel<B, A>), dim3(nb), dim3(256), F6_LDS, s, f, n_mt)
   if (f.ablate == 0) { if (bwd) F6_GO(true, 0); else F6_GO(false, 0); }
+  else if (f.ablate == 1) { if (bwd) F6_GO(true, 1); else F6_GO(false, 1); }
   else if (f.ablate == 64) { if (bwd) F6_GO(true, 64); else F6_GO(false, 64); }
   else RAMP_REQUIRE(false, "ffx16: ablation variant not built");
 #undef F6_GO
@@ -624,7 +647,7 @@ int launch_ffx16(const FfxArgs& f, bool bwd, hipStream_t s) {
 
 int init_ffx16_attributes() {
 #define F6_ATTR(B, A) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffx16_kernel<B, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F6_LDS))
-  F6_ATTR(false, 0); F6_ATTR(true, 0); F6_ATTR(false, 64); F6_ATTR(true, 64);
+  F6_ATTR(false, 0); F6_ATTR(true, 0); F6_ATTR(false, 1); F6_ATTR(true, 1); F6_ATTR(false, 64); F6_ATTR(true, 64);
 #undef F6_ATTR
   return 0;
 }
