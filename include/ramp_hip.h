@@ -69,8 +69,8 @@ typedef struct ramp_launch_plan {
                            * GroupNorm + Mish fused -- forward: behind the convolution; input gradient: GroupNorm backward folded into the
                            * operand -- on sample-owning blocks (tkw.hip) from this many tokens, on levels whose token count (>= 3)
                            * divides 96: 0 never, 1 always */
-  int32_t mfma16;         /* the token-owning fused feed-forward issues v_mfma_f32_16x16x32_f16 (ffx16.hip, 1: the default) or
-                           * v_mfma_f32_32x32x16_f16 (ffx.hip, 0): same products and call sites, another summation tiling; the 16-wide
+  int32_t mfma16;         /* the token-owning kernels -- the fused feed-forward and the K = 256 attention linears -- issue v_mfma_f32_16x16x32_f16
+                           * (ffx16.hip / tkl16.hip, 1: the default) or v_mfma_f32_32x32x16_f16 (ffx.hip / tkl.hip, 0): same products and call sites, another summation tiling; the 16-wide
                            * shape holds a higher clock under the socket power cap (profiles/r06_mfma_shape_probe.txt).  Default from
                            * RAMP_MFMA16, read once in ramp_create */
 } ramp_launch_plan;
@@ -349,6 +349,10 @@ int ramp_op_ffx16(const float* z1, const float* dz, const float* W1, const float
 int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
                 const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
                 float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
+/* the same linear on the v_mfma_f32_16x16x32_f16 kernel (tkl16.hip; what the product runs with ramp_launch_plan.mfma16 = 1) */
+int ramp_op_tkl16(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
+                  const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
+                  float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
 /* Self-attention fused with its output projection (atk.hip; the product path's replacement of the attention kernel + the
  * out-projection launch -- reference layers_attention_mini.py:101-127 and :132):
  *   Y[m] = resid[m] + Wo softmax(q k^T / 8) v [m] + bias + rowbias[rowvar[m / L]],  4 heads x 64, softmax over the L tokens of

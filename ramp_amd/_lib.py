@@ -118,6 +118,7 @@ PROTOTYPES = {
     "ramp_op_ffx": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, c_f32p, C.c_void_p, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_ffx16": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, c_f32p, C.c_void_p, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_tkl": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
+    "ramp_op_tkl16": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_ato": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),
     "ramp_op_atb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ramp_op_abl": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p, c_f32p, c_i32p, C.c_void_p]),

@@ -385,7 +385,10 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     auto fill8 = [&](float* p, size_t n, unsigned seed, float sc) { hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s8, p, (long)n, seed, sc); };
     fill8(X8, (size_t)M * 256, 1u, 1.f); fill8(R8, (size_t)M * N, 4u, 1.f); fill8(W8, (size_t)N * 256, 2u, 1.f / 16.f); fill8(b8, N, 5u, 1.f);
     fill8(lg, 256, 8u, 1.f); fill8(lb, 256, 9u, 1.f);
-    CK(launch_pack_h3(W8, p8, N, 256, 16384.f, s8));
+    const bool s16 = (flags >> 16) & 1;                  // flags bit 16: the v_mfma_f32_16x16x32_f16 kernel (tkl16.hip)
+    if (s16) { float* tmp8 = ar8.alloc((size_t)N * 256); RAMP_REQUIRE(tmp8, "hipMalloc failed"); CK(ffx16_pack(W8, N, 256, 0, 16384.f, tmp8, p8, s8)); }
+    else CK(launch_pack_h3(W8, p8, N, 256, 16384.f, s8));
+    auto launch_tkl = [s16](const TklArgs& t, hipStream_t st) { return s16 ? ramp::launch_tkl16(t, st) : ramp::launch_tkl(t, st); };
     const float one[4] = {(flags & 1) ? 4.f : 1.f, 0.f, 0.f, 0.f};
     RAMP_HIP_CHECK(hipMemcpyAsync(sl, one, sizeof(one), hipMemcpyHostToDevice, s8));
     TklArgs a; a.M = M; a.N = N; a.X = X8; a.Y = Y8; a.ldy = N; a.W = p8; a.amax_in = sl; a.amax_out = sl + 1; a.wsi = 1.f / 16384.f;

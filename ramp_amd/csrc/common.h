@@ -183,6 +183,9 @@ struct TklArgs {
   int ablate = 0;                      // diagnostic (ramp_bench_gemm only)
 };
 int launch_tkl(const TklArgs& a, hipStream_t s);
+// the same linear on v_mfma_f32_16x16x32_f16 (tkl16.hip); W = ffx16_pack(W, N, 256, 0, ...) planes
+int launch_tkl16(const TklArgs& a, hipStream_t s);
+int init_tkl16_attributes();
 int init_tkl_attributes();
 // Token-owning d(ln1) with LayerNorm-1 backward in its epilogue (tkl.hip): out = add + LNbwd(X W^T; z, gamma), X = d(qkv) (M, 768),
 // W = Wqkv^T as [256][768] (fp16 fragment planes, launch_pack_h3), z = the LayerNorm's input (M, 256), add = the gradient that

@@ -176,6 +176,7 @@ struct ramp_ctx {
                                      // many tokens, on levels whose token count (>= 8) divides 48 or 32 (RAMP_TKC: 0 never, n that threshold)
   int tkw_min_rows = 16384;          // fp16x3 evaluations: the k = 5 convolutions with C_out in {128, 256, 512} with GroupNorm + Mish fused around them as
                                      // sample-owning blocks (tkw.hip) from this many tokens, on levels whose token count (>= 3) divides 96 (RAMP_TKW)
+  std::map<const float*, unsigned short*> tk16_w;          // K = 256 linear weight (fp32 base pointer) -> its 16 x 32 fragment planes (tkl16.hip; scale = the tile kernels' planes')
   struct TkcW { unsigned short* planes; float wsi; };
   std::map<const float*, TkcW> tkc_w;                       // fp32 conv weight [5][N][K] -> its tkc planes
   int share_prefix = 1;              // sampling jobs: rows of one trajectory share the network prefix (RAMP_SHARE_PREFIX=0: off)
@@ -491,7 +492,9 @@ struct Run {
     t.rowbias = a.rowbias; t.rowvar = a.rowvar; t.row0 = a.row0; t.rb_stride = a.rb_stride; t.L = a.L; t.n_var = a.rowbias ? c->n_variants : 0;
     t.ln_g = ln_g; t.ln_b = ln_b; t.amax_in = b.a_absmax_in; t.amax_out = b.a_absmax_out; t.wsi = b.w_scale_inv; t.site = b.site_id;
     t.range_flag = b.range_flag;
-    int rc = launch_tkl(t, s);
+    auto w16 = c->mfma16 ? c->tk16_w.find(a.W) : c->tk16_w.end();      // the same linear on v_mfma_f32_16x16x32_f16 (tkl16.hip): its own fragment planes, same scale
+    if (w16 != c->tk16_w.end()) t.W = w16->second;
+    int rc = w16 != c->tk16_w.end() ? launch_tkl16(t, s) : launch_tkl(t, s);
     prof_post(c, s);
     c->launches++;
     return rc;
@@ -1420,6 +1423,14 @@ int ramp_finalize_weights(ramp_ctx* c) {
           CK(ffx16_pack(k.w2_b, 1024, 256, 0, 1.f / e2.w_scale_inv, tmp, p1x, 0));
           CK(ffx16_pack(k.w1_b, 256, 2048, 2, 1.f / e1.w_scale_inv, tmp, p2b, 0));
           CK(ffx16_build_stream(p1x, p2b, k.ffx16_b, true, 0));
+          // ... and the K = 256 attention linears the token-owning kernel serves (LN1 -> QKV, out-projection, d(o)) for tkl16.hip
+          for (const auto& wn : {std::make_pair((const float*)k.wqkv_f, 768), std::make_pair((const float*)k.wo_f, 256), std::make_pair((const float*)k.wo_b, 256)}) {
+            const auto& ew = c->x6.at(wn.first);
+            if (!ew.packed3) continue;
+            float* q16; CK(dev_alloc(c, &q16, (size_t)wn.second * 256 + 4));          // 2 planes x N x 256 halves
+            CK(ffx16_pack(wn.first, wn.second, 256, 0, 1.f / ew.w_scale_inv, tmp, reinterpret_cast<unsigned short*>(q16), 0));
+            c->tk16_w[wn.first] = reinterpret_cast<unsigned short*>(q16);
+          }
         }
     }
     if (c->gemm_mode == 2 && c->x6_pipe) {
@@ -1466,7 +1477,7 @@ int ramp_finalize_weights(ramp_ctx* c) {
   RAMP_HIP_CHECK(hipDeviceSynchronize());
   CK(init_gemm_attributes());          // hipFuncSetAttribute calls must not happen inside a graph capture
   CK(init_attention_attributes());
-  CK(init_ffx_attributes()); CK(init_ffx16_attributes());
+  CK(init_ffx_attributes()); CK(init_ffx16_attributes()); CK(init_tkl16_attributes());
   CK(init_tkl_attributes());
   CK(init_atk_attributes());
   CK(init_atl_attributes());

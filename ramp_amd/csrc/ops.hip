@@ -246,9 +246,9 @@ int ramp_op_ffx16(const float* z1, const float* dz, const float* W1, const float
   return op_ffx_impl(z1, dz, W1, b1, W2, b2, ln_g, ln_b, M, absmax_prev_host, z2, dz1, absmax_out_host, range_flag_out_host, stream, true);
 }
 
-int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
-                const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
-                float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+static int op_tkl_impl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
+                       const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
+                       float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream, bool s16) {
   RAMP_REQUIRE(X && W && Y && M > 0 && N >= 32 && N % 32 == 0 && N <= 768, "bad arguments");
   hipStream_t s = as_stream(stream);
   DevArena ar;
@@ -261,14 +261,18 @@ int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* 
   unsigned short* planes = reinterpret_cast<unsigned short*>(ar.alloc((size_t)N * 256 + 4));
   float* slots = ar.alloc(4);
   RAMP_REQUIRE(planes && slots, "hipMalloc failed");
-  CK(launch_pack_h3(W, planes, N, 256, sc, s));
+  if (s16) {      // 16 x 32 fragments (tkl16.hip)
+    float* tmp = ar.alloc((size_t)N * 256);
+    RAMP_REQUIRE(tmp, "hipMalloc failed");
+    CK(ffx16_pack(W, N, 256, 0, sc, tmp, planes, s));
+  } else CK(launch_pack_h3(W, planes, N, 256, sc, s));
   const float host[4] = {absmax_prev, 0.f, 0.f, 0.f};
   RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, s));
   TklArgs a; a.M = M; a.N = N; a.X = X; a.Y = Y; a.ldy = N; a.W = planes; a.bias = bias; a.resid = resid; a.ldr = N;
   a.rowbias = rowbias; a.rowvar = rowvar; a.row0 = 0; a.rb_stride = N; a.L = L > 0 ? L : 1; a.n_var = n_var;
   a.ln_g = ln_g; a.ln_b = ln_b; a.amax_in = absmax_prev > 0.f ? slots : nullptr; a.amax_out = slots + 1; a.wsi = 1.f / sc; a.site = 0;
   a.range_flag = reinterpret_cast<int*>(slots + 2);
-  int rc = launch_tkl(a, s);
+  int rc = s16 ? launch_tkl16(a, s) : launch_tkl(a, s);
   hipError_t e = hipStreamSynchronize(s);
   float back[4] = {0, 0, 0, 0};
   if (rc == 0 && e == hipSuccess) {
@@ -278,6 +282,17 @@ int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* 
   }
   RAMP_HIP_CHECK(e);
   return rc;
+}
+
+int ramp_op_tkl(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
+                const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
+                float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  return op_tkl_impl(X, W, bias, resid, rowbias, rowvar, n_var, L, ln_g, ln_b, M, N, absmax_prev, Y, absmax_out_host, range_flag_out_host, stream, false);
+}
+int ramp_op_tkl16(const float* X, const float* W, const float* bias, const float* resid, const float* rowbias,
+                  const int32_t* rowvar, int32_t n_var, int32_t L, const float* ln_g, const float* ln_b, int32_t M, int32_t N,
+                  float absmax_prev, float* Y, float* absmax_out_host, int32_t* range_flag_out_host, void* stream) {
+  return op_tkl_impl(X, W, bias, resid, rowbias, rowvar, n_var, L, ln_g, ln_b, M, N, absmax_prev, Y, absmax_out_host, range_flag_out_host, stream, true);
 }
 
 int ramp_op_ato(const float* qkv, const float* Wo, const float* bias, const float* resid, const float* rowbias, const int32_t* rowvar,

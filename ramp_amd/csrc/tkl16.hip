@@ -1,0 +1,347 @@
+// The token-owning K = 256 linears of tkl.hip (LayerNorm-1 -> QKV, the attention output projection, its input gradient d(o);
+// layers_attention_mini.py:60-120, 130-149) on v_mfma_f32_16x16x32_f16 -- round 6, for the reason ffx16.hip gives: the MFMA + fragment-read loop
+// of this dataflow holds a higher clock under the socket power cap in the 16-wide shape at equal cycles per FLOP.  Same dataflow, ring,
+// epilogue pipeline and call-site handling as tkl_kernel; what changes:
+//   * lane (c, gq) = (lane & 15, lane >> 4) carries the tokens 16 t + c of the wave's two token halves, k = 8 gq .. 8 gq + 7 of a k32 step;
+//   * a slab (32 output features x 256 k, 32 KB) = feature tiles ft = 0, 1 x 8 k32 steps x 2 planes of 16 x 32 fragments -- exactly 32 rows of
+//     ffx16_pack(W, N, 256, perm 0), which therefore IS the weight stream; a macro-step = k32 step m = 4 fragments, 12 MFMAs into the quads
+//     q = 2 t + ft of the block's accumulator;
+//   * the accumulators leave through the same wave-private transpose (token-major rows of 32 features), written from the new layout.
+// tklb_kernel (d(ln1) with LayerNorm-1 backward; only on the levels abl_kernel does not serve) stays on tkl.hip.
+#include "common.h"
+#include "tokmma.h"
+#include "atkmma.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace ramp {
+
+namespace {
+constexpr int TK_SLAB = 32 * 1024;
+constexpr int TK_R = 4;
+constexpr int TK_TROW = 36;                             // floats per token row of the transpose scratch (32 + pad)
+constexpr int TK_T = TK_R * TK_SLAB;                    // per wave 32 x 36 floats
+constexpr int TK_BIAS = TK_T + 4 * 32 * TK_TROW * 4;    // bias (<= 768 floats)
+constexpr int TK_LN = TK_BIAS + 768 * 4;                // gamma | beta
+constexpr int TK_RB = TK_LN + 512 * 4;                  // row-variant bias rows (<= 4 x 256)
+constexpr size_t TK_LDS = (size_t)TK_RB + 4 * 256 * 4;
+static_assert(TK_LDS <= 160 * 1024, "LDS budget");
+}  // namespace
+
+// EPI: bit 0 residual, bit 1 row-variant bias.  ABL (diagnostic, ramp_bench_gemm): 1 no LDS-DMA, 2 no stores, 8 no barrier
+template <bool LN, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void tkl16_kernel(TklArgs a, int n_mt) {
+  constexpr int ABL = 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, gq = lane >> 4;
+  const int n_my = (n_mt - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // >= 1 (grid <= n_mt)
+  const int nblk = a.N >> 5;                                // 32-feature blocks = slabs per tile
+
+  const float s_in = scale_of(a.amax_in);
+  const float os = a.wsi / s_in;
+  float amax = 0.f;
+
+  // ---- weight ring (see ffx.hip): wave w copies bytes [8 w KB, 8 w KB + 8 KB) of every slab as 8 LDS-DMA pieces -------------
+  const char* wsrc = reinterpret_cast<const char*>(a.W) + wave * 8192 + lane * 16;
+  int is_q = 0, is_g = 0;
+  const char* cur_src = wsrc; unsigned cur_dst = 0;
+  auto dma_begin = [&]() __attribute__((always_inline)) {
+    cur_src = wsrc + (long)is_q * TK_SLAB;
+    cur_dst = (unsigned)(uintptr_t)(smem + (is_g & (TK_R - 1)) * TK_SLAB + wave * 8192);
+    is_q = is_q + 1 == nblk ? 0 : is_q + 1;
+    ++is_g;
+  };
+#define TK_PIECE(C) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" \
+                                 :: "v"(cur_src + ((C) >> 2) * 4096), "s"(cur_dst + ((C) >> 2) * 4096), "n"(((C) & 3) * 1024) : "memory", "m0")
+  auto piece_raw = [&](int c) __attribute__((always_inline)) {
+    switch (c) { case 0: TK_PIECE(0); break; case 1: TK_PIECE(1); break; case 2: TK_PIECE(2); break; case 3: TK_PIECE(3); break;
+                 case 4: TK_PIECE(4); break; case 5: TK_PIECE(5); break; case 6: TK_PIECE(6); break; default: TK_PIECE(7); break; }
+  };
+  auto dma_piece = [&](int c) __attribute__((always_inline)) { if (!(ABL & 1)) piece_raw(c); };
+  auto issue_slab = [&]() __attribute__((always_inline)) {
+    dma_begin();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) piece_raw(c);
+  };
+
+  u32x4 F[4][4];                                            // fragments of macro-step m in F[m & 3], read two steps ahead
+  int g = 0;
+  const char* rd = smem + lane * 16;
+  u32x4 XB[8][2][2];                                        // the wave's tokens as B operand: [k32 step][token half][plane]
+  f32x4 xn[2][16];                                          // the NEXT tile's rows, raw: [token half][2 ks + half]
+  f32x4 acc[2][4];                                          // two 32-feature blocks in flight: quads q = 2 t + ft (token half t, feature tile ft)
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // one slab = 8 macro-steps = 48 MFMAs into one accumulator.  Top of slab g: my pieces of slab g + 1 have landed (the only
+  // younger LDS-DMA are my 8 pieces of slab g + 2; the side work's loads and stores of slab g - 1 are younger too, so the wait
+  // covers some of them: measured a few tens of cycles in ffx.hip), barrier -> slab g + 1 certified, slot of slab g - 1 free
+  // (a slab of the 16 x 32-fragment planes: [feature tile ft][k32 step ks][plane], 1 KB each -- macro-step m = k32 step m reads the
+  // fragments [ft 0 hi, lo] at 2 m KB and [ft 1 hi, lo] at 16 KB + 2 m KB: ffx16_pack's layout is the weight stream as it is)
+#define T6_MM(ACC, FA, BB, Z) ACC = mm32(FA, BB, (Z) ? zero4 : ACC)
+  auto frag_at = [&](int slot_base, int m, int i) __attribute__((always_inline)) {      // fragment i (0, 1: ft 0 hi / lo; 2, 3: ft 1) of macro-step m
+    return rd + slot_base + (i >> 1) * 16384 + m * 2048 + (i & 1) * 1024;
+  };
+  auto slab = [&](f32x4 (&ac)[4], auto side) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dma_begin();
+    const int slot = g & (TK_R - 1), nslot = (g + 1) & (TK_R - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("" : "+a"(ac[q]));      // (4-register accumulators stay in place: ffx16.hip)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      u32x4 (&FB)[4] = F[m & 3];
+      u32x4 (&FN)[4] = F[(m + 2) & 3];
+      const int nb_ = m < 6 ? slot * TK_SLAB : nslot * TK_SLAB, nm = m < 6 ? m + 2 : m - 6;
+      const bool Z = m == 0;
+      __builtin_amdgcn_sched_barrier(0);
+      T6_MM(ac[0], FB[1], XB[m][0][0], Z);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_piece(m);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) FN[i] = *reinterpret_cast<const u32x4*>(frag_at(nb_, nm, i));
+      T6_MM(ac[2], FB[1], XB[m][1][0], Z);
+      T6_MM(ac[0], FB[0], XB[m][0][1], false); T6_MM(ac[2], FB[0], XB[m][1][1], false);
+      T6_MM(ac[0], FB[0], XB[m][0][0], false); T6_MM(ac[2], FB[0], XB[m][1][0], false);
+      T6_MM(ac[1], FB[3], XB[m][0][0], Z); T6_MM(ac[3], FB[3], XB[m][1][0], Z);
+      T6_MM(ac[1], FB[2], XB[m][0][1], false); T6_MM(ac[3], FB[2], XB[m][1][1], false);
+      T6_MM(ac[1], FB[2], XB[m][0][0], false); T6_MM(ac[3], FB[2], XB[m][1][0], false);
+      side(m);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 12, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ++g;
+  };
+
+  // rows of tile mt -> xn (lane (c, gq) holds k = 32 ks + 8 gq + i of the tokens 16 t + c); j = ks: an eighth of the 32 loads
+  auto x_load = [&](int mt, int j) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      long tok = (long)mt * 128 + wave * 32 + 16 * t + c;
+      tok = tok < a.M ? tok : a.M - 1;                      // (rows past M recompute row M - 1)
+      const float* xrow = a.X + tok * 256 + 8 * gq + 32 * j;
+      xn[t][2 * j] = *reinterpret_cast<const f32x4*>(xrow);
+      xn[t][2 * j + 1] = *reinterpret_cast<const f32x4*>(xrow + 4);
+    }
+  };
+
+  // ---- prologue: tables into LDS, the first tile's rows and three slabs in flight --------------------------------------------
+  {
+    float* bsw = reinterpret_cast<float*>(smem + TK_BIAS);
+    for (int i = tid; i < a.N; i += 256) bsw[i] = a.bias ? a.bias[i] : 0.f;
+    float* lns = reinterpret_cast<float*>(smem + TK_LN);
+    if (LN) { lns[tid] = a.ln_g[tid]; lns[256 + tid] = a.ln_b[tid]; }
+    if (EPI & 2) {
+      float* rbs = reinterpret_cast<float*>(smem + TK_RB);
+      for (int v = 0; v < a.n_var; ++v) rbs[v * 256 + tid] = a.rowbias[(long)v * a.rb_stride + tid];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x_load((int)blockIdx.x, j);
+  issue_slab(); issue_slab(); issue_slab();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // slab 0 (my share; the rows are older)
+  __syncthreads();                                           // (also publishes the tables)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { F[0][i] = *reinterpret_cast<const u32x4*>(frag_at(0, 0, i)); F[1][i] = *reinterpret_cast<const u32x4*>(frag_at(0, 1, i)); }
+
+  const int l8 = lane >> 3, c4 = 4 * (lane & 7);            // store layout: lane -> token 8 j + l8 of the wave, features c4 .. c4 + 3 of the block
+  float* tw = reinterpret_cast<float*>(smem + TK_T) + wave * 32 * TK_TROW;
+  float* tw_w = tw + c * TK_TROW + 4 * gq;                  // accumulator layout: quad q = 2 t + ft holds token 16 t + c, features 16 ft + 4 gq ..
+  const float* tw_r = tw + l8 * TK_TROW + c4;               // + 8 j rows
+  const float* bs = reinterpret_cast<const float*>(smem + TK_BIAS) + c4;
+  const float* lng = reinterpret_cast<const float*>(smem + TK_LN);
+  const float* lnb = lng + 256;
+
+  for (int ti = 0; ti < n_my; ++ti) {
+    const int mt = (int)blockIdx.x + ti * (int)gridDim.x;
+    const int mt_next = ti + 1 < n_my ? mt + (int)gridDim.x : mt;      // (last tile: re-reads its own rows, unused)
+
+    // ---- the wave's 32 tokens -> B-operand planes (through LayerNorm) --------------------------------------------------------
+    {
+      if (LN) {
+        float sum[2], ss[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float v = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v += (xn[t][i][0] + xn[t][i][1]) + (xn[t][i][2] + xn[t][i][3]);
+          sum[t] = v;
+        }
+        sum[0] = gsum(sum[0]); sum[1] = gsum(sum[1]);
+        const float mean0 = sum[0] * (1.f / 256.f), mean1 = sum[1] * (1.f / 256.f);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float mean = t ? mean1 : mean0;
+          float v = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = xn[t][i][e] - mean; v += d * d; }
+          ss[t] = v;
+        }
+        ss[0] = gsum(ss[0]); ss[1] = gsum(ss[1]);
+        const float rstd0 = 1.f / sqrtf(ss[0] * (1.f / 256.f) + 1e-5f), rstd1 = 1.f / sqrtf(ss[1] * (1.f / 256.f) + 1e-5f);
+        // one LDS base per tile (opaque) + immediate offsets (tkl.hip)
+        unsigned lgh = (unsigned)(uintptr_t)(lng + 8 * gq);
+        asm volatile("" : "+v"(lgh));
+        typedef __attribute__((address_space(3))) const char* lds_cptr_t;
+        typedef __attribute__((address_space(3))) const f32x4* lds_f4ptr_t;
+        const lds_cptr_t lgp = (lds_cptr_t)lgh;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = 32 * (i >> 1) + 4 * (i & 1);
+          const f32x4 gm = *(lds_f4ptr_t)(lgp + 4 * k), bt = *(lds_f4ptr_t)(lgp + 4 * (256 + k));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xn[0][i][e] = (xn[0][i][e] - mean0) * rstd0 * gm[e] + bt[e];
+            xn[1][i][e] = (xn[1][i][e] - mean1) * rstd1 * gm[e] + bt[e];
+          }
+          if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (keeps hipcc from hoisting all the table reads)
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          amax_pin(amax, xn[t][2 * ks][0], xn[t][2 * ks][1]); amax_pin(amax, xn[t][2 * ks][2], xn[t][2 * ks][3]);      // (pinned: see tokmma.h)
+          amax_pin(amax, xn[t][2 * ks + 1][0], xn[t][2 * ks + 1][1]); amax_pin(amax, xn[t][2 * ks + 1][2], xn[t][2 * ks + 1][3]);
+          split8(xn[t][2 * ks] * s_in, xn[t][2 * ks + 1] * s_in, XB[ks][t][0], XB[ks][t][1]);
+          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // rows this lane stores (and reads the residual of): token 8 j + l8 of the wave, clamped (rows past M rewrite row M - 1
+    // with the same bits: every lane issues every load and store)
+    // (addresses are formed where they are used, from a tile index hipcc cannot see through: as per-tile arrays of row
+    // pointers they were spilled and every slab reloaded them from scratch behind an s_waitcnt vmcnt(0))
+    int rbo[4] = {0, 0, 0, 0};                              // LDS offset of each row's variant constants
+    if (EPI & 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        long t = (long)mt * 128 + wave * 32 + 8 * j + l8;
+        t = t < a.M ? t : a.M - 1;
+        rbo[j] = a.rowvar[a.row0 + (int)(t / a.L)] * 256 + c4;
+      }
+    }
+    auto row_of = [&](int j) __attribute__((always_inline)) {
+      int mt_o = mt; asm volatile("" : "+s"(mt_o));
+      long t = (long)mt_o * 128 + wave * 32 + 8 * j + l8;
+      return t < a.M ? t : a.M - 1;
+    };
+
+    // epilogue of feature block pb (accumulator P), one step per macro-step of the next slab:
+    // 0 residual requested | 1 accumulators -> transpose scratch | 2 read back token-major | 3 bias, constants | 4..7 one store each
+    f32x4 rz[4], tv[4], bq, rbq[4];
+    auto epi = [&](const f32x4 (&P)[4], int pb, int st) __attribute__((always_inline)) {
+      if (st == 0) {
+        if (EPI & 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rz[j] = *reinterpret_cast<const f32x4*>(a.resid + row_of(j) * a.ldr + c4 + 32 * pb);
+        }
+      } else if (st == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(tw_w + 16 * (q >> 1) * TK_TROW + 16 * (q & 1)) = P[q];
+      } else if (st == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f32x4*>(tw_r + 8 * j * TK_TROW);
+      } else if (st == 3) {
+        bq = *reinterpret_cast<const f32x4*>(bs + 32 * pb);
+        if (EPI & 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rbq[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + TK_RB) + rbo[j] + 32 * pb);
+        }
+      } else {
+        const int j = st - 4;
+        f32x4 v = tv[j] * os + bq;
+        if (EPI & 2) v += rbq[j];
+        if (EPI & 1) v += rz[j];
+        if (!(ABL & 2) || mt < 0) *reinterpret_cast<f32x4*>(a.Y + row_of(j) * a.ldy + c4 + 32 * pb) = v;
+      }
+    };
+    auto no_side = [](int) __attribute__((always_inline)) {};
+
+    // the tile's first eight slabs unrolled (each also fetches an eighth of the next tile's rows), the rest in pairs
+    slab(acc[0], [&](int m) __attribute__((always_inline)) { if (m == 0) x_load(mt_next, 0); });
+#define TK_EARLY(NB)                                                                                                                     \
+    if (NB < nblk) slab(acc[NB & 1], [&](int m) __attribute__((always_inline)) { if (m == 0) x_load(mt_next, NB); epi(acc[(NB - 1) & 1], NB - 1, m); }); \
+    else x_load(mt_next, NB)
+    TK_EARLY(1); TK_EARLY(2); TK_EARLY(3); TK_EARLY(4); TK_EARLY(5); TK_EARLY(6); TK_EARLY(7);
+#undef TK_EARLY
+#pragma unroll 1
+    for (int nb = 8; nb < nblk; nb += 2) {
+      slab(acc[0], [&](int m) __attribute__((always_inline)) { epi(acc[1], nb - 1, m); });
+      if (nb + 1 < nblk) slab(acc[1], [&](int m) __attribute__((always_inline)) { epi(acc[0], nb, m); });
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if ((nblk - 1) & 1) {
+#pragma unroll
+      for (int st = 0; st < 8; ++st) epi(acc[1], nblk - 1, st);
+    } else {
+#pragma unroll
+      for (int st = 0; st < 8; ++st) epi(acc[0], nblk - 1, st);
+    }
+    (void)no_side;
+  }
+#undef TK_PIECE
+#undef T6_MM
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may outlive the block
+
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  record_amax_block(a.amax_out, amax, reinterpret_cast<float*>(smem));      // (no LDS-DMA in flight: vmcnt(0) above)
+  if (lane == 0) {
+    if (a.range_flag && (!(amax * s_in < 60000.f) || (amax > 0.f && amax * s_in < 0.125f))) atomicMax(a.range_flag, a.site + 1);
+  }
+}
+
+
+int launch_tkl16(const TklArgs& a, hipStream_t s) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  RAMP_REQUIRE(a.M > 0 && a.N >= 32 && a.N <= 768 && a.N % 32 == 0 && a.X && a.Y && a.W, "tkl16: bad operand");
+  RAMP_REQUIRE(al16(a.X) && al16(a.Y) && al16(a.W) && al16(a.resid) && a.ldy % 4 == 0 && a.ldr % 4 == 0, "tkl16: operands must be 16-byte aligned");
+  RAMP_REQUIRE(!a.rowbias || (a.rowvar && a.N == 256 && a.n_var >= 1 && a.n_var <= 4 && a.L >= 1 && a.resid), "tkl16: row-variant bias needs N = 256, <= 4 variants, a residual");
+  RAMP_REQUIRE(!a.ln_g == !a.ln_b, "tkl16: LayerNorm needs gamma and beta");
+  RAMP_REQUIRE(a.ablate == 0, "tkl16: no ablation variants");
+  {   // rows past M are recomputed and rewritten from the inputs (unconditional stores): see launch_tkl
+    const size_t yb = ((size_t)(a.M - 1) * a.ldy + a.N) * 4;
+    RAMP_REQUIRE(!ranges_overlap(a.Y, yb, a.X, (size_t)a.M * 256 * 4) && !ranges_overlap(a.Y, yb, a.resid, a.resid ? ((size_t)(a.M - 1) * a.ldr + a.N) * 4 : 0),
+                 "tkl16: the output must not overlap the operand or the residual (no in-place use)");
+  }
+  const int n_mt = (a.M + 127) / 128;
+  const int nb = std::min(n_mt, device_cu_count());          // one 4-wave block per CU
+  const bool ln = a.ln_g != nullptr;
+  const int epi = (a.resid ? 1 : 0) | (a.rowbias ? 2 : 0);
+#define T6_GO(LNV, E) hipLaunchKernelGGL((tkl16_kernel<LNV, E>), dim3(nb), dim3(256), TK_LDS, s, a, n_mt)
+  if (ln && epi == 0) T6_GO(true, 0);
+  else if (!ln && epi == 0) T6_GO(false, 0);
+  else if (!ln && epi == 1) T6_GO(false, 1);
+  else if (!ln && epi == 3) T6_GO(false, 3);
+  else RAMP_REQUIRE(false, "tkl16: variant not built");
+#undef T6_GO
+  RAMP_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int init_tkl16_attributes() {
+#define T6_ATTR(LNV, E) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tkl16_kernel<LNV, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS))
+  T6_ATTR(true, 0); T6_ATTR(false, 0); T6_ATTR(false, 1); T6_ATTR(false, 3);
+#undef T6_ATTR
+  return 0;
+}
+
+}  // namespace ramp

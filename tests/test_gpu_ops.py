@@ -410,9 +410,10 @@ def test_ffx_fused_feed_forward_against_float64_autograd(M, entry):
 
 @pytest.mark.parametrize("M,N,ln,epi", [(128, 768, True, 0), (293, 256, False, 3), (4173, 768, True, 0), (4173, 256, False, 0),
                                          (4173, 256, False, 1), (70000, 256, False, 3), (1000, 32, False, 1), (1000, 96, False, 1)])
-def test_tkl_token_owning_linear_against_float64(M, N, ln, epi):
-    """The token-owning K = 256 linear (tkl.hip; an opt-in launch plan, ramp_launch_plan.tkl_rows) through the C ABI
-    (ramp_op_tkl): LayerNorm(256) folded into the operand (LN1 -> QKV, layers_attention_mini.py:132), bias + residual +
+@pytest.mark.parametrize("entry", ["ramp_op_tkl16", "ramp_op_tkl"])
+def test_tkl_token_owning_linear_against_float64(M, N, ln, epi, entry):
+    """The token-owning K = 256 linear through the C ABI -- ramp_op_tkl16: the v_mfma_f32_16x16x32_f16 kernel the product runs (tkl16.hip,
+    round 6); ramp_op_tkl: the 32x32x16 kernel (tkl.hip, ramp_launch_plan.mfma16 = 0) -- LayerNorm(256) folded into the operand (LN1 -> QKV, layers_attention_mini.py:132), bias + residual +
     per-row-variant constant (the attention output projection with the block's cross-attention constant, :133-135), odd
     numbers of 32-feature blocks and M not a multiple of the 128-token tile, against float64; the recorded operand maximum is
     the true one and scaling from it leaves the result unchanged to rounding; a stale maximum raises the range flag."""
@@ -444,8 +445,8 @@ def test_tkl_token_owning_linear_against_float64(M, N, ln, epi):
 
     def go(prev):
         Y.fill_(float("nan"))
-        _lib.check(_lib.load().ramp_op_tkl(p(X), p(W), p(bias), p(resid), p(rowbias), p(rowvar), n_var if epi & 2 else 0, L, p(g), p(b),
-                                           M, N, prev, p(Y), C.byref(out), C.byref(flag), None), "ramp_op_tkl")
+        _lib.check(getattr(_lib.load(), entry)(p(X), p(W), p(bias), p(resid), p(rowbias), p(rowvar), n_var if epi & 2 else 0, L, p(g), p(b),
+                                               M, N, prev, p(Y), C.byref(out), C.byref(flag), None), entry)
         return rel(Y.double().cpu().numpy(), ref.cpu().numpy())
 
     e = go(0.0)
@@ -725,6 +726,8 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("token-owning fused feed-forward on 16x16x32 MFMAs, forward (ffx16)", 393216, 2048, 256, 1, 1, 6, 1 << 16, False),
     ("token-owning fused feed-forward on 16x16x32 MFMAs, backward (ffx16)", 393216, 2048, 256, 1, 1, 7, 1 << 16, False),
     ("token-owning LN1 -> QKV (tkl)", 393216, 768, 256, 1, 1, 8, 1, False),
+    ("token-owning LN1 -> QKV on 16x16x32 MFMAs (tkl16)", 393216, 768, 256, 1, 1, 8, 1 | (1 << 16), False),
+    ("token-owning d(o) on 16x16x32 MFMAs (tkl16)", 393216, 256, 256, 1, 1, 8, 1 << 16, False),
     ("token-owning out-projection with bias and residual (tkl)", 393216, 256, 256, 1, 1, 8, 2, False),
     ("token-owning d(ln1) with LayerNorm-1 backward (tklb)", 393216, 256, 768, 1, 1, 9, 0, False),
     ("self-attention fused with the out-projection, L = 48 (atk)", 393216, 256, 256, 1, 48, 10, 1, False),
@@ -764,6 +767,7 @@ SOAK_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags
     ("atb L=24", 196608, 256, 256, 1, 24, 13, 0), ("ffx forward", 393216, 2048, 256, 1, 1, 6, 0), ("ffx backward", 393216, 2048, 256, 1, 1, 7, 0),
     ("tkl LN1->QKV", 393216, 768, 256, 1, 1, 8, 1), ("tklb", 196608, 256, 768, 1, 1, 9, 0),
     ("ffx16 forward", 393216, 2048, 256, 1, 1, 6, 1 << 16), ("ffx16 backward", 393216, 2048, 256, 1, 1, 7, 1 << 16),
+    ("tkl16 LN1->QKV", 393216, 768, 256, 1, 1, 8, 1 | (1 << 16)),
 ]
 
 
