@@ -40,7 +40,9 @@ def main():
         for i, n, c, v, t in rows:
             if not (lo < i <= hi):
                 continue
-            m = re.search(r"ramp::(\w+)(<[^>]*>)?", n)
+            m = re.search(r"ramp::(?:\(anonymous namespace\)::)?(\w+)(<[^>]*>)?", n)
+            if not m:
+                continue
             k = m.group(1) + (m.group(2) or "")
             full[k] = n
             agg[k][c] += v; launches[k][c].add(i); dur[k][i] = t
