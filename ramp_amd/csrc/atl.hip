@@ -14,6 +14,9 @@
 // the d(ln1) call site: delayed power-of-two scale, recorded maximum, range guard like every other fp16x3 GEMM.  The LayerNorm backward
 // runs on the accumulators in the epilogue, one 16-token group at a time (its z rows stay in registers between the row sums and the outputs).
 // The points / waits of a head are described by abl_make_sched below: keep it in step with the kernel's issue order when either changes.
+// Round 6 (PK): k is NOT fetched a second time for dQ -- its fp16 planes from the S^T phase (48 registers at T = 48) wait in the accumulation half of
+// the register file, where MFMA A operands may live (12 of a head's 72 one-KB operand requests and one operand split less; the 54 accumulation
+// registers the kernel did not use made room).  Region A then carries q -> d(o) -> next q.  PK = false is the round-4 kernel (A/B twin).
 #include "common.h"
 #include "tokmma.h"
 #include "atkmma.h"
@@ -45,24 +48,24 @@ struct AblSched {
   int w_do, w_v, w_k, w_q;                              // before the region reads of d(o) (dV), v (dP), k (dQ), q (dK)
   int ops;                                              // operand pieces that found a point (must be all 6 streams x GR)
 };
-constexpr int abl_phase_pieces(int ph, int GR) { return ph == 0 ? GR : ph == 1 ? 2 * GR : ph == 2 ? GR / 2 : ph == 3 ? GR / 2 + GR : GR; }
-constexpr AblSched abl_make_sched(int NG) {
+constexpr int abl_phase_pieces(int ph, int GR, bool pk) { return ph == 0 ? GR : ph == 1 ? (pk ? GR : 2 * GR) : ph == 2 ? GR / 2 : ph == 3 ? GR / 2 + GR : GR; }
+constexpr AblSched abl_make_sched(int NG, bool pk) {
   const int GR = 4 * NG;
   AblSched r = {};
   int issued = 0, sl = 0;
   int ring_mark[AL_R] = {0, 0, 0};
   int mk_do = 0, mk_v = 0, mk_k = 0, mk_q = 0;
-  for (int p = 0; p < 4 * NG; ++p) if (p < abl_phase_pieces(0, GR)) { ++issued; ++r.ops; if (p == GR - 1) mk_do = issued; }
+  for (int p = 0; p < 4 * NG; ++p) if (p < abl_phase_pieces(0, GR, pk)) { ++issued; ++r.ops; if (p == GR - 1) mk_do = issued; }
   for (int ph = 1; ph <= 4; ++ph) {
     if (ph == 1) r.w_do = issued - mk_do;
     if (ph == 2) {
       r.w_v = issued - mk_v;
-      for (int p = 0; p < 2 * NG; ++p) if (p < abl_phase_pieces(2, GR)) { ++issued; ++r.ops; }
+      for (int p = 0; p < 2 * NG; ++p) if (p < abl_phase_pieces(2, GR, pk)) { ++issued; ++r.ops; }
       continue;
     }
     if (ph == 3) r.w_k = issued - mk_k;
     if (ph == 4) r.w_q = issued - mk_q;
-    const int np = abl_phase_pieces(ph, GR);
+    const int np = abl_phase_pieces(ph, GR, pk);
     int p = 0;
     auto pt = [&]() {
       if (p < np) {
@@ -87,7 +90,8 @@ constexpr AblSched abl_make_sched(int NG) {
   }
   return r;
 }
-static_assert(abl_make_sched(3).ops == 6 * 12 && abl_make_sched(2).ops == 6 * 8, "every operand piece of a head needs a point");
+static_assert(abl_make_sched(3, false).ops == 6 * 12 && abl_make_sched(2, false).ops == 6 * 8 && abl_make_sched(3, true).ops == 5 * 12 && abl_make_sched(2, true).ops == 5 * 8,
+              "every operand piece of a head needs a point");
 
 }  // namespace
 
@@ -126,7 +130,7 @@ int abl_pack(const float* W, float scale, unsigned short* out, hipStream_t s) {
 // that leaves the softmax phase only d(o) to fetch and gives v the whole dV phase to arrive.  Every slab issues the 4 ring pieces of slab
 // g + 2; the operand pieces ride on the "points" of all phases (see the schedule in the kernel).
 // STAMP (diagnostic twin, ramp_bench_gemm only): per-wave s_memtime sums of the phases
-template <int NG, bool STAMP = false>
+template <int NG, bool STAMP = false, bool PK = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void abl_kernel(AblArgs a, int n_tiles) {
   constexpr int T = 16 * NG;
@@ -288,7 +292,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
     // ---- the head's LDS-DMA schedule (abl_make_sched): the pieces ride on "points" spread over every phase of the head, because a CU sustains
     // ~1 KB per wave and ~360 cycles and a wave that issues faster than that stalls with all of its MFMA work behind it; a consumer waits
     // with vmcnt(requests issued behind its data).  Phase and point index are literals after unrolling.
-    constexpr AblSched SC = abl_make_sched(NG);
+    constexpr AblSched SC = abl_make_sched(NG, PK);
 #define AL_WAIT(N) do { switch (N) { \
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break; \
       case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;   case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break; \
@@ -308,7 +312,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
       if (ph == 0) { if (p < GR) op_piece(ra_dst, dob + hoff, 1024u, tile, p); }                              // d(o)      -> A
       else if (ph == 1) {
         if (p < GR) op_piece(rb_dst, qkvb + 2048 + hoff, 3072u, tile, p);                                     // v         -> B
-        else if (p < 2 * GR) op_piece(ra_dst, qkvb + 1024 + hoff, 3072u, tile, p - GR);                       // k again   -> A
+        else if (!PK && p < 2 * GR) op_piece(ra_dst, qkvb + 1024 + hoff, 3072u, tile, p - GR);                // k again   -> A (PK: its planes are parked)
       }
       else if (ph == 2) { if (p < GR / 2) op_piece(rb_dst, qkvb + hoff, 3072u, tile, p); }                    // q again   -> B, first half
       else if (ph == 3) {
@@ -443,9 +447,11 @@ void abl_kernel(AblArgs a, int n_tiles) {
     stamp(0);
     float sq = 0.f, sk = 0.f, sv = 0.f, sdo = 0.f, sds = 0.f;
     f32x4 pt[NG][NG];                                       // P^T: [key group][query group], keys in the registers, query on the lane
+    u32x4 kph[NG][2], kpl[NG][2];                           // PK: k's planes, parked in the accumulation half until dQ
     // ---- S^T = K Q^T -> P^T (softmax over keys, masked to the query's sample); d(o) -> A, one piece at each of its 4 NG points
     {
-      u32x4 qh[NG][2], ql[NG][2], kh[NG][2], kl[NG][2];
+      u32x4 qh[NG][2], ql[NG][2];
+      u32x4 (&kh)[NG][2] = kph; u32x4 (&kl)[NG][2] = kpl;
       { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sq, qh, ql); }
       { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sk, kh, kl); }
       __builtin_amdgcn_sched_barrier(0);
@@ -489,6 +495,12 @@ void abl_kernel(AblArgs a, int n_tiles) {
         for (int kg = 0; kg < NG; ++kg) pt[kg][qg] = st[kg] * inv;
         point(0, 4 * qg + 3);
       }
+    }
+    if (PK) {
+#pragma unroll
+      for (int t = 0; t < NG; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { asm volatile("" : "+a"(kph[t][j])); asm volatile("" : "+a"(kpl[t][j])); }
     }
     __builtin_amdgcn_sched_barrier(0);
     stamp(1);
@@ -589,8 +601,11 @@ void abl_kernel(AblArgs a, int n_tiles) {
     stamp(3);
     // ---- dQ^T = K^T dS^T / 8: A = k turned, B = dS^T (keys in the registers, query on the lane); its phases carry the rest of q -> B and the
     // NEXT head's q -> A
-    AL_WAIT(SC.w_k);                                        // k in A
-    {
+    if (PK) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) part_step(3, kph, kpl, sbh, sbl, j, 0.125f / (sk * sds));
+    } else {
+      AL_WAIT(SC.w_k);                                      // k in A
       u32x4 kh[NG][2], kl[NG][2];
       { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sk, kh, kl); }
       __builtin_amdgcn_sched_barrier(0);
@@ -740,6 +755,10 @@ int launch_abl(const AblArgs& a, hipStream_t s) {
     RAMP_REQUIRE(ng == 3, "abl: the stamped twin exists for T = 48");
     hipLaunchKernelGGL((abl_kernel<3, true>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
   }
+  else if (a.no_park) {
+    if (ng == 3) hipLaunchKernelGGL((abl_kernel<3, false, false>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
+    else hipLaunchKernelGGL((abl_kernel<2, false, false>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
+  }
   else if (ng == 3) hipLaunchKernelGGL((abl_kernel<3>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
   else hipLaunchKernelGGL((abl_kernel<2>), dim3(nb), dim3(256), AL_LDS, s, a, n_tiles);
   RAMP_HIP_CHECK(hipGetLastError());
@@ -750,6 +769,8 @@ int init_atl_attributes() {
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
   RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<3, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&abl_kernel<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AL_LDS));
   return 0;
 }
 

@@ -127,6 +127,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     const float host[4] = {4.f, 0.f, 0.f, 0.f};
     RAMP_HIP_CHECK(hipMemcpyAsync(slots, host, sizeof(host), hipMemcpyHostToDevice, sb));
     AblArgs t; t.M = M; t.L = L; t.QKV = Q; t.dO = D; t.W = ws; t.Z = Z; t.add = Ad; t.ln_g = gam; t.Y = Y;
+    t.no_park = (flags >> 16) & 1;                       // flags bit 16: the round-4 kernel that fetches k a second time (A/B twin, same bits)
     t.amax_in = slots; t.amax_out = slots + 1; t.wsi = 1.f / 16384.f; t.range_flag = nullptr;
     AtbArgs tb; tb.M = M; tb.L = L; tb.QKV = Q; tb.dO = D; tb.dQKV = G;
     TklbArgs tl; tl.M = M; tl.X = G; tl.Z = Z; tl.add = Ad; tl.Y = Y; tl.W = pl; tl.ln_g = gam;

@@ -250,6 +250,7 @@ struct AblArgs {
   const float* amax_in = nullptr; float* amax_out = nullptr; float wsi = 1.f; int site = 0;
   int* range_flag = nullptr;
   unsigned long long* stamps = nullptr; // diagnostic (ramp_bench_gemm): per wave 8 phase sums + 2 totals
+  int no_park = 0;                     // diagnostic A/B (ramp_bench_gemm): 1 = the round-4 kernel that fetches k a second time for dQ (same bits)
 };
 int launch_abl(const AblArgs& a, hipStream_t s);
 int abl_pack(const float* W /*[256][768] fp32, device*/, float scale, unsigned short* out /*48 * 16 KB*/, hipStream_t s);

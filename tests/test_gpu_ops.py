@@ -739,6 +739,7 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("attention backward on sample-owning waves, L = 24 (atb)", 196608, 256, 256, 1, 24, 13, 0, False),
     ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 48 (abl)", 393216, 256, 768, 1, 48, 15, 0, False),
     ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 12 (abl)", 98304, 256, 768, 1, 12, 15, 0, False),
+    ("attention backward + d(ln1) + LayerNorm-1 backward, k fetched twice (round-4 twin), L = 48 (abl)", 393216, 256, 768, 1, 48, 15, 1 << 16, False),
     ("wide 5-tap convolution 256x256 + GroupNorm + Mish + residual, L = 6 (tkw)", 49152, 256, 256, 5, 6, 17, 1 | 8, False),
     ("wide 5-tap convolution 128x128 input gradient with GroupNorm backward, L = 12 (tkw)", 98304, 128, 128, 5, 12, 17, 2 | 4 | 8, False),
     ("wide 5-tap convolution 256x256 input gradient with GroupNorm backward, L = 6 (tkw)", 49152, 256, 256, 5, 6, 17, 2 | 4, False),
