@@ -824,7 +824,7 @@ def test_ddpm_chain_on_outlier_channel_weights(gemm_mode):
     d = np.abs(chain - g["chain"]).reshape(26, -1).max(1)
     d64 = np.abs(g["chain"] - g["chain64"]).reshape(26, -1).max(1)
     print(f"   free-running: job ended as {dm.last_job_mode} (reruns +{dm.range_reruns - n_re}, bf16x6 fallbacks +{dm.range_fallbacks - n_fb}); "
-          f"|HIP - reference| per state {np.array2string(d[:6], precision=1)} ...; the reference's fp32 run vs its float64 twin {np.array2string(d64[:6], precision=1)} ...")
+          "|HIP - reference| per state " + " ".join(f"{v:.1e}" for v in d[:6]) + " ...; the reference's fp32 run vs its float64 twin " + " ".join(f"{v:.1e}" for v in d64[:6]) + " ...")
     assert np.isfinite(chain).all()
     assert dm.last_job_mode in (("fp16x3", "fp16x3-rerun") if mode == "fp16x3" else ("fp32",))
     assert d[1] < 1e-4 and d[2] < max(1e-4, 3.0 * d64[2])
@@ -1002,8 +1002,8 @@ def test_sharded_philox_jobs_at_config5_shape():
             tf.append(float((x - ref[j + 1, rows]).abs().max()))
     print(f"   teacher-forced from the unsharded job's states: worst step {max(tf):.2e}, mean {np.mean(tf):.2e}")
     assert max(tf) < 1e-4
-    # (3) free-running: 2 x measured (1.1e-3 on the round-6 library; the source is the chain, see the docstring)
-    assert d.max() < 2.2e-3 and bool(torch.isfinite(got).all())
+    # (3) free-running: 2 x the measured 5.5e-4 (round-6 library; the source is the chain, see the docstring)
+    assert d.max() < 1.1e-3 and bool(torch.isfinite(got).all())
 
 
 def test_predict_epsilon_false_and_the_public_helpers():
