@@ -50,7 +50,7 @@ __device__ __forceinline__ void sched_seq() {
 }
 
 // one launch: every block runs `n_slabs` slabs of 8 macro-steps
-template <int SHAPE, int V, bool DMA>
+template <int SHAPE, int V, bool DMA, int DPOS = -1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void probe_kernel(const unsigned short* __restrict__ wstream, const unsigned short* __restrict__ xb, float* __restrict__ out,
                   unsigned long long* __restrict__ stamps, int n_slabs) {
@@ -97,8 +97,11 @@ void probe_kernel(const unsigned short* __restrict__ wstream, const unsigned sho
         u32x4 (&FN)[4] = F[(m + 2 + FO) % 3];
         const char* np = rd + (m < 6 ? slot * SLAB + (m + 2) * 4096 : nslot * SLAB + (m - 6) * 4096);
         __builtin_amdgcn_sched_barrier(0);
-        if (DMA) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
-                              :: "v"(cur_src + (m >> 2) * 4096), "s"(cur_dst + (m >> 2) * 4096), "n"((m & 3) * 1024) : "memory", "m0");
+        auto dma_now = [&]() __attribute__((always_inline)) {
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
+                       :: "v"(cur_src + (m >> 2) * 4096), "s"(cur_dst + (m >> 2) * 4096), "n"((m & 3) * 1024) : "memory", "m0");
+        };
+        if (DMA && DPOS < 0) dma_now();                      // (ffx's place: ahead of the macro-step's reads; DPOS >= 0: behind MFMA DPOS instead)
         __builtin_amdgcn_sched_barrier(0);
         const int s = (2 * m + sub) & 15;
         // issue order written out and pinned gap by gap (sched_barrier(0) after every MFMA and its gap's share of the side work): the
@@ -110,6 +113,7 @@ void probe_kernel(const unsigned short* __restrict__ wstream, const unsigned sho
           const int nv = (i + 1) * V / n - i * V / n;
           for (int k = 0; k < nv; ++k, ++fv_i) fv[fv_i & 7] = __builtin_fmaf(fv[fv_i & 7], fm, fv[fv_i & 7]);
           __builtin_amdgcn_sched_barrier(0);
+          if (DMA && DPOS == i) { dma_now(); __builtin_amdgcn_sched_barrier(0); }
         };
         if constexpr (SHAPE == 0) {
           // fragments [a hi, a lo, b hi, b lo]; per pair: lo x hi, hi x lo, hi x hi (small terms first)
@@ -148,9 +152,9 @@ void probe_kernel(const unsigned short* __restrict__ wstream, const unsigned sho
 
 static unsigned short f2h(float f) { _Float16 h = (_Float16)f; unsigned short u; memcpy(&u, &h, 2); return u; }
 
-template <int SHAPE, int V, bool DMA>
+template <int SHAPE, int V, bool DMA, int DPOS = -1>
 static void run(const char* label, const unsigned short* w, const unsigned short* xb, float* out, unsigned long long* stamps, int ncu, double secs) {
-  auto k = probe_kernel<SHAPE, V, DMA>;
+  auto k = probe_kernel<SHAPE, V, DMA, DPOS>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, RING * SLAB));
   const int n_slabs = 96 * 12;                               // 12 "tiles" per block and launch
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -200,6 +204,14 @@ int main(int argc, char** argv) {
   RUN(1, 10, true, "16x16x32  + DMA + 10 VALU / macro-step (bwd)");
   RUN(0, 18, true, "32x32x16  + DMA + 18 VALU / macro-step (fwd)");
   RUN(1, 18, true, "16x16x32  + DMA + 18 VALU / macro-step (fwd)");
+  if (argc > 3) {                                            // DMA placement sweep on the 16-wide shape (the piece behind MFMA p of the macro-step's 12)
+    run<1, 10, true, 3>("16x16x32  + DMA behind MFMA 3  + 10 VALU", w, xb, out, stamps, ncu, secs);
+    run<1, 10, true, 7>("16x16x32  + DMA behind MFMA 7  + 10 VALU", w, xb, out, stamps, ncu, secs);
+    run<1, 10, true, 9>("16x16x32  + DMA behind MFMA 9  + 10 VALU", w, xb, out, stamps, ncu, secs);
+    run<1, 10, true, 11>("16x16x32  + DMA behind MFMA 11 + 10 VALU", w, xb, out, stamps, ncu, secs);
+    run<1, 18, true, 9>("16x16x32  + DMA behind MFMA 9  + 18 VALU", w, xb, out, stamps, ncu, secs);
+    run<1, 18, true, 11>("16x16x32  + DMA behind MFMA 11 + 18 VALU", w, xb, out, stamps, ncu, secs);
+  }
   RUN(0, 0, false, "32x32x16  mfma + lds reads (repeat)");
   RUN(1, 0, false, "16x16x32  mfma + lds reads (repeat)");
   return 0;
