@@ -12,7 +12,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libramp_hip.so")
 TOOLS_LIB = os.path.join(LIBDIR, "libramp_hip_tools.so")
 # the product library: kernels + engine.hip (context, schedule, sampler, graphs) + ops.hip (context-free kernel-level entry points)
-SOURCES = ["gemm.hip", "ffx.hip", "ffx16.hip", "tkl.hip", "tkl16.hip", "atk.hip", "atl.hip", "tkc.hip", "tkw.hip", "rowops.hip", "attention.hip", "sampler.hip", "scene.hip", "metrics.hip", "engine.hip", "ops.hip"]
+SOURCES = ["gemm.hip", "ffx.hip", "ffx16.hip", "tkl.hip", "tkl16.hip", "atk.hip", "atb.hip", "atl.hip", "tkc.hip", "tkw.hip", "rowops.hip", "attention.hip", "sampler.hip", "scene.hip", "metrics.hip", "engine.hip", "ops.hip"]
 # the tools library = the same objects + the micro-benchmark / stress harness (ramp_bench_gemm, ramp_stress_gemm): tests/ and ramp_amd/tools/ only
 TOOLS_SOURCES = ["bench.hip"]
 # default GEMM mode 2 = fp16x3 split with delayed operand scaling, 1 = bf16x6 split (both fp32-accurate, see gemm.hip);
@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # -ffp-contract=fast would fuse a*b - c*d into an FMA (HIP's __fmul_rn is a plain multiply), so it is off there.
 # ffx.hip: hipcc's SLP vectoriser pairs the GEGLU elements into v_pk_* instructions, which issue slower beside MFMAs and
 # bunch the elementwise work in front of a slab's first MFMA
-EXTRA_FLAGS = {"sampler.hip": ["-ffp-contract=off"], "ffx.hip": ["-fno-slp-vectorize"], "ffx16.hip": ["-fno-slp-vectorize"], "tkl.hip": ["-fno-slp-vectorize"], "tkl16.hip": ["-fno-slp-vectorize"], "atk.hip": ["-fno-slp-vectorize"], "atl.hip": ["-fno-slp-vectorize"], "tkc.hip": ["-fno-slp-vectorize"], "tkw.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"sampler.hip": ["-ffp-contract=off"], "ffx.hip": ["-fno-slp-vectorize"], "ffx16.hip": ["-fno-slp-vectorize"], "tkl.hip": ["-fno-slp-vectorize"], "tkl16.hip": ["-fno-slp-vectorize"], "atk.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"], "atb.hip": ["-fno-slp-vectorize"], "atl.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"], "tkc.hip": ["-fno-slp-vectorize"], "tkw.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(out: str, deps) -> bool:

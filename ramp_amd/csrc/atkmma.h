@@ -90,6 +90,16 @@ __device__ __forceinline__ void split4s(const f32x4 a, float s, u32x2& hi, u32x2
   hi = u32x2{h0, h1}; lo = u32x2{l0, l1};
 }
 __device__ __forceinline__ u32x4 cat2(const u32x2 a, const u32x2 b) { return u32x4{a[0], a[1], b[0], b[1]}; }
+// Between operand planes that split2m / split4s / split4m just wrote and the first MFMA that reads them: the low planes come out of INLINE ASM
+// (v_fma_mix*), which the compiler's hazard recogniser does not look into, and a vector write -> MFMA operand read needs two wait states.  With the
+// AGPR-form MFMAs of rounds 4-5 the accumulator's zero-initialisation (four v_accvgpr_write) happened to sit in that gap; a VGPR-form MFMA takes 0 as an
+// inline constant and follows the split at once -- ato's first query group read stale low planes of v (1e-4 errors on tokens 0-15 of every wave tile).
+// One s_nop 1, fenced so that nothing moves across it.
+__device__ __forceinline__ void planes_fence() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 1");
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 }  // namespace
 }  // namespace ramp

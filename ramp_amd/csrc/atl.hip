@@ -325,6 +325,13 @@ void abl_kernel(AblArgs a, int n_tiles) {
 
     // the projection of one k32 step of a gradient part: two slabs (output features [0, 128), [128, 256)); B = the gradient tile's planes.
     // Macro-step m = output block 8 half + m: first MFMA | this macro-step's LDS-DMA pieces | fragment reads of m + 1 | the other MFMAs
+    // Round 6: the projection's MFMAs are inline asm with the accumulator tied in the accumulation half ("+a"), so that the file can be compiled with
+    // -mllvm -amdgpu-mfma-vgpr-form: every OTHER MFMA of the kernel -- the ~190 small result tiles of a head that vector instructions consume at once --
+    // then writes VGPRs directly (the compiler pads those hazards itself) instead of AGPRs that have to be read back register by register: 28 % of the
+    // head's vector instructions were v_accvgpr_* (DESIGN section 8-2b).  Hazards of the asm, by the guide's table: an accumulate chain on the same
+    // accumulator needs no wait states; the B planes are compiler-written VGPRs -> `s_nop 1` opens every slab; the fragments come from ds_read (the compiler
+    // waits for the registers it hands in); the accumulators are read by vector instructions in the epilogue only -> `s_nop 11` + a scheduling fence there.
+#define AL_ACC(ACC, WA, WB) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(WA), "v"(WB))
     auto project = [&](const u32x4 (&bh)[NG], const u32x4 (&bl)[NG], int ph, int j) __attribute__((always_inline)) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -336,12 +343,13 @@ void abl_kernel(AblArgs a, int n_tiles) {
         const char* sl = rd + (sl_i % AL_R) * AL_SLAB;
         u32x4 wf[2][2];
         wf[0][0] = *reinterpret_cast<const u32x4*>(sl); wf[0][1] = *reinterpret_cast<const u32x4*>(sl + 1024);
+        asm volatile("s_nop 1" ::: "memory");                 // (a just-written B plane -> MFMA operand inside asm)
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           const int nb = 8 * half + m;
           const u32x4 wh = wf[m & 1][0], wl = wf[m & 1][1];
           __builtin_amdgcn_sched_barrier(0);
-          acc[nb][0] = mm32(wh, bl[0], acc[nb][0]);
+          AL_ACC(acc[nb][0], wh, bl[0]);
           __builtin_amdgcn_sched_barrier(0);
           if (!(m & 1)) ring_piece(m >> 1);
           if (m == 1 || m == 4 || m == 7) point(ph, 12 * j + 6 + 3 * half + m / 3);
@@ -350,18 +358,14 @@ void abl_kernel(AblArgs a, int n_tiles) {
             wf[(m + 1) & 1][0] = *reinterpret_cast<const u32x4*>(sl + ((m + 1) * 2) * 1024);
             wf[(m + 1) & 1][1] = *reinterpret_cast<const u32x4*>(sl + ((m + 1) * 2 + 1) * 1024);
           }
-          acc[nb][0] = mm32(wl, bh[0], acc[nb][0]);
-          acc[nb][0] = mm32(wh, bh[0], acc[nb][0]);
+          AL_ACC(acc[nb][0], wl, bh[0]);
+          AL_ACC(acc[nb][0], wh, bh[0]);
 #pragma unroll
           for (int t = 1; t < NG; ++t) {
-            f32x4 v = acc[nb][t];
-            v = mm32(wh, bl[t], v);
-            v = mm32(wl, bh[t], v);
-            v = mm32(wh, bh[t], v);
-            acc[nb][t] = v;
+            AL_ACC(acc[nb][t], wh, bl[t]);
+            AL_ACC(acc[nb][t], wl, bh[t]);
+            AL_ACC(acc[nb][t], wh, bh[t]);
           }
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 3 * NG - 1, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         ++gs;
@@ -397,6 +401,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
           xc = xn;
         }
       }
+      planes_fence();                                       // (the turned operand's low planes come out of inline asm: atkmma.h)
       u32x4 ah[2][2], al[2][2];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
@@ -454,7 +459,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
       u32x4 (&kh)[NG][2] = kph; u32x4 (&kl)[NG][2] = kpl;
       { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sq, qh, ql); }
       { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sk, kh, kl); }
-      __builtin_amdgcn_sched_barrier(0);
+      planes_fence();
       // (both regions are free: their rows are planes)
       const float ssc = 0.125f * 1.4426950408889634f / (sq * sk);
 #pragma unroll
@@ -516,7 +521,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
         pbh[0][qg] = cat2(ph[0], ph[1]); pbl[0][qg] = cat2(pl[0], pl[1]);
         pbh[1][qg] = NG == 3 ? cat2(ph[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u}; pbl[1][qg] = NG == 3 ? cat2(pl[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
       }
-      __builtin_amdgcn_sched_barrier(0);
+      planes_fence();
       u32x2 tph[NG][NG], tpl[NG][NG];                       // [query group][key group]
 #pragma unroll
       for (int qg = 0; qg < NG; ++qg)
@@ -542,7 +547,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
     // It needs neither v nor dS, so it comes first: its phases carry v -> B (for dP) and k -> A (for dQ)
     u32x4 doh[NG][2], dol[NG][2];
     { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sdo, doh, dol); }
-    __builtin_amdgcn_sched_barrier(0);
+    planes_fence();
 #pragma unroll
     for (int j = 0; j < 2; ++j) part_step(1, doh, dol, pqh, pql, j, 1.f / (sdo * 8192.f));
     __builtin_amdgcn_sched_barrier(0);
@@ -552,7 +557,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
     {
       u32x4 vh[NG][2], vl[NG][2];
       { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sv, vh, vl); }
-      __builtin_amdgcn_sched_barrier(0);
+      planes_fence();
       const float dsc = 1.f / (sv * sdo);
       float dmax = 0.f;
 #pragma unroll
@@ -597,7 +602,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
       sbh[0][qg] = cat2(sh[0], sh[1]); sbl[0][qg] = cat2(sl2[0], sl2[1]);
       sbh[1][qg] = NG == 3 ? cat2(sh[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u}; sbl[1][qg] = NG == 3 ? cat2(sl2[NG - 1], z2) : u32x4{0u, 0u, 0u, 0u};
     }
-    __builtin_amdgcn_sched_barrier(0);
+    planes_fence();
     stamp(3);
     // ---- dQ^T = K^T dS^T / 8: A = k turned, B = dS^T (keys in the registers, query on the lane); its phases carry the rest of q -> B and the
     // NEXT head's q -> A
@@ -608,7 +613,7 @@ void abl_kernel(AblArgs a, int n_tiles) {
       AL_WAIT(SC.w_k);                                      // k in A
       u32x4 kh[NG][2], kl[NG][2];
       { f32x4 raw[4][NG]; read_region(ra_rd, raw); finish(raw, sk, kh, kl); }
-      __builtin_amdgcn_sched_barrier(0);
+      planes_fence();
 #pragma unroll
       for (int j = 0; j < 2; ++j) part_step(3, kh, kl, sbh, sbl, j, 0.125f / (sk * sds));
     }
@@ -639,17 +644,20 @@ void abl_kernel(AblArgs a, int n_tiles) {
       AL_WAIT(SC.w_q);                                      // q in B
       u32x4 qh[NG][2], ql[NG][2];
       { f32x4 raw[4][NG]; read_region(rb_rd, raw); finish(raw, sq, qh, ql); }
-      __builtin_amdgcn_sched_barrier(0);
+      planes_fence();
 #pragma unroll
       for (int j = 0; j < 2; ++j) part_step(4, qh, ql, sqh, sql, j, 0.125f / (sq * sds));
     }
 #undef AL_WAIT
+#undef AL_ACC
   }
     // ================= epilogue of the tile: dz = add + LNbwd(d(ln1); z, gamma)  (rowops.hip ln_bwd_kernel; tklb_kernel's epilogue) ==========
     // lane (c, g) holds features 16 nb + 4 g + i of tokens 16 t + c: row sums = in-lane over (nb, i) + two shuffles over g.  One token group
     // at a time, so that its 64 z values per lane stay in registers between the sums and the outputs (z is read once); the next group's z
     // rows are requested before this group's outputs.
     {
+      asm volatile("s_nop 11" ::: "memory");                  // (the last asm MFMA's accumulator -> the epilogue's reads: 12 wait states behind an 8-pass MFMA)
+      __builtin_amdgcn_sched_barrier(0);
       derive();
       const float* gam = reinterpret_cast<const float*>(smem + AL_GAM) + 4 * g;
       const char* zb = reinterpret_cast<const char*>(a.Z);
