@@ -103,6 +103,7 @@ void atb_kernel(AtbArgs a, int n_tiles) {
   // turn the T-layout planes of one k32 step (two feature blocks) of ALL token groups into the planes with the feature on the lane and
   // the tokens in the registers: out[f][pair] = tokens of groups (0, 1) | (2, -) of feature block 2 j + f, as a k32-step A operand
   auto turn = [&](const u32x4 (&hi)[NG][2], const u32x4 (&lo)[NG][2], int j, u32x4 (&oh)[2][2], u32x4 (&ol)[2][2]) __attribute__((always_inline)) {
+    planes_fence();                                         // (asm-written low planes -> MFMA operand: atkmma.h; round 6, correct by construction)
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       u32x2 th[NG], tl[NG];
@@ -124,6 +125,7 @@ void atb_kernel(AtbArgs a, int n_tiles) {
   // the contracted token in the registers, [pair][free token group]); scaled and stored as rows of dqkv
   auto contract_store = [&](const u32x4 (&ah)[2][2], const u32x4 (&al)[2][2], const u32x4 (&bh)[2][NG], const u32x4 (&bl)[2][NG], int j, float oscale,
                             int col0) __attribute__((always_inline)) {
+    planes_fence();
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -153,6 +155,7 @@ void atb_kernel(AtbArgs a, int n_tiles) {
       finish(rawB, sk, kh, kl);
       issue(qb, roff, hoff + 2048, rawA); issue(ob, ooff, hoff, rawB);      // v, d(o): in flight during the scores and the softmax
       const float ssc = 0.125f * 1.4426950408889634f / (sq * sk);
+      planes_fence();
 #pragma unroll
       for (int qg = 0; qg < NG; ++qg) {
         f32x4 st[NG];
@@ -198,6 +201,7 @@ void atb_kernel(AtbArgs a, int n_tiles) {
       issue(qb, roff, hoff + 1024, rawA);                   // k again (L1 / L2; held since the first phase it would cost 96 registers): in flight during dP
       const float dsc = 1.f / (sv * sdo);
       float dmax = 0.f;
+      planes_fence();
 #pragma unroll
       for (int qg = 0; qg < NG; ++qg) {
         f32x4 dp[NG];
@@ -259,6 +263,7 @@ void atb_kernel(AtbArgs a, int n_tiles) {
     u32x4 pqh[2][NG], pql[2][NG], sqh[2][NG], sql[2][NG];   // [query-group pair][key group]
     {
       u32x2 tph[NG][NG], tpl[NG][NG], tsh[NG][NG], tsl[NG][NG];      // [query group][key group]
+      planes_fence();
 #pragma unroll
       for (int qg = 0; qg < NG; ++qg)
 #pragma unroll
