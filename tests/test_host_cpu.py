@@ -289,9 +289,18 @@ def test_token_owning_kernels_do_not_spill():
     # atl.hip (attention backward + d(ln1) + LayerNorm-1 backward): a handful of kernel-lifetime values may live in scratch (stored in the
     # prologue, reloaded at a tile's / the kernel's end), nothing more -- a reload inside a head would drain every LDS-DMA piece in flight
     atl = _kernel_notes("atl.o")
-    for pat, most in (("abl_kernelILi3ELb0E", 4), ("abl_kernelILi2ELb0E", 0)):
+    # (round 6: <NG, STAMP, PK>; the product variant parks k's planes (PK = 1) and, with the small MFMA result tiles in VGPRs, spills nothing)
+    for pat, most in (("abl_kernelILi3ELb0ELb1E", 0), ("abl_kernelILi2ELb0ELb1E", 0), ("abl_kernelILi3ELb0ELb0E", 4), ("abl_kernelILi2ELb0ELb0E", 0)):
         assert one(atl, pat)["vgpr_spill_count"] <= most, (pat, one(atl, pat))
-    for d in (ffx, tkl, atk, atl):
+        assert one(atl, pat)["private_segment_fixed_size"] <= 16 * (most > 0), (pat, one(atl, pat))
+    # round 6: the 16-wide token-owning kernels (what the product runs): no scratch in the fused feed-forward pair, LN1 -> QKV and d(o)
+    ffx16 = _kernel_notes("ffx16.o")
+    tkl16 = _kernel_notes("tkl16.o")
+    for pat in ("ffx16_kernelILb0ELi0E", "ffx16_kernelILb1ELi0E"):
+        assert one(ffx16, pat)["vgpr_spill_count"] == 0 and one(ffx16, pat)["private_segment_fixed_size"] == 0, (pat, one(ffx16, pat))
+    for pat in ("tkl16_kernelILb1ELi0E", "tkl16_kernelILb0ELi0E"):
+        assert one(tkl16, pat)["private_segment_fixed_size"] == 0, (pat, one(tkl16, pat))       # (LN variant: 8 values parked in spare AGPRs, no scratch)
+    for d in (ffx, tkl, atk, atl, ffx16, tkl16):
         for k, v in d.items():
             assert v["vgpr_count"] <= 512, (k, v)
 
