@@ -19,8 +19,11 @@ namespace ramp {
 
 namespace {
 
-constexpr int TC_XROWS = 48 + 2 * 6 + 2;                // rows of a wave's tile: T tokens + 2 zero rows in front of every sample and behind the last (L >= 8: <= 6 samples)
-constexpr int TC_SCR = 2048;                            // bytes of wave-private scratch behind the tiles (GroupNorm sums: 8 groups x 48 tokens)
+// rows of a wave's tile: T tokens + 2 zero rows in front of every sample and behind the last.  T = 48 / 32 (NG 3 / 2): L >= 8, <= 6 samples;
+// T = 64 (NG 4, round 6: the finest level of the H = 64 configurations): ONE sample of L = 64 tokens
+constexpr int tc_xrows(int NG) { return NG == 4 ? 64 + 2 + 2 : 48 + 2 * 6 + 2; }
+// bytes of wave-private scratch behind the tiles (GroupNorm sums: 8 groups x T tokens, then 8 x samples results)
+constexpr int tc_scr(int NG) { return NG == 4 ? 2304 : 2048; }
 
 __device__ __forceinline__ float tc_mish(float x) {     // rowops.hip mish_f
   const float e = __builtin_amdgcn_exp2f(fminf(x, 20.f) * 1.44269504088896340736f);
@@ -81,6 +84,8 @@ void tkc_kernel(TkcArgs a, int n_tiles) {
   constexpr int T = 16 * NG, K = 32 * KS, N = 16 * NB;
   constexpr int XROW = 4 * K + 16;                          // bytes of a tile row: hi plane (2 K) | lo plane (2 K) | 16 bytes of padding (bank spread)
   constexpr int WBYTES = 5 * NB * KS * 2048;
+  constexpr int TC_XROWS = tc_xrows(NG), TC_SCR = tc_scr(NG);
+  static_assert(8 * T * 4 + 8 * (NG == 4 ? 1 : 6) * 4 <= TC_SCR, "GroupNorm scratch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -386,13 +391,13 @@ void tkc_kernel(TkcArgs a, int n_tiles) {
 
 bool tkc_applicable(int M, int L, int N, int K, int* ng) {
   int n = 0;
-  if (L >= 8 && 48 % L == 0) n = 3; else if (L >= 8 && 32 % L == 0) n = 2;
+  if (L >= 8 && 48 % L == 0) n = 3; else if (L >= 8 && 32 % L == 0) n = 2; else if (L == 64 && !(N == 64 && K == 64)) n = 4;      // (64 x 64 at L = 64: 164 KB of LDS; no such layer)
   if (ng) *ng = n;
   return n != 0 && M > 0 && M % L == 0 && (N == 32 || N == 64) && (K == 32 || K == 64);
 }
 
 namespace {
-template <int NG, int NB, int KS> size_t tkc_lds() { return (size_t)5 * NB * KS * 2048 + 4 * (size_t)TC_XROWS * (4 * 32 * KS + 16) + 4 * TC_SCR; }
+template <int NG, int NB, int KS> size_t tkc_lds() { return (size_t)5 * NB * KS * 2048 + 4 * (size_t)tc_xrows(NG) * (4 * 32 * KS + 16) + 4 * tc_scr(NG); }
 template <int NG, int NB, int KS, int PRO, int EPI> int tkc_go(const TkcArgs& a, int n_tiles, hipStream_t s) {
   const size_t lds = tkc_lds<NG, NB, KS>();
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;         // blocks the LDS lets a CU hold (a block pays an 20-80 KB weight prologue: no more blocks than stay resident)
@@ -406,7 +411,7 @@ template <int NG, int NB, int KS, int PRO, int EPI> int tkc_go(const TkcArgs& a,
 int launch_tkc(const TkcArgs& a, hipStream_t s) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   int ng = 0;
-  RAMP_REQUIRE(tkc_applicable(a.M, a.L, a.N, a.K, &ng), "tkc: C_in, C_out in {32, 64}, tokens per sample >= 8 dividing 48 or 32, whole samples");
+  RAMP_REQUIRE(tkc_applicable(a.M, a.L, a.N, a.K, &ng), "tkc: C_in, C_out in {32, 64}, tokens per sample >= 8 dividing 48 or 32 (or 64, not 64 x 64 channels), whole samples");
   RAMP_REQUIRE(a.X && a.W && a.Y && (a.dir == 1 || a.dir == -1), "tkc: bad operand");
   RAMP_REQUIRE(al16(a.X) && al16(a.W) && al16(a.Y) && al16(a.bias) && al16(a.resid) && al16(a.resid2) && a.ldx % 4 == 0 && a.ldy % 4 == 0 &&
                a.ldr % 4 == 0 && a.ldr2 % 4 == 0 && a.ldx >= a.K && a.ldy >= a.N, "tkc: operands must be 16-byte aligned");
@@ -429,6 +434,12 @@ int launch_tkc(const TkcArgs& a, hipStream_t s) {
     TC_SHAPE(NGV, 0, 0) \
   }
   TC_CASE(3) TC_CASE(2)
+#undef TC_SHAPE
+#define TC_SHAPE(NGV, PROV, EPIV) \
+    if (a.N == 64 && a.K == 32) return tkc_go<NGV, 4, 1, PROV, EPIV>(a, n_tiles, s); \
+    if (a.N == 32 && a.K == 64) return tkc_go<NGV, 2, 2, PROV, EPIV>(a, n_tiles, s); \
+    if (a.N == 32 && a.K == 32) return tkc_go<NGV, 2, 1, PROV, EPIV>(a, n_tiles, s);
+  TC_CASE(4)
 #undef TC_CASE
 #undef TC_SHAPE
   RAMP_REQUIRE(false, "tkc: variant not built");
@@ -439,6 +450,7 @@ int init_tkc_attributes() {
 #define TC_ATTR(NGV, NBV, KSV) TC_ATTR1(NGV, NBV, KSV, 0, 0); TC_ATTR1(NGV, NBV, KSV, 1, 0); TC_ATTR1(NGV, NBV, KSV, 0, 1)
   TC_ATTR(3, 4, 2); TC_ATTR(3, 4, 1); TC_ATTR(3, 2, 2); TC_ATTR(3, 2, 1);
   TC_ATTR(2, 4, 2); TC_ATTR(2, 4, 1); TC_ATTR(2, 2, 2); TC_ATTR(2, 2, 1);
+  TC_ATTR(4, 4, 1); TC_ATTR(4, 2, 2); TC_ATTR(4, 2, 1);
 #undef TC_ATTR
 #undef TC_ATTR1
   return 0;

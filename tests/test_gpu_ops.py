@@ -613,7 +613,9 @@ def test_abl_per_sample_accuracy_under_a_magnitude_spread():
 
 
 @pytest.mark.parametrize("L,R,N,K,extras", [(48, 3, 32, 32, True), (48, 9, 64, 64, True), (24, 7, 64, 32, False), (24, 8, 32, 64, True), (12, 33, 64, 64, True),
-                                            (16, 5, 64, 64, False), (32, 3, 32, 32, True), (8, 41, 64, 64, True), (48, 4096, 32, 32, True)])
+                                            (16, 5, 64, 64, False), (32, 3, 32, 32, True), (8, 41, 64, 64, True), (48, 4096, 32, 32, True),
+                                            # round 6: L = 64 (the finest level of the H = 64 configurations): a wave owns ONE sample (tkc_kernel<NG = 4>)
+                                            (64, 5, 32, 32, True), (64, 3, 32, 64, True), (64, 9, 64, 32, False), (64, 2048, 32, 32, True)])
 @pytest.mark.parametrize("backward", [False, True])
 def test_tkc_narrow_convolution_against_float64(L, R, N, K, extras, backward):
     """The k = 5 convolutions with C_in, C_out in {32, 64} on sample-owning waves (tkc.hip, ramp_op_gemm_mode 5): Conv1d(padding 2) inside
@@ -736,6 +738,8 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("sample-owning 5-tap convolution 32x32 input gradient, L = 48 (tkc)", 393216, 32, 32, 5, 48, 12, 4, False),
     ("sample-owning 5-tap convolution 64x64 with GroupNorm + Mish and residual, L = 24 (tkc)", 196608, 64, 64, 5, 24, 12, 2 | 8, False),
     ("sample-owning 5-tap convolution 32x32 input gradient with GroupNorm backward, L = 48 (tkc)", 393216, 32, 32, 5, 48, 12, 4 | 16 | 2, False),
+    ("sample-owning 5-tap convolution 32x32 with GroupNorm + Mish and residual, L = 64 (tkc)", 524288, 32, 32, 5, 64, 12, 2 | 8, False),
+    ("sample-owning 5-tap convolution 64->32 input gradient with GroupNorm backward, L = 64 (tkc)", 524288, 64, 32, 5, 64, 12, 4 | 16 | 2, False),
     ("attention backward on sample-owning waves, L = 24 (atb)", 196608, 256, 256, 1, 24, 13, 0, False),
     ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 48 (abl)", 393216, 256, 768, 1, 48, 15, 0, False),
     ("attention backward + d(ln1) + LayerNorm-1 backward in one launch, L = 12 (abl)", 98304, 256, 768, 1, 12, 15, 0, False),
@@ -816,6 +820,8 @@ TKW_FWD = [   # L, K, N, samples, K1 (operand split) -- Conv1dBlock of the coars
     # the narrow levels: the same fusion on sample-owning waves (tkc.hip), wave tiles of 48 and of 32 tokens, partly empty last tiles
     (48, 32, 32, 7, 0), (24, 32, 64, 9, 0), (24, 64, 64, 11, 0), (48, 64, 32, 3, 0), (16, 32, 32, 5, 0), (8, 64, 64, 13, 0), (12, 64, 64, 9, 0),
     (32, 32, 64, 3, 0), (48, 64, 64, 300, 0),
+    # round 6: L = 64, one sample per wave
+    (64, 32, 32, 5, 0), (64, 64, 32, 3, 0), (64, 32, 32, 700, 0),
 ]
 
 
@@ -883,6 +889,8 @@ TKW_BWD = [   # L, K (= C_out of the forward layer), N (= C_in), samples, N1 (ou
     # the narrow levels (tkc.hip)
     (48, 32, 32, 7, 0), (24, 64, 32, 9, 0), (24, 64, 64, 11, 0), (48, 32, 64, 3, 0), (16, 32, 32, 5, 0), (8, 64, 64, 13, 0), (12, 64, 64, 9, 0),
     (32, 64, 32, 3, 0), (48, 64, 64, 300, 0),
+    # round 6: L = 64, one sample per wave
+    (64, 32, 32, 5, 0), (64, 32, 64, 3, 0), (64, 32, 32, 700, 0),
 ]
 
 
