@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -33,22 +34,40 @@ def _stale(out: str, deps) -> bool:
 
 
 def header_deps():
-    """Every shared header / include file a translation unit may pull in (csrc/*.h, csrc/*.inc, the public header) plus this
-    script (its flags): a change to any of them makes every object stale."""
+    """Every shared header / include file a translation unit may pull in (csrc/*.h, csrc/*.inc, the public headers) plus this
+    script (its flags)."""
     import glob
     hs = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")))
-    return hs + [os.path.join(HERE, "..", "include", "ramp_hip.h"), os.path.abspath(__file__)]
+    return hs + [os.path.join(HERE, "..", "include", "ramp_hip.h"), os.path.join(HERE, "..", "include", "ramp_hip_tools.h"), os.path.abspath(__file__)]
+
+
+_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def source_deps(path: str):
+    """The files ONE translation unit depends on: itself, every file its `#include "..."` lines reach (followed recursively, resolved
+    against the including file's directory, as hipcc does) and this script.  A kernel file includes core.h + its family's argument
+    header, so an edit to one family's arguments recompiles that family, engine.hip, ops.hip and bench.hip -- not every object."""
+    seen, todo = [], [os.path.normpath(path)]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        with open(f, encoding="utf-8") as fh:
+            for inc in _INCLUDE.findall(fh.read()):
+                todo.append(os.path.normpath(os.path.join(os.path.dirname(f), inc)))
+    return seen + [os.path.abspath(__file__)]
 
 
 def stale_sources(force: bool = False):
     """(source, object) pairs that build() would recompile now."""
     objdir = os.path.join(LIBDIR, "obj")
-    headers = header_deps()
     jobs = []
     for src in SOURCES + TOOLS_SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(op, [sp] + headers):
+        if force or _stale(op, source_deps(sp)):
             jobs.append((sp, op))
     return jobs
 

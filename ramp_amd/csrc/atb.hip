@@ -2,7 +2,7 @@
 // (ato_kernel) can be compiled with -mllvm -amdgpu-mfma-vgpr-form while this kernel -- 368 registers at T = 48, every MFMA result in the
 // accumulation half by the compiler's default -- keeps the code it was tuned with.  The product path reaches it only where abl_kernel is
 // switched off (RAMP_ABL=0) and through ramp_op_atb / the stress cases.
-#include "common.h"
+#include "args_attention.h"
 #include "tokmma.h"
 #include "atkmma.h"
 

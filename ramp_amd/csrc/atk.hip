@@ -22,7 +22,7 @@
 //   * the projection's weights (256 KB of fp16 planes) stream through an LDS ring in head order, 32 KB per slab = half a head's
 //     k range x 128 output features... (slab s = head s / 2, output features [128 (s & 1), +128)); 256 x T accumulators per wave.
 // Tokens past M are clamped for loads (finite garbage that is never stored).
-#include "common.h"
+#include "args_attention.h"
 #include "tokmma.h"
 #include "atkmma.h"
 

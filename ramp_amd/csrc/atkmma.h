@@ -1,6 +1,6 @@
 // 16 x 16 fp16x3 MFMA helpers shared by the sample-owning kernels (atk.hip, atl.hip)
 #pragma once
-#include "common.h"
+#include "core.h"
 #include "tokmma.h"
 
 namespace ramp {

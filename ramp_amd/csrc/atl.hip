@@ -17,7 +17,7 @@
 // Round 6 (PK): k is NOT fetched a second time for dQ -- its fp16 planes from the S^T phase (48 registers at T = 48) wait in the accumulation half of
 // the register file, where MFMA A operands may live (12 of a head's 72 one-KB operand requests and one operand split less; the 54 accumulation
 // registers the kernel did not use made room).  Region A then carries q -> d(o) -> next q.  PK = false is the round-4 kernel (A/B twin).
-#include "common.h"
+#include "args_attention.h"
 #include "tokmma.h"
 #include "atkmma.h"
 

@@ -15,7 +15,7 @@
 // global memory in MFMA layout (64 contiguous bytes per lane, k order permuted identically for A and B);
 // transposed operand access (V^T, K^T, dO^T, Q^T) goes through one [Lp][68] LDS tile per wave, reused
 // phase after phase, which also hosts the transposes: 13 KB per wave at L = 48 -> 12 waves per CU.
-#include "common.h"
+#include "args_attention.h"
 
 namespace ramp {
 

@@ -27,7 +27,8 @@
 // Arithmetic is the fp16x3 split of gemm.hip (two scaled fp16 planes per operand, h1h1' + h1h2' + h2h1', fp32 accumulate),
 // same delayed per-call-site scales, maxima recording and range guard: the kernels consume the call sites of the launches
 // they replace (forward: FF1, FF2; backward: d(hg), FF1-dX) in the same order.
-#include "common.h"
+#include "args_token.h"
+#include "pack.h"
 #include "tokmma.h"
 
 #include <algorithm>

@@ -24,7 +24,8 @@
 //   * the 4-register accumulators are pinned to the accumulation half of the file at the top of every loop trip
 //     (asm "+a"): hipcc leaves the 16-register accumulators of ffx.hip in place by itself (tied operands) but moves
 //     4-register ones through VGPRs at every back edge.
-#include "common.h"
+#include "args_token.h"
+#include "pack.h"
 #include "tokmma.h"
 #include "atkmma.h"
 

@@ -18,7 +18,7 @@
 //  * Epilogue through LDS: accumulators are transposed in LDS and leave as coalesced float4 rows;
 //    bias, per-row-variant bias, up to two residuals, and the GEGLU forward / backward elementwise
 //    math are applied there (no separate elementwise passes over the 2048-wide hidden).
-#include "common.h"
+#include "args_gemm.h"
 
 #include <algorithm>
 

@@ -2,7 +2,7 @@
 // (scripts/inference/core/metrics.py:8-81 of the reference): AABB collision intensity, path length, velocity
 // smoothness per trajectory, and the waypoint variance (variance of ALL B x B entries of the strictly-upper-
 // triangular pairwise distance matrix, per waypoint, summed over waypoints).
-#include "common.h"
+#include "args_sampler.h"
 
 namespace ramp {
 

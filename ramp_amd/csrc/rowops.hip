@@ -9,7 +9,7 @@
 //   last conv (32 -> S, 1x1) fwd + energy-gradient seed  UnetInference.py:142-145, 26-27
 //
 // All reductions are deterministic (fixed shuffle / LDS trees, no float atomics).
-#include "common.h"
+#include "args_rows.h"
 
 namespace ramp {
 
@@ -346,7 +346,7 @@ int launch_geglu_bwd(const float* dhg, const float* ag, float* dag, int n_tok, i
 }
 
 // ------------------------------------------------------------------------------------------
-// stride-2 resampling convolutions (generic gather form, see common.h)
+// stride-2 resampling convolutions (generic gather form, see args_rows.h)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
   extern __shared__ float xs[];                         // Lin * Cin

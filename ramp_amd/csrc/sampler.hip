@@ -11,7 +11,7 @@
 // These kernels are HBM-bound elementwise work; every product/sum is written with explicit
 // round-to-nearest intrinsics in the reference's own evaluation order so that no FMA contraction
 // changes a rounding (the x0 clamp makes borderline elements sensitive to single ulps).
-#include "common.h"
+#include "args_sampler.h"
 
 #include <algorithm>
 

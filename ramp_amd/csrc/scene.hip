@@ -1,7 +1,7 @@
 // Scene encoders in HIP (run once per scene): the 2-D ObstacleEncoderSet (obstacle_encoder.py:52-152) and the
 // 3-D ObstacleEncoder in eval mode (obstacle_encoder3d.py:5-94).  0.7 GFLOP per scene — small generic kernels,
 // the dense linears reuse the exact-fp32 MFMA GEMM of gemm.hip.  All reductions are deterministic.
-#include "common.h"
+#include "args_scene.h"
 
 namespace ramp {
 

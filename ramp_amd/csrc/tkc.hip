@@ -10,7 +10,7 @@
 // c's shifted row).  The whole weight (5 taps x C_out x C_in as fp16 fragment planes, <= 80 KB) is resident in LDS for the block's lifetime --
 // no ring, no barrier after the prologue.  D^T[c_out][token] accumulates in 16 x 16 tiles; the next tile's rows are fetched into registers
 // while the current tile computes.  fp16x3 products, delayed operand scale / maxima / range guard of ONE call site, like every other GEMM.
-#include "common.h"
+#include "args_conv.h"
 #include "tokmma.h"
 
 #include <algorithm>
@@ -383,7 +383,7 @@ void tkc_kernel(TkcArgs a, int n_tiles) {
     }
   amax = fmaxf(amax, __shfl_xor(amax, 32)); amax = fmaxf(amax, __shfl_xor(amax, 16)); amax = fmaxf(amax, __shfl_xor(amax, 8));
   amax = fmaxf(amax, __shfl_xor(amax, 4)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 1));
-  // ONE atomic per block, behind a plain read of the slot (2048 same-address atomics at the tail of a 20-40 us launch cost 20 us: common.h)
+  // ONE atomic per block, behind a plain read of the slot (2048 same-address atomics at the tail of a 20-40 us launch cost 20 us: core.h)
   __syncthreads();
   // (exact mode: every tile was scaled from its own maximum -- nothing can be out of range, and s_in is just the LAST tile's scale: no guard)
   record_amax_block_guarded<true>(a.amax_out, amax, reinterpret_cast<float*>(smem + WBYTES), exact ? nullptr : a.range_flag, s_in, a.site);

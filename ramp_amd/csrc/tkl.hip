@@ -16,7 +16,7 @@
 //     at the tile switch);
 //   * the packed fp16 planes of the tile kernels ([row / 32][k / 16][plane][lane][8], launch_pack_h3) ARE the weight stream.
 // LayerNorm runs on the registers the tile holds anyway (ln_fwd and its round trip disappear from the fp16x3 evaluations).
-#include "common.h"
+#include "args_token.h"
 #include "tokmma.h"
 
 #include <algorithm>

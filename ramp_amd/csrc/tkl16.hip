@@ -8,7 +8,7 @@
 //     q = 2 t + ft of the block's accumulator;
 //   * the accumulators leave through the same wave-private transpose (token-major rows of 32 features), written from the new layout.
 // tklb_kernel (d(ln1) with LayerNorm-1 backward; only on the levels abl_kernel does not serve) stays on tkl.hip.
-#include "common.h"
+#include "args_token.h"
 #include "tokmma.h"
 #include "atkmma.h"
 

@@ -21,7 +21,7 @@
 // Operand channels beyond 256 are staged in chunks (K = 512: the concatenated input of ups.0.0, two sources); outputs beyond 128 MB channels
 // run as passes over the same staged tile (N = 512: the split input gradient of ups.0.0).
 // fp16x3 products, delayed operand scale / recorded maximum / range guard of ONE call site, like every other GEMM of the library.
-#include "common.h"
+#include "args_conv.h"
 #include "tokmma.h"
 
 #include <algorithm>

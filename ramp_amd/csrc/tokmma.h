@@ -1,7 +1,7 @@
 // Shared pieces of the token-owning kernels (ffx.hip, tkl.hip): vector types, the fp16x3 operand split, the delayed scale,
 // Phi / phi for GEGLU, the 32x32x16 fp16 MFMA.
 #pragma once
-#include "common.h"
+#include "core.h"
 
 namespace ramp {
 

@@ -306,15 +306,28 @@ def test_token_owning_kernels_do_not_spill():
 
 
 def test_touching_a_shared_header_marks_its_objects_stale():
-    """build(force=False) must recompile when ANY shared header changes (round-3 review: tokmma.h was missing from the
-    dependency list, so an edit of the token-owning kernels' helpers left ffx.o / tkl.o stale)."""
+    """build(force=False) must recompile what a header edit reaches (round-3 review: tokmma.h was missing from the dependency list,
+    so an edit of the token-owning kernels' helpers left ffx.o / tkl.o stale) -- and, since round 6, ONLY that: build.py follows the
+    `#include "..."` lines of every translation unit, a kernel file includes core.h + its family's argument header, so an edit to the
+    token-owning kernels' helpers leaves the sampler, the row kernels and the tile GEMMs alone."""
     from ramp_amd import build as B
     deps = [os.path.basename(p) for p in B.header_deps()]
-    for h in ("common.h", "tokmma.h", "gemm_x6p_body.inc", "ramp_hip.h", "build.py"):
+    for h in ("common.h", "core.h", "tokmma.h", "gemm_x6p_body.inc", "ramp_hip.h", "ramp_hip_tools.h", "build.py"):
         assert h in deps, (h, deps)
     csrc = os.path.join(ROOT, "ramp_amd", "csrc")
     on_disk = {f for f in os.listdir(csrc) if f.endswith((".h", ".inc"))}
     assert on_disk <= set(deps), on_disk - set(deps)
+    # what one translation unit reaches
+    per_tu = {src: {os.path.basename(d) for d in B.source_deps(os.path.join(csrc, src))} for src in B.SOURCES + B.TOOLS_SOURCES}
+    assert {"core.h", "args_token.h", "pack.h", "tokmma.h", "build.py"} <= per_tu["ffx.hip"] and "args_sampler.h" not in per_tu["ffx.hip"]
+    assert {"gemm_x6p_body.inc", "args_gemm.h", "pack.h"} <= per_tu["gemm.hip"] and "tokmma.h" not in per_tu["gemm.hip"]
+    assert per_tu["sampler.hip"] == {"sampler.hip", "args_sampler.h", "core.h", "build.py"}
+    for src in ("engine.hip", "ops.hip", "bench.hip"):      # the files that see every family
+        assert {"common.h", "engine_util.h", "ramp_hip.h"} | {h for h in on_disk if h.startswith("args_")} <= per_tu[src], src
+    assert "ramp_hip_tools.h" in per_tu["bench.hip"]
+    for src, d in per_tu.items():                           # every header on disk is reached by somebody; nobody includes a file that is not there
+        assert src in d
+    assert on_disk <= set().union(*per_tu.values()), on_disk - set().union(*per_tu.values())
     B.build(force=False, verbose=False)                     # everything current first
     assert B.stale_sources() == []
     hdr = os.path.join(csrc, "tokmma.h")
@@ -323,7 +336,9 @@ def test_touching_a_shared_header_marks_its_objects_stale():
         newest = max(os.path.getmtime(op) for _, op in B.stale_sources(force=True))
         os.utime(hdr, (newest + 10, newest + 10))           # "edited after the last build"
         stale = {os.path.basename(sp) for sp, _ in B.stale_sources()}
-        assert {"ffx.hip", "tkl.hip"} <= stale, stale
+        assert stale == {src for src, d in per_tu.items() if "tokmma.h" in d}, stale
+        assert {"ffx.hip", "ffx16.hip", "tkl.hip", "tkl16.hip", "atk.hip", "atl.hip", "tkc.hip", "tkw.hip"} <= stale, stale
+        assert not ({"sampler.hip", "rowops.hip", "gemm.hip", "scene.hip", "metrics.hip", "engine.hip"} & stale), stale
     finally:
         os.utime(hdr, (st.st_atime, st.st_mtime))
     assert B.stale_sources() == []
