@@ -558,13 +558,14 @@ def main():
             "frac_ffx": achieved / peak, "frac_definition": "dominant kernel pair (fused feed-forward) since round 5; rounds 1-4: class_frac",
             "traffic": traffic, "traffic_source": traffic_src,
             "hbm_frac": (traffic / (avg_us * 1e-6) / 1e12 / PEAK_HBM_TBS) if traffic else None,
-            "kernel": "ramp::ffx16_kernel<BWD = false | true> (ffx16.hip, v_mfma_f32_16x16x32_f16; ramp_launch_plan.mfma16 = 0: ramp::ffx_kernel, "
+            "kernel": "ramp::ffx16_kernel<BWD = false | true> + its half-tile twin ramp::ffx16h_kernel for the last round of the L = 6 level's launches "
+                      "(ffx16.hip, v_mfma_f32_16x16x32_f16; ramp_launch_plan.mfma16 = 0: ramp::ffx_kernel, "
                       "ffx.hip, 32x32x16): LN3 -> FF1 -> GEGLU -> FF2 + residual and its input gradient as token-owning waves, all 16 transformer "
                       "blocks, forward and dX; 1.573 MFLOP (algorithmic, fp32) per token and direction",
             "peak_note": "achieved = ALGORITHMIC fp32 FLOPs of the ffx launches (tokens x 1.573 MFLOP) / their summed HIP-event time on the "
                          "launch stream; peak = the pipe the kernel executes on, fp16 dense MFMA 2500 TFLOP/s, divided by the 3 fp16 "
                          "products it spends per fp32 product (833.3); recompute from profiles/r06_kernel_stats.csv: "
-                         "sum(tokens) x 1.573e6 / TotalDurationNs of the two ffx16_kernel rows",
+                         "sum(tokens) x 1.573e6 / TotalDurationNs of the two ffx16_kernel rows + the two ffx16h_kernel rows",
             "executed_fp16_tflops": FP16_PRODUCTS_PER_FP32 * achieved,
             "frac_vs_fp32_matrix_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
             "launches_per_step": fx_n, "avg_launch_us": avg_us,

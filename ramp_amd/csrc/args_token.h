@@ -22,6 +22,9 @@ struct FfxArgs {
   int* range_flag = nullptr;
   unsigned long long* stamps = nullptr; // diagnostic (ablate 64): per wave 4 cycle sums [slab-top wait, barrier, DMA issue, slab body]
   int ablate = 0;                      // diagnostic (ramp_bench_gemm only; wrong results): 1 no LDS-DMA after the first slabs, 2 no stash traffic, 4 no elementwise step, 8 no slab barrier
+  // ffx16.hip only: the launch's first token / first stash slot (set by launch_ffx16 for its half-tile launch) and the tiling policy --
+  // 0 auto (half tiles for a last round that would idle half of the CUs, and for launches of at most CUs / 2 tiles), 1 full tiles only, 2 half tiles only
+  int tok0 = 0, slot0 = 0, half_mode = 0;
 };
 int launch_ffx(const FfxArgs& f, bool bwd, hipStream_t s);
 // W [rows][cols] fp32 -> column-gathered copy (tmp, rows * cols floats) -> fragment-packed fp16 planes (out, 2 * rows * cols halves)

@@ -319,6 +319,7 @@ int ramp_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t taps, int32_t L, in
     FfxArgs f; f.M = M; f.X = z1; f.Z1 = z1; f.Y = out; f.stash = stash; f.ln_g = lg; f.ln_b = lb; f.Wstream = pk.stream_f; f.b1 = pk.b1_pk; f.b2 = b2;
     f.amax_in1 = sl; f.amax_out1 = sl + 4; f.wsi1 = pk.wsi_w1; f.amax_in2 = sl + 1; f.amax_out2 = sl + 5; f.wsi2 = pk.wsi_w2; f.site2 = 1;
     f.range_flag = reinterpret_cast<int*>(sl + 8); f.ablate = (flags >> 8) & 255;
+    f.half_mode = s16 ? (flags >> 17) & 3 : 0;          // flags bits 17-18 (ffx16.hip): 1 full tiles only, 2 half tiles only (0: launch_ffx16's own policy)
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ar6.alloc(256 * 4 * 6 * 2));
     if (f.ablate & 64) { RAMP_REQUIRE(stamps, "hipMalloc failed"); RAMP_HIP_CHECK(hipMemsetAsync(stamps, 0, 256 * 4 * 6 * 8, s6)); f.stamps = stamps; }
     FfxArgs g = f; g.X = dz; g.Wstream = pk.stream_b; g.amax_in1 = sl + 2; g.amax_out1 = sl + 6; g.wsi1 = pk.wsi_w2; g.amax_in2 = sl + 3; g.amax_out2 = sl + 7; g.wsi2 = pk.wsi_w1;

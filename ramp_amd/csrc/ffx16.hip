@@ -69,9 +69,15 @@ __device__ __forceinline__ void split2x(float x0, float x1, float s, unsigned& h
 }  // namespace
 
 // ABL: 0 the product; 1 = the packs through split2x (A/B twin, same bits: measured 0.4-0.9 % SLOWER, profiles/r06_ab_same_box.txt); 64 = whole-kernel clock stamp per wave (s_memtime / s_memrealtime) into f.stamps [block][wave][6] slots 4, 5
-template <bool BWD, int ABL = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void ffx16_kernel(FfxArgs f, int n_mt) {
+// NT: token halves of a wave.  2 = the kernel described above (a wave owns 32 tokens, a tile is 128).  1 = HALF TILES (ffx16h_kernel): a wave owns 16
+// tokens, a tile is 64 -- the same slabs with the second token half's MFMAs and elementwise work left out, i.e. more than half of a full tile's time
+// (the fragment reads no longer amortise over two MFMAs), but on twice as many CUs: launch_ffx16 turns the tiles of a last round that would leave
+// half of the CUs idle (the L = 6 level: 384 tiles on 256 CUs) into half tiles, so that round costs ~0.7 instead of 1 tile time.  n_mt counts the
+// launch's tiles of ITS kind; f.tok0 / f.slot0 (NT = 1) are its first token and its first stash slot (two half tiles share a 128-token slot).
+template <bool BWD, int ABL, int NT>
+__device__ __forceinline__ void ffx16_body(const FfxArgs& f, int n_mt) {
+  static_assert(NT == 1 || NT == 2, "token halves");
+  constexpr int NQ = 2 * NT;                               // accumulator quads q = 2 t + ft of a hidden unit
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,11 +127,11 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
     dma_begin();
   };
 
-  u32x4 XB[8][2][2];                                        // the wave's tokens as B operand: [k32 step][token half][plane]
-  f32x4 acc2[16][2];                                        // 256 features x 32 tokens: [feature tile][token half]
-  f32x4 acc1[2][BWD ? 1 : 2][4];                            // [unit parity][a, g (backward: d(hg))][quad q = 2 t + ft]
-  u32x4 HB[BWD ? 4 : 2][2];                                 // the second product's B operand: [(da / dg,) token half][plane]
-  f32x4 st1[BWD ? 4 : 1], st2[BWD ? 4 : 1];                 // backward: the stash of the unit E works on next
+  u32x4 XB[8][NT][2];                                       // the wave's tokens as B operand: [k32 step][token half][plane]
+  f32x4 acc2[16][NT];                                       // 256 features x 32 tokens: [feature tile][token half]
+  f32x4 acc1[2][BWD ? 1 : 2][NQ];                           // [unit parity][a, g (backward: d(hg))][quad q = 2 t + ft]
+  u32x4 HB[BWD ? 2 * NT : NT][2];                           // the second product's B operand: [(da / dg,) token half][plane]
+  f32x4 st1[BWD ? NQ : 1], st2[BWD ? NQ : 1];               // backward: the stash of the unit E works on next
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // The twelve MFMAs of a macro-step: fragments FB = [P hi, P lo, Q hi, Q lo]; per fragment pair the three product terms, small
@@ -150,24 +156,25 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
       //   backward P2A / P2B: feature tile nt = 8 (KIND - P2A) + m, P = the da step, Q = the dg step -> acc2[nt][t], B = HB[2 w + t]
       constexpr bool P1 = KIND == Q_P1A || KIND == Q_P1B;
       const bool Z = P1 && m == 0;
+      constexpr int T1 = NT - 1;                             // the second token half (NT = 1: none -- X1 / Y1 alias X0 / Y0 and are never used)
       f32x4* X0; f32x4* X1; f32x4* Y0; f32x4* Y1;
       const u32x4 (*BP)[2]; const u32x4 (*BQ)[2];
       if constexpr (!BWD) {
         if constexpr (P1) {
-          X0 = &acc1[par][0][KIND]; X1 = &acc1[par][0][2 + KIND]; Y0 = &acc1[par][1][KIND]; Y1 = &acc1[par][1][2 + KIND];
+          X0 = &acc1[par][0][KIND]; X1 = &acc1[par][0][2 * T1 + KIND]; Y0 = &acc1[par][1][KIND]; Y1 = &acc1[par][1][2 * T1 + KIND];
           BP = XB[m]; BQ = XB[m];
         } else {
-          X0 = &acc2[2 * m][0]; X1 = &acc2[2 * m][1]; Y0 = &acc2[2 * m + 1][0]; Y1 = &acc2[2 * m + 1][1];
+          X0 = &acc2[2 * m][0]; X1 = &acc2[2 * m][T1]; Y0 = &acc2[2 * m + 1][0]; Y1 = &acc2[2 * m + 1][T1];
           BP = HB; BQ = HB;
         }
       } else {
         if constexpr (P1) {
-          X0 = &acc1[par][0][0]; X1 = &acc1[par][0][2]; Y0 = &acc1[par][0][1]; Y1 = &acc1[par][0][3];
+          X0 = &acc1[par][0][0]; X1 = &acc1[par][0][2 * T1]; Y0 = &acc1[par][0][1]; Y1 = &acc1[par][0][2 * T1 + 1];
           BP = XB[m]; BQ = XB[m];
         } else {
           const int nt = 8 * (KIND - Q_P2A) + m;
-          X0 = &acc2[nt][0]; X1 = &acc2[nt][1]; Y0 = X0; Y1 = X1;
-          BP = HB; BQ = HB + 2;
+          X0 = &acc2[nt][0]; X1 = &acc2[nt][T1]; Y0 = X0; Y1 = X1;
+          BP = HB; BQ = HB + NT;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -178,15 +185,29 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
       // ---- one scheduling region: the four fragment reads, MFMAs 2..12 and this step's share of the elementwise work ----
 #pragma unroll
       for (int i = 0; i < 4; ++i) FN[i] = *reinterpret_cast<const u32x4*>(np + i * 1024);
+      if constexpr (NT == 2) {
       F6_MM(*X1, FB[1], BP[1][0], Z);
       F6_MM(*X0, FB[0], BP[0][1], false); F6_MM(*X1, FB[0], BP[1][1], false);
       F6_MM(*X0, FB[0], BP[0][0], false); F6_MM(*X1, FB[0], BP[1][0], false);
       F6_MM(*Y0, FB[3], BQ[0][0], Z); F6_MM(*Y1, FB[3], BQ[1][0], Z);
       F6_MM(*Y0, FB[2], BQ[0][1], false); F6_MM(*Y1, FB[2], BQ[1][1], false);
       F6_MM(*Y0, FB[2], BQ[0][0], false); F6_MM(*Y1, FB[2], BQ[1][0], false);
+      } else {      // one token half: the P and Q chains alternate (no MFMA reads the accumulator of the one before it)
+      F6_MM(*Y0, FB[3], BQ[0][0], Z);
+      F6_MM(*X0, FB[0], BP[0][1], false); F6_MM(*Y0, FB[2], BQ[0][1], false);
+      F6_MM(*X0, FB[0], BP[0][0], false); F6_MM(*Y0, FB[2], BQ[0][0], false);
+      }
       side(m);
       // issue order hints: one fragment read per 16-cycle MFMA gap (a second one saturates the LDS array beside it), up to two
       // vector instructions per gap (an MFMA holds the vector issue for 8 of its 16 cycles), what is left behind the last MFMA
+      if constexpr (NT == 1) {      // six MFMAs: a fragment read in four of the five gaps behind the first
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 12, 0);
+      } else {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
@@ -199,6 +220,7 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 12, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     ++g;
@@ -207,13 +229,15 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
   // the loop-carried accumulators stay where they are: see the header
   auto pin_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { asm volatile("" : "+a"(acc2[i][0])); asm volatile("" : "+a"(acc2[i][1])); }
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc2[i][t]));
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int j = 0; j < (BWD ? 1 : 2); ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) asm volatile("" : "+a"(acc1[p][j][q]));
+        for (int q = 0; q < NQ; ++q) asm volatile("" : "+a"(acc1[p][j][q]));
   };
 
   // ---- prologue: b1 into LDS, first three slabs in flight --------------------------------------------------------------
@@ -237,15 +261,18 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
 
   for (int ti = 0; ti < n_my; ++ti) {
     const int mt = (int)blockIdx.x + ti * (int)gridDim.x;
-    float* stash_w = f.stash + (((long)mt * 32) * 4 + wave) * 2048 + lane * 4;      // + unit * 8192 + (2 q + which) * 256
+    // NT = 2: tile mt = tokens 128 mt .., stash slot mt.  NT = 1: half tile mt of this launch = tokens tok0 + 64 mt .., the (mt & 1) half of slot slot0 + mt / 2
+    float* stash_w = NT == 2 ? f.stash + (((long)mt * 32) * 4 + wave) * 2048 + lane * 4      // + unit * 8192 + (2 q + which) * 256
+                             : f.stash + (((long)(f.slot0 + (mt >> 1)) * 32) * 4 + wave) * 2048 + lane * 4 + (mt & 1) * 1024;
+    const long tok_w = NT == 2 ? (long)mt * 128 + wave * 32 + c : (long)f.tok0 + (long)mt * 64 + wave * 16 + c;      // + 16 t
 
     // ---- the wave's 32 tokens -> B-operand planes (forward: through LayerNorm-3) ---------------------------------------
     // lane (c, gq) holds k = 32 ks + 8 gq + i of the tokens 16 t + c
     {
-      f32x4 xv[2][16];
+      f32x4 xv[NT][16];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        long tok = (long)mt * 128 + wave * 32 + 16 * t + c;
+      for (int t = 0; t < NT; ++t) {
+        long tok = tok_w + 16 * t;
         tok = tok < f.M ? tok : f.M - 1;
         const float* xrow = f.X + tok * 256 + 8 * gq;
 #pragma unroll
@@ -255,17 +282,18 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
         }
       }
       if (!BWD) {
-        float sum[2], ss[2];
+        float sum[NT], ss[NT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NT; ++t) {
           float a = 0.f;
 #pragma unroll
           for (int i = 0; i < 16; ++i) a += (xv[t][i][0] + xv[t][i][1]) + (xv[t][i][2] + xv[t][i][3]);
           sum[t] = a;
         }
-        sum[0] = gsum(sum[0]); sum[1] = gsum(sum[1]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NT; ++t) sum[t] = gsum(sum[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
           const float mean = sum[t] * (1.f / 256.f);
           float a = 0.f;
 #pragma unroll
@@ -274,22 +302,23 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
             for (int e = 0; e < 4; ++e) { const float d = xv[t][i][e] - mean; a += d * d; }
           ss[t] = a;
         }
-        ss[0] = gsum(ss[0]); ss[1] = gsum(ss[1]);
-        const float mean0 = sum[0] * (1.f / 256.f), mean1 = sum[1] * (1.f / 256.f);
-        const float rstd0 = 1.f / sqrtf(ss[0] * (1.f / 256.f) + 1e-5f), rstd1 = 1.f / sqrtf(ss[1] * (1.f / 256.f) + 1e-5f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ss[t] = gsum(ss[t]);
+        float mean_[NT], rstd_[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { mean_[t] = sum[t] * (1.f / 256.f); rstd_[t] = 1.f / sqrtf(ss[t] * (1.f / 256.f) + 1e-5f); }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = 32 * (i >> 1) + 8 * gq + 4 * (i & 1);
           const f32x4 gm = *reinterpret_cast<const f32x4*>(f.ln_g + k), bt = *reinterpret_cast<const f32x4*>(f.ln_b + k);      // (global: see ffx.hip)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            xv[0][i][e] = (xv[0][i][e] - mean0) * rstd0 * gm[e] + bt[e];
-            xv[1][i][e] = (xv[1][i][e] - mean1) * rstd1 * gm[e] + bt[e];
-          }
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xv[t][i][e] = (xv[t][i][e] - mean_[t]) * rstd_[t] * gm[e] + bt[e];
         }
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           amax_pin(amax1, xv[t][2 * ks][0], xv[t][2 * ks][1]); amax_pin(amax1, xv[t][2 * ks][2], xv[t][2 * ks][3]);
@@ -298,13 +327,15 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc2[i][0] = zero4; acc2[i][1] = zero4; }
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc2[i][t] = zero4;
 
     auto stash_load = [&](int u) __attribute__((always_inline)) {                           // backward: prefetch unit u's stash
       if (BWD) {
         const float* p = stash_w + (long)u * 8192;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           st1[BWD ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (2 * q) * 256));      // (read once)
           st2[BWD ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (2 * q + 1) * 256));
         }
@@ -312,7 +343,7 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
     };
     // E(u): the elementwise step between the two products, on acc1[par], cut into work items that the slabs of a group take one
     // at a time (E_step) -- ffx.hip's, on the quads q = 2 t + ft
-    f32x4 hq[BWD ? 8 : 4];                                   // forward: h quads; backward: [da quads | dg quads]
+    f32x4 hq[BWD ? 2 * NQ : NQ];                             // forward: h quads; backward: [da quads | dg quads]
     f32x4 ba[2], bg[2];                                      // forward: b1 of quad q in [q & 1], read a stage ahead
     f32x4 qa[2], qg[2], qt[2], qp[2], s1q, s2q;              // the quad in progress [q & 1]: a, g, t = 1 / (1 + p |g|) then Phi(g), phi(g)
     auto bias_load = [&](int u, int q) __attribute__((always_inline)) {      // quad q = features 16 (q & 1) + 4 gq .. + 3 of unit u
@@ -343,7 +374,7 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
             const float qq = qp[q & 1][e] * (poly * t);
             qt[q & 1][e] = qg[q & 1][e] >= 0.f ? 1.f - qq : qq;      // Phi(g)
           }
-          if (hf == 1) { if (q < 3) bias_load(u, q + 1); else bias_load(u < 31 ? u + 1 : 31, 0); }
+          if (hf == 1) { if (q < NQ - 1) bias_load(u, q + 1); else bias_load(u < 31 ? u + 1 : 31, 0); }
         } else {
 #pragma unroll
           for (int e = 2 * hf; e < 2 * hf + 2; ++e) {
@@ -366,7 +397,7 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
         const f32x4 d = acc1[par][0][q] * os1;
         const f32x4 da = d * st1[q], dg = d * st2[q];
         amax_pin(amax2, da[0], da[1]); amax_pin(amax2, da[2], da[3]); amax_pin(amax2, dg[0], dg[1]); amax_pin(amax2, dg[2], dg[3]);
-        if (!(ABL & 1)) { hq[q] = da * s_2; hq[4 + q] = dg * s_2; } else { hq[q] = da; hq[4 + q] = dg; }
+        if (!(ABL & 1)) { hq[q] = da * s_2; hq[NQ + q] = dg * s_2; } else { hq[q] = da; hq[NQ + q] = dg; }
       }
     };
     // B operand of token half t (backward: tt = 2 w + t): elements jj = 0..3 from the ft = 0 quad, 4..7 from the ft = 1 quad
@@ -383,9 +414,9 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
     auto E_step = [&](int u, int par, int idx, int n, int pack_from) __attribute__((always_inline)) {
       if constexpr (!BWD) {
 #pragma unroll
-        for (int it = 0; it < 28; ++it) {                    // q0: s0 h0, s0 h1, s1 h0, .. s2 h1; q1: ..; P0 h0, P0 h1; q2; q3; P1 h0, P1 h1
+        for (int it = 0; it < 14 * NT; ++it) {               // q0: s0 h0, s0 h1, s1 h0, .. s2 h1; q1: ..; P0 h0, P0 h1; (NT = 2:) q2; q3; P1 h0, P1 h1
           const bool is_pack = (it >= 12 && it < 14) || it >= 26;
-          int at = it * n / 28;
+          int at = it * n / (14 * NT);
           if (is_pack && at < pack_from) at = pack_from;
           if (at > n - 1) at = n - 1;
           if (at != idx) continue;
@@ -394,13 +425,13 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
         }
       } else {
 #pragma unroll
-        for (int it = 0; it < 9; ++it) {
-          int at = it < 4 ? it * pack_from / 4 : (it == 4 ? pack_from - 1 : pack_from + (it - 5) * (n - pack_from) / 4);
+        for (int it = 0; it < 2 * NQ + 1; ++it) {            // the NQ quads, the next unit's stash, the NQ packs [da t.., dg t..]
+          int at = it < NQ ? it * pack_from / NQ : (it == NQ ? pack_from - 1 : pack_from + (it - NQ - 1) * (n - pack_from) / NQ);
           if (at > n - 1) at = n - 1;
           if (at != idx) continue;
-          if (it < 4) quad_b(par, it);
-          else if (it == 4) { if (u + 1 < 32) stash_load(u + 1); }
-          else pack1(it - 5);
+          if (it < NQ) quad_b(par, it);
+          else if (it == NQ) { if (u + 1 < 32) stash_load(u + 1); }
+          else pack1(it - NQ - 1);
         }
       }
     };
@@ -408,7 +439,7 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
     // ---- the 32 hidden units, software-pipelined: P2(k - 1), P1(k + 1) and E(k) share a group (ffx.hip) ------------------
     using KA = std::integral_constant<int, Q_P1A>; using KB = std::integral_constant<int, Q_P1B>;
     using KC = std::integral_constant<int, Q_P2A>; using KD = std::integral_constant<int, Q_P2B>;
-    using V8 = std::integral_constant<int, 8>; using V16 = std::integral_constant<int, 16>;
+    using V8 = std::integral_constant<int, 8>; using V16 = std::integral_constant<int, 8 + 2 * NQ>;      // (the slab's 8 pieces + the 2 NQ stash loads of a unit)
     pin_acc();
     if constexpr (!BWD) {
       slab(KA{}, QO<0>{}, 0, no_side, V8{}); slab(KB{}, QO<2>{}, 0, no_side, V8{});
@@ -441,7 +472,7 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
           const int k = kk + o, pe = 1 - o, pn = o;
           slab(KC{}, QO<1>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, m, 24, 16); }, V8{});
           slab(KD{}, QO<0>{}, 0, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 8 + m, 24, 16); }, V8{});
-          slab(KA{}, QO<2>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 16 + m, 24, 16); }, V16{});   // (8 stash loads + 8 pieces younger)
+          slab(KA{}, QO<2>{}, pn, [&](int m) __attribute__((always_inline)) { E_step(k, pe, 16 + m, 24, 16); }, V16{});   // (2 NQ stash loads + 8 pieces younger)
         }
       }
       pin_acc();
@@ -457,21 +488,24 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
     // (row addresses recomputed from an opaque copy of the tile index: ffx.hip)
     int mt_e = mt;
     asm volatile("" : "+s"(mt_e));
-    long tok_e[2];
+    long tok_e[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { tok_e[t] = (long)mt_e * 128 + wave * 32 + 16 * t + c; tok_e[t] = tok_e[t] < f.M ? tok_e[t] : f.M - 1; }
+    for (int t = 0; t < NT; ++t) {
+      tok_e[t] = (NT == 2 ? (long)mt_e * 128 + wave * 32 : (long)f.tok0 + (long)mt_e * 64 + wave * 16) + 16 * t + c;
+      tok_e[t] = tok_e[t] < f.M ? tok_e[t] : f.M - 1;
+    }
     if (!BWD) {
       const float* b2s = reinterpret_cast<const float*>(smem + F6_B2) + 4 * gq;
       // all 32 residual quads first, every store unconditional (tokens past M recompute and rewrite row M - 1 with the same bits)
-      f32x4 rz[2][16];
+      f32x4 rz[NT][16];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const float* zrow = f.Z1 + tok_e[t] * 256 + 4 * gq;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) rz[t][nt] = *reinterpret_cast<const f32x4*>(zrow + 16 * nt);
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         float* orow = f.Y + tok_e[t] * 256 + 4 * gq;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
@@ -484,7 +518,7 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
       // dz1 = dz + LNbwd(d(ln3); z1, gamma)   (rowops.hip, ln_bwd_kernel), one token half at a time
       const float* lgq = lng + 4 * gq;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const float* zrow = f.Z1 + tok_e[t] * 256 + 4 * gq;
         const float* drow = f.X + tok_e[t] * 256 + 4 * gq;
         float* orow = f.Y + tok_e[t] * 256 + 4 * gq;
@@ -553,6 +587,14 @@ void ffx16_kernel(FfxArgs f, int n_mt) {
     }
   }
 }
+
+template <bool BWD, int ABL = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void ffx16_kernel(FfxArgs f, int n_mt) { ffx16_body<BWD, ABL, 2>(f, n_mt); }
+// half tiles (NT = 1): see ffx16_body
+template <bool BWD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void ffx16h_kernel(FfxArgs f, int n_mt) { ffx16_body<BWD, 0, 1>(f, n_mt); }
 
 // ---- weights -------------------------------------------------------------------------------------------------------------
 // W [rows][cols] fp32 -> tmp [2 rows][cols / 2] such that launch_pack_h3(tmp) writes 16 x 32 fragments: its 32 x 16 fragment
@@ -634,15 +676,35 @@ int launch_ffx16(const FfxArgs& f, bool bwd, hipStream_t s) {
     const size_t yb = (size_t)f.M * 256 * 4;
     RAMP_REQUIRE(!ranges_overlap(f.Y, yb, f.X, yb) && !ranges_overlap(f.Y, yb, f.Z1, yb), "ffx16: the output must not overlap X or z1 (no in-place use)");
   }
-  const int n_mt = (f.M + 127) / 128;
-  const int nb = std::min(n_mt, device_cu_count());          // one 4-wave block per CU
-#define F6_GO(B, A) hipLaunchKernelGGL((ffx16_kernel<B, A>), dim3(nb), dim3(256), F6_LDS, s, f, n_mt)
-  if (f.ablate == 0) { if (bwd) F6_GO(true, 0); else F6_GO(false, 0); }
-  else if (f.ablate == 1) { if (bwd) F6_GO(true, 1); else F6_GO(false, 1); }
-  else if (f.ablate == 64) { if (bwd) F6_GO(true, 64); else F6_GO(false, 64); }
-  else RAMP_REQUIRE(false, "ffx16: ablation variant not built");
+  const int n_mt = (f.M + 127) / 128, cus = device_cu_count();          // one 4-wave block per CU
+  // tiling: full tiles of 128 tokens; the tiles of a last round that would leave half of the CUs idle -- and every tile of a launch that cannot fill half
+  // of them -- run as two half tiles of 64 tokens each (ffx16h_kernel: ~0.7 tile times on twice the CUs).  Forward and backward launches of one M take
+  // the same decision (the stash slots are addressed by it).
+  RAMP_REQUIRE(f.half_mode >= 0 && f.half_mode <= 2 && (f.half_mode == 0 || f.ablate == 0), "ffx16: bad tiling mode");
+  int n_full = n_mt;
+  if (f.half_mode == 2) n_full = 0;
+  else if (f.half_mode == 0 && f.ablate == 0) {
+    const int r = n_mt % cus;
+    if (2 * n_mt <= cus) n_full = 0;
+    else if (n_mt > cus && r > 0 && 2 * r <= cus) n_full = n_mt - r;
+  }
+#define F6_GO(B, A) hipLaunchKernelGGL((ffx16_kernel<B, A>), dim3(std::min(n_full, cus)), dim3(256), F6_LDS, s, f, n_full)
+  if (n_full > 0) {
+    if (f.ablate == 0) { if (bwd) F6_GO(true, 0); else F6_GO(false, 0); }
+    else if (f.ablate == 1) { if (bwd) F6_GO(true, 1); else F6_GO(false, 1); }
+    else if (f.ablate == 64) { if (bwd) F6_GO(true, 64); else F6_GO(false, 64); }
+    else RAMP_REQUIRE(false, "ffx16: ablation variant not built");
+    RAMP_HIP_CHECK(hipGetLastError());
+  }
 #undef F6_GO
-  RAMP_HIP_CHECK(hipGetLastError());
+  if (n_full < n_mt) {
+    FfxArgs h = f;
+    h.tok0 = n_full * 128; h.slot0 = n_full;
+    const int n_half = (f.M - h.tok0 + 63) / 64;
+    if (bwd) hipLaunchKernelGGL((ffx16h_kernel<true>), dim3(std::min(n_half, cus)), dim3(256), F6_LDS, s, h, n_half);
+    else hipLaunchKernelGGL((ffx16h_kernel<false>), dim3(std::min(n_half, cus)), dim3(256), F6_LDS, s, h, n_half);
+    RAMP_HIP_CHECK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -650,6 +712,8 @@ int init_ffx16_attributes() {
 #define F6_ATTR(B, A) RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffx16_kernel<B, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F6_LDS))
   F6_ATTR(false, 0); F6_ATTR(true, 0); F6_ATTR(false, 1); F6_ATTR(true, 1); F6_ATTR(false, 64); F6_ATTR(true, 64);
 #undef F6_ATTR
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffx16h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F6_LDS));
+  RAMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffx16h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F6_LDS));
   return 0;
 }
 

@@ -75,7 +75,7 @@ def main():
     for k, e in out.items():
         if not isinstance(e, dict) or "hbm_bytes" not in e:
             continue
-        for c in ([klass("ramp::" + k)] + (["ffx"] if k.startswith(("ffx_kernel", "ffx16_kernel")) else [])):
+        for c in ([klass("ramp::" + k)] + (["ffx"] if k.startswith(("ffx_kernel", "ffx16_kernel", "ffx16h_kernel")) else [])):
             if c is None:
                 continue
             q = cls.setdefault(c, {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})

@@ -11,7 +11,7 @@ import sys
 
 
 def klass(name):
-    if "gemm_x6" in name or "gemm_kernel" in name or "ff_fwd_kernel" in name or "ffx_kernel" in name or "ffx16_kernel" in name or "tkl_kernel" in name or "tkl16_kernel" in name or "tklb_kernel" in name \
+    if "gemm_x6" in name or "gemm_kernel" in name or "ff_fwd_kernel" in name or "ffx_kernel" in name or "ffx16_kernel" in name or "ffx16h_kernel" in name or "tkl_kernel" in name or "tkl16_kernel" in name or "tklb_kernel" in name \
             or "ato_kernel" in name or "abl_kernel" in name or "tkc_kernel" in name:      # (ato / abl: attention fused with a GEMM, counted with it)
         return "gemm"
     if "attn2" in name or "atb_kernel" in name:

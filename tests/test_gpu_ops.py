@@ -365,7 +365,9 @@ def test_fp16x3_dynamic_range_sweep(kind, wkind):
     assert flag != 0
 
 
-@pytest.mark.parametrize("M", [128, 293, 4173])
+# ffx16's tiling by M on a 256-CU device (launch_ffx16): 128, 293, 4173 -> half tiles only (at most CUs / 2 tiles: a wave owns 16 tokens, ffx16h_kernel);
+# 20000 -> full tiles only (157); 33000 -> 256 full tiles + the last round's 2 tiles as 4 half tiles, the very last one partly past M
+@pytest.mark.parametrize("M", [128, 293, 4173, 20000, 33000])
 @pytest.mark.parametrize("entry", ["ramp_op_ffx16", "ramp_op_ffx"])
 def test_ffx_fused_feed_forward_against_float64_autograd(M, entry):
     """The token-owning fused feed-forward kernels through the C ABI -- ramp_op_ffx16: the v_mfma_f32_16x16x32_f16 pair the
@@ -727,6 +729,10 @@ STRESS_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags, comp
     ("token-owning fused feed-forward, backward (ffx)", 393216, 2048, 256, 1, 1, 7, 0, False),
     ("token-owning fused feed-forward on 16x16x32 MFMAs, forward (ffx16)", 393216, 2048, 256, 1, 1, 6, 1 << 16, False),
     ("token-owning fused feed-forward on 16x16x32 MFMAs, backward (ffx16)", 393216, 2048, 256, 1, 1, 7, 1 << 16, False),
+    ("token-owning fused feed-forward, HALF tiles only, forward (ffx16h)", 393216, 2048, 256, 1, 1, 6, (1 << 16) | (2 << 17), False),
+    ("token-owning fused feed-forward, HALF tiles only, backward (ffx16h)", 393216, 2048, 256, 1, 1, 7, (1 << 16) | (2 << 17), False),
+    ("token-owning fused feed-forward, 256 full + 256 half tiles, forward (ffx16 + ffx16h)", 49152, 2048, 256, 1, 1, 6, 1 << 16, False),
+    ("token-owning fused feed-forward, 256 full + 256 half tiles, backward (ffx16 + ffx16h)", 49152, 2048, 256, 1, 1, 7, 1 << 16, False),
     ("token-owning LN1 -> QKV (tkl)", 393216, 768, 256, 1, 1, 8, 1, False),
     ("token-owning LN1 -> QKV on 16x16x32 MFMAs (tkl16)", 393216, 768, 256, 1, 1, 8, 1 | (1 << 16), False),
     ("token-owning d(o) on 16x16x32 MFMAs (tkl16)", 393216, 256, 256, 1, 1, 8, 1 << 16, False),
@@ -773,6 +779,7 @@ SOAK_CASES = [   # name, M, N, K, taps, L, mode (ramp_bench_gemm), flags
     ("tkl LN1->QKV", 393216, 768, 256, 1, 1, 8, 1), ("tklb", 196608, 256, 768, 1, 1, 9, 0),
     ("ffx16 forward", 393216, 2048, 256, 1, 1, 6, 1 << 16), ("ffx16 backward", 393216, 2048, 256, 1, 1, 7, 1 << 16),
     ("tkl16 LN1->QKV", 393216, 768, 256, 1, 1, 8, 1 | (1 << 16)),
+    ("ffx16h forward", 196608, 2048, 256, 1, 1, 6, (1 << 16) | (2 << 17)), ("ffx16h backward", 196608, 2048, 256, 1, 1, 7, (1 << 16) | (2 << 17)),
 ]
 
 

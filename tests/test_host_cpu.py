@@ -298,6 +298,8 @@ def test_token_owning_kernels_do_not_spill():
     tkl16 = _kernel_notes("tkl16.o")
     for pat in ("ffx16_kernelILb0ELi0E", "ffx16_kernelILb1ELi0E"):
         assert one(ffx16, pat)["vgpr_spill_count"] == 0 and one(ffx16, pat)["private_segment_fixed_size"] == 0, (pat, one(ffx16, pat))
+    for pat in ("ffx16h_kernelILb0E", "ffx16h_kernelILb1E"):      # the half-tile twins (a wave owns 16 tokens): the same, with room to spare
+        assert one(ffx16, pat)["vgpr_spill_count"] == 0 and one(ffx16, pat)["private_segment_fixed_size"] == 0, (pat, one(ffx16, pat))
     for pat in ("tkl16_kernelILb1ELi0E", "tkl16_kernelILb0ELi0E"):
         assert one(tkl16, pat)["private_segment_fixed_size"] == 0, (pat, one(tkl16, pat))       # (LN variant: 8 values parked in spare AGPRs, no scratch)
     for d in (ffx, tkl, atk, atl, ffx16, tkl16):
