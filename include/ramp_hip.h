@@ -335,7 +335,9 @@ int ramp_op_gemm_mode(const float* A, const float* W, const float* bias, const f
 int ramp_op_ffx(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
                 const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
                 float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
-/* the same operation on the v_mfma_f32_16x16x32_f16 kernel pair (ffx16.hip; ramp_launch_plan.mfma16 = 1, what the product runs) */
+/* the same operation on the v_mfma_f32_16x16x32_f16 kernel pair (ffx16.hip; ramp_launch_plan.mfma16 = 1, what the product runs).  Its tiling follows M and
+ * the device's CU count exactly as in a job: 128-token tiles, 64-token half tiles for a last round that would idle half of the CUs and for launches of at
+ * most CUs / 2 tiles (on 256 CUs: M <= 16384 half tiles only; M = 20000 full tiles only; M = 33000 or 49152 both). */
 int ramp_op_ffx16(const float* z1, const float* dz, const float* W1, const float* b1, const float* W2, const float* b2,
                   const float* ln_g, const float* ln_b, int32_t M, const float* absmax_prev_host, float* z2, float* dz1,
                   float* absmax_out_host, int32_t* range_flag_out_host, void* stream);
